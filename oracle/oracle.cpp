@@ -1,0 +1,403 @@
+/*
+ * oracle.cpp — CPU oracle (test infrastructure, see oracle.h for the rules and
+ * the parity status of each function).  Build: oracle/Makefile
+ *   g++ -O2 -ffp-contract=off -fno-fast-math  (no -march=native)
+ * so every float/double expression below rounds exactly like the reference
+ * build (plain x86-64 SSE2 arithmetic, no FMA contraction).
+ *
+ * Citations are relative to /root/reference/.
+ */
+#include "oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+namespace {
+
+/* ---- SDK helpers, src/sdk/src/sl_lidar_driver.cpp:102-126 ---------------- */
+inline float sdk_get_angle(const orc_node_t &nd) {
+  return nd.angle_z_q14 * 90.f / 16384.f; /* :104 */
+}
+inline void sdk_set_angle(orc_node_t &nd, float v) {
+  nd.angle_z_q14 = (uint16_t)(uint32_t)(v * 16384.f / 90.f); /* :109, u32 then u16 store */
+}
+inline uint32_t sdk_get_dist(const orc_node_t &nd) { return nd.dist_mm_q2; } /* :119 */
+bool sdk_angle_less(const orc_node_t &a, const orc_node_t &b) {              /* :123-126 */
+  return sdk_get_angle(a) < sdk_get_angle(b);
+}
+
+/* One point after LOOP 1 of publish_scan, src/rplidar_node.cpp:568-572. */
+struct PolarPoint {
+  float angle_rad;
+  float dist_m;
+  float intensity;
+};
+
+inline float node_dist_m(const orc_node_t &nd) { return nd.dist_mm_q2 / 4000.0f; } /* :590 */
+
+/* angle conversion + wrap of LOOP 1, src/rplidar_node.cpp:588-599 */
+inline float node_angle_rad(const orc_node_t &nd) {
+  float angle_deg = nd.angle_z_q14 * 90.0f / 16384.0f; /* :588 */
+  float angle_rad = angle_deg * (M_PI / 180.0f);       /* :589 double multiply, float store */
+  if (angle_rad < 0.0f) {                              /* :594 */
+    angle_rad += 2.0f * M_PI;
+  }
+  if (angle_rad >= 2.0f * M_PI) {                      /* :597 */
+    angle_rad -= 2.0f * M_PI;
+  }
+  return angle_rad;
+}
+
+inline float node_intensity(const orc_node_t &nd, bool is_new_protocol) { /* :591-592 */
+  return is_new_protocol ? static_cast<float>(nd.quality)
+                         : static_cast<float>(nd.quality >> 2);
+}
+
+/* invert rule of Mode A, src/rplidar_node.cpp:646-651 */
+inline float invert_angle(float angle) {
+  angle = (2.0f * M_PI) - angle;
+  if (angle >= 2.0f * M_PI) {
+    angle -= 2.0f * M_PI;
+  }
+  return angle;
+}
+
+/* E1 keep mask (extension). With clip_enable == 0 this is :584 alone. */
+inline bool keep_sample(const orc_node_t &nd, const orc_params_t &p) {
+  if (nd.dist_mm_q2 == 0) return false; /* :584 */
+  if (!p.clip_enable) return true;
+  if ((uint32_t)nd.quality < p.q_min) return false;
+  float dist_m = node_dist_m(nd);
+  if (!(dist_m >= p.range_min)) return false;
+  if (!(dist_m <= p.range_max)) return false;
+  return true;
+}
+
+template <class F>
+void parallel_over_scans(size_t B, int threads, F &&fn) {
+  if (threads < 1) threads = 1;
+  if ((size_t)threads > B) threads = (int)std::max<size_t>(B, 1);
+  if (threads == 1) {
+    for (size_t b = 0; b < B; ++b) fn(b, 0);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; ++t) {
+    pool.emplace_back([&, t]() {
+      for (size_t b = (size_t)t; b < B; b += (size_t)threads) fn(b, t);
+    });
+  }
+  for (auto &th : pool) th.join();
+}
+
+}  // namespace
+
+/* ========================================================================== */
+/* a3: ascendScanData_, src/sdk/src/sl_lidar_driver.cpp:128-184               */
+/* ========================================================================== */
+extern "C" uint32_t orc_ascend(orc_node_t *nodebuffer, size_t count) {
+  const uint32_t RESULT_OK = 0u;                     /* sl_types.h:71 */
+  const uint32_t RESULT_OPERATION_FAIL = 0x80008001u; /* sl_types.h:75 */
+
+  float inc_origin_angle = 360.f / count; /* :131 */
+  size_t i = 0;
+
+  /* head: first valid sample anchors the leading invalid ones, :135-148 */
+  for (i = 0; i < count; i++) {
+    if (sdk_get_dist(nodebuffer[i]) == 0) {
+      continue;
+    } else {
+      while (i != 0) {
+        i--;
+        float expect_angle = sdk_get_angle(nodebuffer[i + 1]) - inc_origin_angle;
+        if (expect_angle < 0.0f) expect_angle = 0.0f;
+        sdk_set_angle(nodebuffer[i], expect_angle);
+      }
+      break;
+    }
+  }
+
+  if (i == count) return RESULT_OPERATION_FAIL; /* :151 all invalid, buffer untouched */
+
+  /* tail: last valid sample anchors the trailing invalid ones, :154-168 */
+  for (i = count - 1; i < count; i--) {
+    if (sdk_get_dist(nodebuffer[i]) == 0) {
+      continue;
+    } else {
+      while (i != (count - 1)) {
+        i++;
+        float expect_angle = sdk_get_angle(nodebuffer[i - 1]) + inc_origin_angle;
+        if (expect_angle > 360.0f) expect_angle -= 360.0f;
+        sdk_set_angle(nodebuffer[i], expect_angle);
+      }
+      break;
+    }
+  }
+
+  /* fill: every invalid sample i>=1 gets front + i*inc, :171-178 */
+  float frontAngle = sdk_get_angle(nodebuffer[0]);
+  for (i = 1; i < count; i++) {
+    if (sdk_get_dist(nodebuffer[i]) == 0) {
+      float expect_angle = frontAngle + i * inc_origin_angle;
+      if (expect_angle > 360.0f) expect_angle -= 360.0f;
+      sdk_set_angle(nodebuffer[i], expect_angle);
+    }
+  }
+
+  /* reorder by float angle with the same (unstable) std::sort, :181 */
+  std::sort(nodebuffer, nodebuffer + count, &sdk_angle_less);
+
+  return RESULT_OK;
+}
+
+/* ========================================================================== */
+/* a4..a8: RPlidarNode::publish_scan, src/rplidar_node.cpp:558-683            */
+/* ========================================================================== */
+extern "C" void orc_publish_scan(const orc_node_t *nodes, size_t n,
+                                 const orc_params_t *p, double scan_duration,
+                                 float *ranges, float *intensities,
+                                 orc_scan_meta_t *meta) {
+  std::memset(meta, 0, sizeof(*meta));
+  if (n == 0) return; /* :561-563 */
+
+  std::vector<PolarPoint> valid_points;
+  valid_points.reserve(n);
+  const bool is_new_protocol = p->is_new_protocol != 0;
+
+  for (size_t k = 0; k < n; ++k) { /* LOOP 1, :583-602 */
+    const orc_node_t &node = nodes[k];
+    if (!keep_sample(node, *p)) continue;
+    float angle_rad = node_angle_rad(node);
+    float dist_m = node_dist_m(node);
+    float intensity = node_intensity(node, is_new_protocol);
+    valid_points.push_back({angle_rad, dist_m, intensity});
+  }
+
+  std::sort(valid_points.begin(), valid_points.end(), /* :607-609 */
+            [](const PolarPoint &a, const PolarPoint &b) { return a.angle_rad < b.angle_rad; });
+
+  if (valid_points.empty()) return; /* :611-613 */
+
+  meta->published = 1;
+  meta->angle_min = 0.0f;          /* :623 */
+  meta->angle_max = 2.0f * M_PI;   /* :624 */
+  meta->range_min = 0.15f;         /* :625 */
+  meta->range_max = p->range_max;  /* :626 cached_current_max_range_ */
+  meta->scan_time = scan_duration; /* :627 */
+
+  if (p->scan_processing) { /* Mode A, :632-662 */
+    size_t beam_count = valid_points.size();
+    meta->angle_increment = static_cast<float>((2.0 * M_PI) / static_cast<double>(beam_count));
+    meta->time_increment = static_cast<float>(scan_duration / static_cast<double>(beam_count));
+    meta->count = (uint32_t)beam_count;
+    for (size_t k = 0; k < beam_count; ++k) { /* :640-641 */
+      ranges[k] = std::numeric_limits<float>::infinity();
+      intensities[k] = 0.0f;
+    }
+    for (const auto &pt : valid_points) {
+      float angle = pt.angle_rad;
+      if (p->inverted) angle = invert_angle(angle); /* :646-651 */
+      int index = static_cast<int>((angle - meta->angle_min) / meta->angle_increment); /* :653-654 */
+      if (index >= 0 && index < static_cast<int>(beam_count)) {                          /* :656 */
+        if (pt.dist_m < ranges[index]) { /* :657 strict: first minimum in sorted order wins */
+          ranges[index] = pt.dist_m;
+          intensities[index] = pt.intensity;
+        }
+      }
+    }
+  } else { /* Mode B, :663-680 */
+    size_t count = valid_points.size();
+    double denom = static_cast<double>(count > 1 ? count - 1 : 1);
+    meta->angle_increment = static_cast<float>((2.0 * M_PI) / denom);
+    meta->time_increment = static_cast<float>(scan_duration / denom);
+    meta->count = (uint32_t)count;
+    for (size_t k = 0; k < count; ++k) {
+      size_t idx = p->inverted ? k : (count - 1 - k); /* :676 */
+      ranges[idx] = valid_points[k].dist_m;
+      intensities[idx] = valid_points[k].intensity;
+    }
+  }
+}
+
+/* a9, src/rplidar_node.cpp:391-396 */
+extern "C" float orc_effective_max_range(float max_distance_param, float hw_limit) {
+  if (max_distance_param > 0.0f) return std::min(max_distance_param, hw_limit);
+  return hw_limit;
+}
+
+/* a11, src/lidar_driver_wrapper.cpp:441-471 */
+extern "C" void orc_gen_dummy(uint32_t scan_index, orc_node_t *nodes) {
+  const int count = 360;
+  float phase = 0.0f; /* static in the reference; replay the accumulation */
+  for (uint32_t s = 0; s <= scan_index; ++s) phase += 0.1f; /* :450 */
+  for (int i = 0; i < count; ++i) {
+    orc_node_t node{};
+    node.angle_z_q14 = static_cast<uint16_t>((static_cast<float>(i) * 16384.0f / 90.0f)); /* :456-457 */
+    float dist_meters =
+        2.0f + 0.5f * std::sin(static_cast<float>(i) * 3.141592f / 180.0f + phase); /* :459-461 */
+    node.dist_mm_q2 = static_cast<uint32_t>(dist_meters * 1000.0f * 4.0f);         /* :463 */
+    node.quality = 200;                                                            /* :464 */
+    nodes[i] = node;
+  }
+}
+
+/* ========================================================================== */
+/* a-ext: extensions, spec = SURVEY.md §8(a-ext). Parity unpinned.            */
+/* ========================================================================== */
+extern "C" void orc_ror_mask(const float *xyzi, size_t n, float radius, uint32_t k,
+                             uint8_t *keep) {
+  const float r2 = radius * radius;
+  for (size_t i = 0; i < n; ++i) {
+    const float xi = xyzi[4 * i + 0], yi = xyzi[4 * i + 1];
+    uint32_t cnt = 0;
+    for (size_t j = 0; j < n; ++j) {
+      if (j == i) continue;
+      float dx = xi - xyzi[4 * j + 0];
+      float dy = yi - xyzi[4 * j + 1];
+      float d2 = dx * dx + dy * dy; /* products then sum, no FMA (-ffp-contract=off) */
+      if (d2 <= r2) ++cnt;
+    }
+    keep[i] = (cnt >= k) ? 1 : 0;
+  }
+}
+
+extern "C" size_t orc_scan_to_cloud(const orc_node_t *nodes, size_t n,
+                                    const orc_params_t *p, float *xyzi) {
+  size_t m = 0;
+  const bool is_new_protocol = p->is_new_protocol != 0;
+  for (size_t k = 0; k < n; ++k) {
+    const orc_node_t &node = nodes[k];
+    if (!keep_sample(node, *p)) continue; /* E1 */
+    float theta = node_angle_rad(node);
+    if (p->inverted) theta = invert_angle(theta);
+    float dist_m = node_dist_m(node);
+    float c = (float)std::cos((double)theta); /* E2: what the host-built LUT holds */
+    float s = (float)std::sin((double)theta);
+    xyzi[4 * m + 0] = dist_m * c;
+    xyzi[4 * m + 1] = dist_m * s;
+    xyzi[4 * m + 2] = 0.0f;
+    xyzi[4 * m + 3] = node_intensity(node, is_new_protocol);
+    ++m;
+  }
+  if (p->ror_enable && m > 0) { /* E5, applied before E4 */
+    std::vector<uint8_t> keep(m);
+    orc_ror_mask(xyzi, m, p->ror_radius, p->ror_min_neighbors, keep.data());
+    size_t w = 0;
+    for (size_t i = 0; i < m; ++i) {
+      if (!keep[i]) continue;
+      if (w != i) std::memcpy(xyzi + 4 * w, xyzi + 4 * i, 4 * sizeof(float));
+      ++w;
+    }
+    m = w;
+  }
+  return m;
+}
+
+extern "C" size_t orc_voxel_grid(const float *xyzi, size_t n, float leaf, float *out,
+                                 int32_t *cells, uint32_t *counts) {
+  struct Tag {
+    int32_t iy, ix;
+    uint32_t idx;
+  };
+  std::vector<Tag> tags(n);
+  for (size_t i = 0; i < n; ++i) {
+    float x = xyzi[4 * i + 0], y = xyzi[4 * i + 1];
+    tags[i].ix = (int32_t)std::floor(x / leaf); /* float divide, float floor */
+    tags[i].iy = (int32_t)std::floor(y / leaf);
+    tags[i].idx = (uint32_t)i;
+  }
+  std::sort(tags.begin(), tags.end(), [](const Tag &a, const Tag &b) {
+    if (a.iy != b.iy) return a.iy < b.iy;
+    if (a.ix != b.ix) return a.ix < b.ix;
+    return a.idx < b.idx; /* ascending sample order inside a cell */
+  });
+  size_t ncell = 0;
+  size_t i = 0;
+  while (i < n) {
+    size_t j = i;
+    double sx = 0.0, sy = 0.0, sz = 0.0, si = 0.0;
+    while (j < n && tags[j].iy == tags[i].iy && tags[j].ix == tags[i].ix) {
+      const float *pt = xyzi + 4 * (size_t)tags[j].idx;
+      sx += (double)pt[0];
+      sy += (double)pt[1];
+      sz += (double)pt[2];
+      si += (double)pt[3];
+      ++j;
+    }
+    double cnt = (double)(j - i);
+    out[4 * ncell + 0] = (float)(sx / cnt);
+    out[4 * ncell + 1] = (float)(sy / cnt);
+    out[4 * ncell + 2] = (float)(sz / cnt);
+    out[4 * ncell + 3] = (float)(si / cnt);
+    if (cells) {
+      cells[2 * ncell + 0] = tags[i].ix;
+      cells[2 * ncell + 1] = tags[i].iy;
+    }
+    if (counts) counts[ncell] = (uint32_t)(j - i);
+    ++ncell;
+    i = j;
+  }
+  return ncell;
+}
+
+extern "C" size_t orc_cloud_pipeline(const orc_node_t *nodes, size_t n,
+                                     const orc_params_t *p, float *out, int32_t *cells,
+                                     uint32_t *counts) {
+  if (!p->voxel_enable) return orc_scan_to_cloud(nodes, n, p, out);
+  std::vector<float> pts(4 * std::max<size_t>(n, 1));
+  size_t m = orc_scan_to_cloud(nodes, n, p, pts.data());
+  return orc_voxel_grid(pts.data(), m, p->voxel_leaf, out, cells, counts);
+}
+
+/* ========================================================================== */
+/* batched drivers for the timed CPU baseline                                 */
+/* ========================================================================== */
+extern "C" uint64_t orc_batch_ascend(orc_node_t *nodes, size_t n_stride,
+                                     const uint32_t *n_per_scan, size_t B, int threads) {
+  std::vector<uint64_t> acc((size_t)std::max(threads, 1), 0);
+  parallel_over_scans(B, threads, [&](size_t b, int t) {
+    uint32_t r = orc_ascend(nodes + b * n_stride, n_per_scan[b]);
+    acc[t] += (r == 0) ? n_per_scan[b] : 0;
+  });
+  uint64_t total = 0;
+  for (auto v : acc) total += v;
+  return total;
+}
+
+extern "C" uint64_t orc_batch_laserscan(const orc_node_t *nodes, size_t n_stride,
+                                        const uint32_t *n_per_scan, size_t B,
+                                        const orc_params_t *p, int threads) {
+  int T = std::max(threads, 1);
+  std::vector<uint64_t> acc((size_t)T, 0);
+  std::vector<std::vector<float>> bufs((size_t)T);
+  for (auto &v : bufs) v.resize(2 * std::max<size_t>(n_stride, 1));
+  parallel_over_scans(B, threads, [&](size_t b, int t) {
+    orc_scan_meta_t meta;
+    float *r = bufs[t].data();
+    orc_publish_scan(nodes + b * n_stride, n_per_scan[b], p, 0.1, r, r + n_stride, &meta);
+    acc[t] += meta.count;
+  });
+  uint64_t total = 0;
+  for (auto v : acc) total += v;
+  return total;
+}
+
+extern "C" uint64_t orc_batch_cloud(const orc_node_t *nodes, size_t n_stride,
+                                    const uint32_t *n_per_scan, size_t B,
+                                    const orc_params_t *p, int threads) {
+  int T = std::max(threads, 1);
+  std::vector<uint64_t> acc((size_t)T, 0);
+  std::vector<std::vector<float>> bufs((size_t)T);
+  for (auto &v : bufs) v.resize(4 * std::max<size_t>(n_stride, 1));
+  parallel_over_scans(B, threads, [&](size_t b, int t) {
+    acc[t] += orc_cloud_pipeline(nodes + b * n_stride, n_per_scan[b], p, bufs[t].data(),
+                                 nullptr, nullptr);
+  });
+  uint64_t total = 0;
+  for (auto v : acc) total += v;
+  return total;
+}
