@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py — raw scans -> filtered, voxelised PointCloud2 on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic raw scans that is
+already resident in HBM: BASELINE config 3 — 4096 scans x 32 000 samples (131 072 000
+input samples, 1 048 576 000 B of packed 8-byte nodes) -> E1 quality/range clip -> polar->XYZ
+-> 5 cm voxel grid (kernel ``k_cloud_voxel``), then packed into one contiguous cloud.
+With --gpus N > 1 (config 4) the SAME batch is sharded by scan index (strong scaling), each
+rank processes its block and the packed clouds are all-gathered with RCCL over xGMI inside
+the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+``roofline`` (dominant kernel vs the HBM roofline) and ``cpu_baseline`` (the CPU oracle
+timed on this box's host cores on a bounded sample of the same buffers).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scans", type=int, default=4096, help="scans in the whole batch (config 3)")
+    ap.add_argument("--samples", type=int, default=32000, help="samples per scan")
+    ap.add_argument("--out-stride", type=int, default=8192, help="cloud slots per scan")
+    ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="target wall time of the CPU baseline sample (0 disables)")
+    ap.add_argument("--no-laserscan", action="store_true",
+                    help="skip the secondary ascend+LaserScan measurement")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch_np, lens_np, params, target_s):
+    """Time the CPU oracle (a port of the spec; the reference has no cloud path) on this
+    host, all cores, on a bounded prefix of the same scans.  Only this function touches
+    oracle/."""
+    from tests import oracle_lib
+
+    orc = oracle_lib.load_oracle()
+    op = oracle_lib.copy_params(params)
+    import ctypes as C
+
+    cores = os.cpu_count() or 1
+    B, n = batch_np.shape
+
+    def run(nscans, threads):
+        nodes = np.ascontiguousarray(batch_np[:nscans])
+        lens = np.ascontiguousarray(lens_np[:nscans].astype(np.uint32))
+        t0 = time.perf_counter()
+        tot = orc.lib.orc_batch_cloud(nodes.ctypes.data, n, lens.ctypes.data, nscans,
+                                      C.byref(op), threads)
+        return time.perf_counter() - t0, int(tot)
+
+    probe = min(B, max(cores, 8))
+    t, _ = run(probe, cores)
+    rate = probe * n / max(t, 1e-9)
+    nscans = int(min(B, max(probe, rate * target_s / n)))
+    t_all, tot = run(nscans, cores)
+    t_one_scans = min(nscans, max(4, nscans // max(cores, 1)))
+    t_one, _ = run(t_one_scans, 1)
+    return {
+        "value": round(nscans * n / t_all / 1e6, 3),
+        "unit": "Mpoints/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {nscans} scans x {n} samples of the same batch, "
+                  f"{t_all:.2f} s wall, {cores} threads over scans (g++ -O2)",
+        "single_thread_value": round(t_one_scans * n / t_one / 1e6, 3),
+        "cells_out": tot,
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from rplidar_ros2_driver_amd import Params, RplGpu, synth
+    from rplidar_ros2_driver_amd.sharding import allgather_clouds, shard_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B_total, n = args.scans, args.samples
+    lo, hi = shard_range(B_total, world, rank)
+    B = hi - lo
+    out_stride = args.out_stride
+
+    # ---- synthetic input, generated on the host then made resident in HBM --------------
+    t0 = time.perf_counter()
+    batch_np = synth.make_batch(args.seed, B, n, first_scan=lo)
+    gen_s = time.perf_counter() - t0
+    lens_np = np.full(B, n, np.int32)
+    d_nodes = torch.from_numpy(batch_np.view(np.uint8).reshape(B, n * 8)).to(dev)
+    d_len = torch.from_numpy(lens_np).to(dev)
+    d_xyzi = torch.empty(B, out_stride, 4, dtype=torch.float32, device=dev)
+    d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    d_packed = torch.empty(B * out_stride, 4, dtype=torch.float32, device=dev)
+
+    params = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0,
+                             voxel_enable=1, voxel_leaf=0.05)
+    gpu = RplGpu(device=local_rank, max_samples_per_scan=32768, max_batch=max(B, 1))
+    # a real (non-null) stream shared by torch and the library, so that HIP events
+    # recorded through torch bracket exactly the library's kernels
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    gpu.set_stream(stream.cuda_stream)
+
+    def step():
+        gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
+                            d_xyzi.data_ptr(), out_stride, d_np.data_ptr(), d_st.data_ptr())
+        gpu.pack_clouds_dev(d_xyzi.data_ptr(), out_stride, d_np.data_ptr(), B,
+                            d_packed.data_ptr(), d_off.data_ptr())
+        if world > 1:
+            total = int(d_off[B].item())
+            return allgather_clouds(d_packed, total, d_np)
+        return None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    status = int(d_st.max().item())
+    cells_local = int(d_off[B].item())
+
+    # ---- dominant kernel alone: HIP events on the launch stream, per launch -------------
+    reps = max(args.steps, 5)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(reps)]
+    for a, b in ev:
+        a.record(stream)
+        gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
+                            d_xyzi.data_ptr(), out_stride, d_np.data_ptr(), d_st.data_ptr())
+        b.record(stream)
+    torch.cuda.synchronize(dev)
+    k_ms = sorted(a.elapsed_time(b) for a, b in ev)
+    k_ms_avg = sum(k_ms) / len(k_ms)
+    algo_bytes = 8 * B * n + 16 * cells_local  # 8 B read/sample + 16 B/cell out
+    achieved = algo_bytes / (k_ms_avg * 1e-3) / 1e9
+
+    extra = {}
+    if not args.no_laserscan:
+        # secondary: the reference's own path (ascend + publish_scan Mode A) on a copy
+        d_nodes2 = d_nodes.clone()
+        d_r = torch.empty(B, n, dtype=torch.float32, device=dev)
+        d_i = torch.empty(B, n, dtype=torch.float32, device=dev)
+        d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        pl = Params.defaults(range_max=40.0)
+        res = {}
+        for name, fn in (
+            ("ascend", lambda: gpu.ascend_batch_dev(d_nodes2.data_ptr(), n, d_len.data_ptr(), B,
+                                                    d_st.data_ptr())),
+            ("laserscan", lambda: gpu.laserscan_batch_dev(
+                d_nodes2.data_ptr(), n, d_len.data_ptr(), B, pl, d_r.data_ptr(),
+                d_i.data_ptr(), d_cnt.data_ptr())),
+        ):
+            ts = []
+            for it in range(4):
+                if name == "ascend":
+                    d_nodes2.copy_(d_nodes)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                fn()
+                b.record(stream)
+                torch.cuda.synchronize(dev)
+                ts.append(a.elapsed_time(b))
+            res[name] = min(ts[1:])
+        extra = {
+            "ascend_ms": round(res["ascend"], 4),
+            "laserscan_ms": round(res["laserscan"], 4),
+            "ascend_mpts": round(B * n / res["ascend"] / 1e3, 1),
+            "laserscan_mpts": round(B * n / res["laserscan"] / 1e3, 1),
+        }
+        del d_nodes2, d_r, d_i
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(batch_np, lens_np, params, args.cpu_seconds)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = B_total * n / (elapsed / args.steps) / 1e6
+        line = {
+            "metric": "Mpoints/s raw-scan->filtered PointCloud2",
+            "value": round(value, 1),
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u32/f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"config3: {B_total} scans x {n} samples (ring, 10% invalid runs), "
+                            f"clip [0.15,40] m + polar->XYZ + 5 cm voxel grid + pack"
+                            + ("" if world == 1 else f", sharded by scan over {world} GPUs + "
+                               "RCCL all-gather of voxelised clouds"),
+                "scans": B_total, "samples_per_scan": n, "voxel_leaf_m": 0.05,
+                "input_bytes": 8 * B_total * n,
+            },
+            "roofline": {
+                "kernel": "k_cloud_voxel",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "kernel_ms_avg": round(k_ms_avg, 4),
+                "kernel_ms_min": round(k_ms[0], 4),
+                "algorithmic_bytes": algo_bytes,
+            },
+            "cpu_baseline": cpu,
+            "status_bits": status,
+            "cells_out_rank0": cells_local,
+            "host_gen_s": round(gen_s, 2),
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+
+    gpu.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,268 @@
+"""ctypes binding over the C ABI of ``librplgpu.so`` (``include/rplgpu.h``).
+
+This is the same door the reference's C++ node would use; Python is
+only plumbing for tests and ``bench.py``.  Nothing here computes on samples and nothing
+falls back to a CPU implementation: a missing library raises ``RplGpuError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+# == sl_lidar_response_measurement_node_hq_t (reference src/sdk/include/sl_lidar_cmd.h:272-278)
+NODE_DTYPE = np.dtype(
+    [("angle_z_q14", "<u2"), ("dist_mm_q2", "<u4"), ("quality", "u1"), ("flag", "u1")]
+)
+assert NODE_DTYPE.itemsize == 8
+
+MAX_SAMPLES_PER_SCAN = 32768
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_NO_DEVICE = -2
+ERR_HIP = -3
+ERR_CAPACITY = -4
+ERR_ALL_INVALID = -5
+ERR_SCAN_OVERFLOW = -6
+
+SCAN_ALL_INVALID = 0x1
+SCAN_CELL_RANGE = 0x2
+SCAN_TABLE_FULL = 0x4
+SCAN_OUT_TRUNCATED = 0x8
+
+SL_RESULT_OK = 0
+SL_RESULT_OPERATION_FAIL = 0x80008001
+
+# every symbol include/rplgpu.h declares (checked by the CPU-side ABI test)
+ABI_SYMBOLS = [
+    "rplgpu_abi_version",
+    "rplgpu_create",
+    "rplgpu_destroy",
+    "rplgpu_last_error",
+    "rplgpu_default_params",
+    "rplgpu_set_stream",
+    "rplgpu_synchronize",
+    "rplgpu_ascend",
+    "rplgpu_scan_to_laserscan",
+    "rplgpu_scan_to_cloud",
+    "rplgpu_ascend_batch_dev",
+    "rplgpu_laserscan_batch_dev",
+    "rplgpu_cloud_batch_dev",
+    "rplgpu_pack_clouds_dev",
+    "rplgpu_fill_meta",
+]
+
+
+class RplGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str = ""):
+        super().__init__(f"rplgpu error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """Mirror of ``rplgpu_params_t``."""
+
+    _fields_ = [
+        ("is_new_protocol", C.c_int32),
+        ("inverted", C.c_int32),
+        ("scan_processing", C.c_int32),
+        ("clip_enable", C.c_int32),
+        ("q_min", C.c_uint32),
+        ("range_min", C.c_float),
+        ("range_max", C.c_float),
+        ("voxel_leaf", C.c_float),
+        ("ror_radius", C.c_float),
+        ("ror_min_neighbors", C.c_uint32),
+        ("ror_enable", C.c_int32),
+        ("voxel_enable", C.c_int32),
+    ]
+
+    @classmethod
+    def defaults(cls, **kw) -> "Params":
+        p = cls(0, 0, 1, 0, 0, 0.15, 12.0, 0.05, 0.10, 2, 0, 0)
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        return p
+
+
+class ScanMeta(C.Structure):
+    """Mirror of ``rplgpu_scan_meta_t``."""
+
+    _fields_ = [
+        ("angle_min", C.c_float),
+        ("angle_max", C.c_float),
+        ("angle_increment", C.c_float),
+        ("time_increment", C.c_float),
+        ("scan_time", C.c_float),
+        ("range_min", C.c_float),
+        ("range_max", C.c_float),
+        ("count", C.c_uint32),
+        ("published", C.c_int32),
+    ]
+
+
+def library_path() -> Path:
+    env = os.environ.get("RPLGPU_LIBRARY")
+    if env:
+        return Path(env)
+    return Path(__file__).resolve().parent / "lib" / "librplgpu.so"
+
+
+_LIB = None
+
+
+def load_library() -> C.CDLL:
+    """Load ``librplgpu.so`` (in-tree build).  Raises if it is missing — no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.exists():
+        raise RplGpuError(
+            ERR_NO_DEVICE,
+            f"{path} not built; run `python -c 'import __graft_entry__ as g; g.build()'`",
+        )
+    lib = C.CDLL(str(path))
+    vp, u32, i32, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_size_t
+    lib.rplgpu_abi_version.restype = i32
+    lib.rplgpu_create.argtypes = [i32, u32, u32, C.POINTER(vp)]
+    lib.rplgpu_destroy.argtypes = [vp]
+    lib.rplgpu_last_error.argtypes = [vp]
+    lib.rplgpu_last_error.restype = C.c_char_p
+    lib.rplgpu_default_params.argtypes = [C.POINTER(Params)]
+    lib.rplgpu_default_params.restype = None
+    lib.rplgpu_set_stream.argtypes = [vp, vp]
+    lib.rplgpu_synchronize.argtypes = [vp]
+    lib.rplgpu_ascend.argtypes = [vp, vp, sz, C.POINTER(u32)]
+    lib.rplgpu_scan_to_laserscan.argtypes = [
+        vp, vp, sz, C.POINTER(Params), C.c_double, vp, vp, C.POINTER(ScanMeta)]
+    lib.rplgpu_scan_to_cloud.argtypes = [
+        vp, vp, sz, C.POINTER(Params), vp, C.POINTER(u32), C.POINTER(u32)]
+    lib.rplgpu_ascend_batch_dev.argtypes = [vp, vp, u32, vp, u32, vp]
+    lib.rplgpu_laserscan_batch_dev.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), vp, vp, vp]
+    lib.rplgpu_cloud_batch_dev.argtypes = [
+        vp, vp, u32, vp, u32, C.POINTER(Params), vp, u32, vp, vp]
+    lib.rplgpu_pack_clouds_dev.argtypes = [vp, vp, u32, vp, u32, vp, vp]
+    lib.rplgpu_fill_meta.argtypes = [C.POINTER(Params), u32, C.c_double, C.POINTER(ScanMeta)]
+    lib.rplgpu_fill_meta.restype = None
+    for name in ABI_SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int:  # default
+            fn.restype = i32
+    _LIB = lib
+    return lib
+
+
+def _nodes_ptr(arr: np.ndarray) -> int:
+    if arr.dtype != NODE_DTYPE or not arr.flags["C_CONTIGUOUS"]:
+        raise TypeError("nodes must be a C-contiguous array of NODE_DTYPE")
+    return arr.ctypes.data
+
+
+class RplGpu:
+    """One ``rplgpu_handle_t`` (== one lidar node instance / one GPU stream)."""
+
+    def __init__(self, device: int = 0, max_samples_per_scan: int = MAX_SAMPLES_PER_SCAN,
+                 max_batch: int = 4096):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.rplgpu_create(device, max_samples_per_scan, max_batch, C.byref(h))
+        if rc != OK:
+            msg = self._lib.rplgpu_last_error(None) or b""
+            raise RplGpuError(rc, "rplgpu_create failed: " + msg.decode())
+        self._h = h
+        self.device = device
+        self.max_samples_per_scan = max_samples_per_scan
+        self.max_batch = max_batch
+
+    # -- lifecycle -------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rplgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int, allow=()):
+        if rc != OK and rc not in allow:
+            msg = self._lib.rplgpu_last_error(self._h) or b""
+            raise RplGpuError(rc, msg.decode())
+        return rc
+
+    def set_stream(self, hip_stream_ptr: int | None):
+        self._check(self._lib.rplgpu_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
+
+    def synchronize(self):
+        self._check(self._lib.rplgpu_synchronize(self._h))
+
+    # -- single scan, host buffers -----------------------------------------------------
+    def ascend(self, nodes: np.ndarray) -> int:
+        """In place; returns the SDK ``sl_result`` (0 or 0x80008001)."""
+        res = C.c_uint32(0)
+        self._check(self._lib.rplgpu_ascend(self._h, _nodes_ptr(nodes), len(nodes), C.byref(res)))
+        return res.value
+
+    def scan_to_laserscan(self, nodes: np.ndarray, params: Params, scan_duration: float = 0.1):
+        n = len(nodes)
+        ranges = np.empty(max(n, 1), np.float32)
+        intens = np.empty(max(n, 1), np.float32)
+        meta = ScanMeta()
+        self._check(self._lib.rplgpu_scan_to_laserscan(
+            self._h, _nodes_ptr(nodes), n, C.byref(params), scan_duration,
+            ranges.ctypes.data, intens.ctypes.data, C.byref(meta)))
+        return ranges[: meta.count], intens[: meta.count], meta
+
+    def scan_to_cloud(self, nodes: np.ndarray, params: Params, allow_overflow: bool = False):
+        n = len(nodes)
+        xyzi = np.empty((max(n, 1), 4), np.float32)
+        npts = C.c_uint32(0)
+        status = C.c_uint32(0)
+        self._check(self._lib.rplgpu_scan_to_cloud(
+            self._h, _nodes_ptr(nodes), n, C.byref(params), xyzi.ctypes.data,
+            C.byref(npts), C.byref(status)),
+            allow=(ERR_SCAN_OVERFLOW,) if allow_overflow else ())
+        return xyzi[: npts.value], status.value
+
+    # -- device-resident batches (raw device pointers, e.g. torch ``data_ptr()``) ---------
+    def ascend_batch_dev(self, d_nodes: int, n_stride: int, d_n_per_scan: int, B: int,
+                         d_status: int = 0):
+        self._check(self._lib.rplgpu_ascend_batch_dev(
+            self._h, d_nodes, n_stride, d_n_per_scan, B, d_status))
+
+    def laserscan_batch_dev(self, d_nodes: int, n_stride: int, d_n_per_scan: int, B: int,
+                            params: Params, d_ranges: int, d_intens: int, d_beam_count: int):
+        self._check(self._lib.rplgpu_laserscan_batch_dev(
+            self._h, d_nodes, n_stride, d_n_per_scan, B, C.byref(params),
+            d_ranges, d_intens, d_beam_count))
+
+    def cloud_batch_dev(self, d_nodes: int, n_stride: int, d_n_per_scan: int, B: int,
+                        params: Params, d_xyzi: int, out_stride: int, d_n_points: int,
+                        d_status: int = 0):
+        self._check(self._lib.rplgpu_cloud_batch_dev(
+            self._h, d_nodes, n_stride, d_n_per_scan, B, C.byref(params),
+            d_xyzi, out_stride, d_n_points, d_status))
+
+    def pack_clouds_dev(self, d_xyzi: int, out_stride: int, d_n_points: int, B: int,
+                        d_packed: int, d_offsets: int):
+        self._check(self._lib.rplgpu_pack_clouds_dev(
+            self._h, d_xyzi, out_stride, d_n_points, B, d_packed, d_offsets))
+
+    def fill_meta(self, params: Params, count: int, scan_duration: float) -> ScanMeta:
+        meta = ScanMeta()
+        self._lib.rplgpu_fill_meta(C.byref(params), count, scan_duration, C.byref(meta))
+        return meta

@@ -1,0 +1,424 @@
+// rpl_kernels.hip — hand-written gfx950 (CDNA4) kernels for the RPLIDAR scan path.
+//
+// No MFMA anywhere: this is filtering / binning / compaction (HBM-bound integer and
+// fp32 work).  What matters is coalesced 8-byte node streaming, wave64 ballots and
+// prefix sums for the keep mask, and LDS-staged per-bin / per-cell reductions.
+//
+// Reference semantics reproduced (citations relative to /root/reference):
+//   k_ascend      src/sdk/src/sl_lidar_driver.cpp:128-184  (ascendScanData_)
+//   k_laserscan   src/rplidar_node.cpp:568-680             (publish_scan body)
+//   k_cloud*      extensions E1..E4 of SURVEY.md §8(a-ext)
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math): every
+// fp32 divide below must be the correctly rounded IEEE divide and no mul+add may be
+// fused, otherwise bin / cell indices stop being bit-exact.
+#include "rpl_device.hpp"
+#include "rpl_launch.hpp"
+
+namespace rpl {
+
+// ------------------------------------------------------------------------------
+// Resident-scan helpers
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sample_index(int j) {
+  return ((uint32_t)(j * kWaves) + wave_id()) * 64u + lane_id();
+}
+
+__device__ __forceinline__ void load_scan(const uint2 *__restrict__ scan, uint32_t n,
+                                          uint2 (&v)[kIters]) {
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    uint32_t i = sample_index(j);
+    v[j] = (i < n) ? scan[i] : make_uint2(0u, 0u);
+  }
+}
+
+// Publishes one ballot per chunk, then turns the 512 chunk populations into
+// exclusive bases.  Returns the total.  All 1024 threads must call.
+__device__ __forceinline__ uint32_t publish_masks_and_scan(uint32_t flagbits, uint64_t *s_mask,
+                                                           uint32_t *s_cbase, uint32_t *s_tmp) {
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    uint64_t m = __ballot((flagbits >> j) & 1u);
+    if (lane_id() == 0) s_mask[j * kWaves + wave_id()] = m;
+  }
+  __syncthreads();
+  uint32_t cnt = (threadIdx.x < kChunks) ? (uint32_t)__popcll(s_mask[threadIdx.x]) : 0u;
+  uint32_t total;
+  uint32_t ex = block_excl_scan(cnt, s_tmp, &total);
+  if (threadIdx.x < kChunks) s_cbase[threadIdx.x] = ex;
+  __syncthreads();
+  return total;
+}
+
+__device__ __forceinline__ uint32_t sample_rank(int j, const uint64_t *s_mask,
+                                                const uint32_t *s_cbase) {
+  int c = j * kWaves + (int)wave_id();
+  return s_cbase[c] + (uint32_t)__popcll(s_mask[c] & lanemask_lt());
+}
+
+// Sort `count` composite keys (value<<16 | sample index) held in s_keys[0..count)
+// unless they are already ascending, then turn the array into the inverse map
+// s_keys[sample index] = sorted position.  Keys are unique, so the order is the
+// stable (value, input index) order.  `count` <= 32768.  Block-uniform control flow.
+__device__ __forceinline__ void sort_keys_to_positions(uint32_t *s_keys, uint32_t count,
+                                                       uint32_t *s_flag) {
+  if (threadIdx.x == 0) *s_flag = 0u;
+  __syncthreads();
+  uint32_t bad = 0;
+  for (uint32_t t = threadIdx.x; t + 1 < count; t += kBlock) bad |= (s_keys[t] > s_keys[t + 1]);
+  if (bad) atomicOr(s_flag, 1u);
+  __syncthreads();
+  bool unsorted = *s_flag != 0u;
+  uint32_t N = count;
+  if (unsorted) {
+    N = next_pow2(count);
+    for (uint32_t t = count + threadIdx.x; t < N; t += kBlock) s_keys[t] = 0xFFFFFFFFu;
+    block_bitonic_sort(s_keys, N);  // starts and ends with a barrier
+  }
+  // inverse map through registers (the array is read completely before it is rewritten)
+  uint32_t mine[kIters];
+#pragma unroll
+  for (int k = 0; k < kIters; ++k) {
+    uint32_t r = threadIdx.x + (uint32_t)k * kBlock;
+    mine[k] = (r < count) ? s_keys[r] : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kIters; ++k) {
+    uint32_t r = threadIdx.x + (uint32_t)k * kBlock;
+    if (r < count) s_keys[mine[k] & 0xFFFFu] = r;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------
+// k_ascend — SDK ascendScanData, in place (one workgroup per scan)
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ float q14_to_deg(uint32_t q) {  // getAngle, :102-105 (exact in fp32)
+  return (float)q * 90.f / 16384.f;
+}
+__device__ __forceinline__ uint32_t deg_to_q14(float v) {  // setAngle, :107-110 (u32 then u16 store)
+  return ((uint32_t)(v * 16384.f / 90.f)) & 0xFFFFu;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, uint32_t n_stride,
+                                                   const uint32_t *__restrict__ n_per_scan,
+                                                   uint32_t *__restrict__ status) {
+  __shared__ uint32_t s_keys[kMaxN];
+  __shared__ uint32_t s_misc[8];
+  const uint32_t b = blockIdx.x;
+  const uint32_t n = min(n_per_scan[b], kMaxN);
+  uint2 *scan = nodes + (size_t)b * n_stride;
+
+  uint2 v[kIters];
+  load_scan(scan, n, v);
+
+  // first valid index (block min)
+  if (threadIdx.x == 0) s_misc[0] = 0xFFFFFFFFu;
+  __syncthreads();
+  uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+  for (int j = kIters - 1; j >= 0; --j) {
+    uint32_t i = sample_index(j);
+    if (i < n && nd_dist(v[j]) != 0u) first = i;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) first = min(first, (uint32_t)__shfl_xor((int)first, d, 64));
+  if (lane_id() == 0 && first != 0xFFFFFFFFu) atomicMin(&s_misc[0], first);
+  __syncthreads();
+  first = s_misc[0];
+  if (first == 0xFFFFFFFFu) {  // :151 all invalid -> SL_RESULT_OPERATION_FAIL, buffer untouched
+    if (threadIdx.x == 0 && status) status[b] = RPLGPU_SCAN_ALL_INVALID;
+    return;
+  }
+  if (threadIdx.x == 0 && status) status[b] = 0u;
+
+  const float inc = 360.f / (float)n;  // :131
+
+  // head chain (:135-148): a quantised recurrence from the first valid sample back to
+  // sample 0. The fill pass below overwrites every invalid sample i>=1, and the tail
+  // pass (:154-168) only touches such samples, so only sample 0's value survives.
+  if (threadIdx.x == 0) {
+    uint32_t q = nd_q14(scan[first]);
+    for (uint32_t s = first; s > 0; --s) {
+      float e = q14_to_deg(q) - inc;
+      if (e < 0.0f) e = 0.0f;
+      q = deg_to_q14(e);
+    }
+    s_misc[1] = q;  // angle of sample 0 after head tuning (unchanged when first == 0)
+  }
+  __syncthreads();
+  const uint32_t front_q = s_misc[1];
+  const float front = q14_to_deg(front_q);  // :171
+
+  uint32_t changed = 0;
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    uint32_t i = sample_index(j);
+    if (i < n) {
+      uint32_t q = nd_q14(v[j]);
+      uint32_t nq = q;
+      if (nd_dist(v[j]) == 0u) {
+        if (i == 0) {
+          nq = front_q;
+        } else {  // :172-178
+          float e = front + (float)i * inc;
+          if (e > 360.0f) e -= 360.0f;
+          nq = deg_to_q14(e);
+        }
+      }
+      if (nq != q) {
+        changed |= 1u << j;
+        v[j].x = (v[j].x & 0xFFFF0000u) | nq;
+      }
+      s_keys[i] = (nq << 16) | i;  // unique key: (angle, input index)
+    }
+  }
+  __syncthreads();
+
+  // std::sort by float angle (:181) == sort by q14 (getAngle is exact and monotone).
+  // Equal angles: the reference order is whatever introsort leaves; ours is input order.
+  sort_keys_to_positions(s_keys, n, &s_misc[2]);
+
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    uint32_t i = sample_index(j);
+    if (i < n) {
+      uint32_t pos = s_keys[i];
+      if (pos != i || ((changed >> j) & 1u)) scan[pos] = v[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// k_laserscan — publish_scan body (one workgroup per scan)
+// ------------------------------------------------------------------------------
+constexpr uint32_t kBinCap = 16384;  // u64 bins per round (128 KiB of LDS)
+
+__global__ __launch_bounds__(kBlock) void k_laserscan(
+    const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
+    KParams p, Tables T, const float *__restrict__ inc_table, float *__restrict__ ranges,
+    float *__restrict__ intens, uint32_t *__restrict__ beam_count) {
+  __shared__ uint64_t s_big[kBinCap];  // Mode A: u64 bins; Mode B: 32768 u32 keys
+  __shared__ uint64_t s_mask[kChunks];
+  __shared__ uint32_t s_cbase[kChunks];
+  __shared__ uint32_t s_tmp[32];
+
+  const uint32_t b = blockIdx.x;
+  const uint32_t n = min(n_per_scan[b], kMaxN);
+  const uint2 *scan = nodes + (size_t)b * n_stride;
+  float *out_r = ranges + (size_t)b * n_stride;
+  float *out_i = intens + (size_t)b * n_stride;
+
+  uint2 v[kIters];
+  load_scan(scan, n, v);
+
+  // LOOP 1 (:583-602): keep mask; the unit conversions are redone where needed.
+  uint32_t kept = 0;
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    uint32_t d = nd_dist(v[j]);
+    if (nd_keep(d, nd_quality(v[j]), nd_dist_m(d), p)) kept |= 1u << j;
+  }
+  const uint32_t count = publish_masks_and_scan(kept, s_mask, s_cbase, s_tmp);
+  if (threadIdx.x == 0) beam_count[b] = count;
+  if (count == 0) return;  // :611-613 nothing published
+
+  const float *lut = p.inverted ? T.angle_inv : T.angle;
+
+  if (p.scan_processing) {
+    // ---- Mode A (:632-662): min-reduce into beam_count angular bins.
+    // key = dist_m bits | q14 | input index: the u64 minimum is the first strict
+    // minimum in (angle, input order), i.e. the reference's winner.
+    const float inc = inc_table[count];  // (float)(2*pi / (double)count), host-evaluated
+    for (uint32_t lo = 0; lo < count; lo += kBinCap) {
+      const uint32_t hi = min(count, lo + kBinCap);
+      for (uint32_t t = threadIdx.x; t < hi - lo; t += kBlock) s_big[t] = ~0ull;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {
+        if ((kept >> j) & 1u) {
+          uint32_t q = nd_q14(v[j]);
+          float angle = lut[q];
+          int idx = (int)((angle - 0.0f) / inc);  // :653-654, fp32 IEEE divide
+          if (idx >= (int)lo && idx < (int)hi) {  // :656 guard (idx < beam_count)
+            uint64_t key = ((uint64_t)__float_as_uint(nd_dist_m(nd_dist(v[j]))) << 32) |
+                           (uint64_t)((q << 16) | sample_index(j));
+            atomicMin((unsigned long long *)&s_big[idx - (int)lo], (unsigned long long)key);
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < kIters; ++j) {
+        if ((kept >> j) & 1u) {
+          uint32_t q = nd_q14(v[j]);
+          float angle = lut[q];
+          int idx = (int)((angle - 0.0f) / inc);
+          if (idx >= (int)lo && idx < (int)hi) {
+            float dm = nd_dist_m(nd_dist(v[j]));
+            uint64_t key = ((uint64_t)__float_as_uint(dm) << 32) |
+                           (uint64_t)((q << 16) | sample_index(j));
+            if (s_big[idx - (int)lo] == key) {
+              out_r[idx] = dm;
+              out_i[idx] = nd_intensity(nd_quality(v[j]), p.is_new_protocol);
+            }
+          }
+        }
+      }
+      for (uint32_t t = threadIdx.x; t < hi - lo; t += kBlock) {
+        if (s_big[t] == ~0ull) {  // :640-641 defaults
+          out_r[lo + t] = __uint_as_float(0x7F800000u);
+          out_i[lo + t] = 0.0f;
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // ---- Mode B (:663-680): sorted order, reversed unless inverted.
+    uint32_t *s_keys = reinterpret_cast<uint32_t *>(s_big);
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      if ((kept >> j) & 1u) {
+        s_keys[sample_rank(j, s_mask, s_cbase)] = (nd_q14(v[j]) << 16) | sample_index(j);
+      }
+    }
+    __syncthreads();
+    sort_keys_to_positions(s_keys, count, &s_tmp[20]);
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      if ((kept >> j) & 1u) {
+        uint32_t pos = s_keys[sample_index(j)];
+        uint32_t idx = p.inverted ? pos : (count - 1u - pos);  // :676
+        out_r[idx] = nd_dist_m(nd_dist(v[j]));
+        out_i[idx] = nd_intensity(nd_quality(v[j]), p.is_new_protocol);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// k_cloud — E1 keep mask + E2 polar->XYZ, stable compaction in input order
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_cloud(
+    const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
+    KParams p, Tables T, float4 *__restrict__ xyzi, uint32_t out_stride,
+    uint32_t *__restrict__ n_points, uint32_t *__restrict__ status) {
+  __shared__ uint64_t s_mask[kChunks];
+  __shared__ uint32_t s_cbase[kChunks];
+  __shared__ uint32_t s_tmp[32];
+
+  const uint32_t b = blockIdx.x;
+  const uint32_t n = min(n_per_scan[b], kMaxN);
+  const uint2 *scan = nodes + (size_t)b * n_stride;
+  float4 *out = xyzi + (size_t)b * out_stride;
+
+  uint2 v[kIters];
+  load_scan(scan, n, v);
+  uint32_t kept = 0;
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    uint32_t d = nd_dist(v[j]);
+    if (nd_keep(d, nd_quality(v[j]), nd_dist_m(d), p)) kept |= 1u << j;
+  }
+  const uint32_t count = publish_masks_and_scan(kept, s_mask, s_cbase, s_tmp);
+  if (threadIdx.x == 0) {
+    n_points[b] = min(count, out_stride);
+    if (status) status[b] = (count > out_stride) ? RPLGPU_SCAN_OUT_TRUNCATED : 0u;
+  }
+  const float2 *cs = p.inverted ? T.cs_inv : T.cs;
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    if ((kept >> j) & 1u) {
+      uint32_t r = sample_rank(j, s_mask, s_cbase);
+      if (r < out_stride) {
+        float dm = nd_dist_m(nd_dist(v[j]));
+        float2 c = cs[nd_q14(v[j])];
+        out[r] = make_float4(dm * c.x, dm * c.y, 0.0f,
+                             nd_intensity(nd_quality(v[j]), p.is_new_protocol));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// pack: per-scan regions -> one contiguous cloud (scan order)
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_offsets(const uint32_t *__restrict__ n_points,
+                                                    uint32_t B, uint64_t *__restrict__ offsets) {
+  __shared__ uint32_t s_tmp[32];
+  __shared__ uint64_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0ull;
+  __syncthreads();
+  for (uint32_t base = 0; base < B; base += kBlock) {
+    uint32_t i = base + threadIdx.x;
+    uint32_t v = (i < B) ? n_points[i] : 0u;
+    uint32_t total;
+    uint32_t ex = block_excl_scan(v, s_tmp, &total);
+    uint64_t carry = s_carry;
+    if (i < B) offsets[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = carry + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offsets[B] = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_pack(const float4 *__restrict__ xyzi, uint32_t out_stride,
+                                              const uint32_t *__restrict__ n_points,
+                                              const uint64_t *__restrict__ offsets,
+                                              float4 *__restrict__ packed) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t m = n_points[b];
+  const float4 *src = xyzi + (size_t)b * out_stride;
+  float4 *dst = packed + offsets[b];
+  for (uint32_t t = threadIdx.x; t < m; t += 256) dst[t] = src[t];
+}
+
+// ------------------------------------------------------------------------------
+// host-side launchers (declared in rpl_launch.hpp)
+// ------------------------------------------------------------------------------
+hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
+                         uint32_t B, uint32_t *status) {
+  if (B == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_ascend, dim3(B), dim3(kBlock), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
+                     status);
+  return hipGetLastError();
+}
+
+hipError_t launch_laserscan(hipStream_t s, const void *nodes, uint32_t n_stride,
+                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
+                            const Tables &T, const float *inc_table, float *ranges, float *intens,
+                            uint32_t *beam_count) {
+  if (B == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_laserscan, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
+                     n_per_scan, p, T, inc_table, ranges, intens, beam_count);
+  return hipGetLastError();
+}
+
+hipError_t launch_cloud(hipStream_t s, const void *nodes, uint32_t n_stride,
+                        const uint32_t *n_per_scan, uint32_t B, const KParams &p, const Tables &T,
+                        bool voxel, float *xyzi, uint32_t out_stride, uint32_t *n_points,
+                        uint32_t *status) {
+  if (B == 0) return hipSuccess;
+  if (voxel) {
+    return launch_cloud_voxel(s, nodes, n_stride, n_per_scan, B, p, T, xyzi, out_stride, n_points,
+                              status);
+  } else {
+    hipLaunchKernelGGL(k_cloud, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
+                       n_per_scan, p, T, (float4 *)xyzi, out_stride, n_points, status);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pack(hipStream_t s, const float *xyzi, uint32_t out_stride,
+                       const uint32_t *n_points, uint32_t B, float *packed, uint64_t *offsets) {
+  hipLaunchKernelGGL(k_offsets, dim3(1), dim3(kBlock), 0, s, n_points, B, offsets);
+  if (B)
+    hipLaunchKernelGGL(k_pack, dim3(B), dim3(256), 0, s, (const float4 *)xyzi, out_stride,
+                       n_points, offsets, (float4 *)packed);
+  return hipGetLastError();
+}
+
+}  // namespace rpl

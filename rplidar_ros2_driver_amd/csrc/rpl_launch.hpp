@@ -1,0 +1,28 @@
+// rpl_launch.hpp — host-callable launchers of the gfx950 kernels (rpl_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rplgpu.h"
+#include "rpl_device.hpp"
+
+namespace rpl {
+
+hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
+                         uint32_t B, uint32_t *status);
+hipError_t launch_laserscan(hipStream_t s, const void *nodes, uint32_t n_stride,
+                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
+                            const Tables &T, const float *inc_table, float *ranges, float *intens,
+                            uint32_t *beam_count);
+hipError_t launch_cloud(hipStream_t s, const void *nodes, uint32_t n_stride,
+                        const uint32_t *n_per_scan, uint32_t B, const KParams &p, const Tables &T,
+                        bool voxel, float *xyzi, uint32_t out_stride, uint32_t *n_points,
+                        uint32_t *status);
+hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_stride,
+                              const uint32_t *n_per_scan, uint32_t B, const KParams &p,
+                              const Tables &T, float *xyzi, uint32_t out_stride,
+                              uint32_t *n_points, uint32_t *status);
+hipError_t launch_pack(hipStream_t s, const float *xyzi, uint32_t out_stride,
+                       const uint32_t *n_points, uint32_t B, float *packed, uint64_t *offsets);
+
+}  // namespace rpl

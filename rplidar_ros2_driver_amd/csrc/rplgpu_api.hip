@@ -1,0 +1,414 @@
+// rplgpu_api.hip — the extern "C" boundary declared in include/rplgpu.h.
+//
+// Host side only: context/stream management, the host-evaluated lookup tables, the
+// pinned staging used by the single-scan (host buffer) entry points, and argument
+// checking.  All arithmetic on samples happens in rpl_kernels.hip.  There is no CPU
+// fallback: if no gfx950 device is usable, rplgpu_create fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rplgpu.h"
+#include "rpl_launch.hpp"
+
+struct rplgpu_ctx {
+  int device = -1;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  uint32_t max_n = 0, max_b = 0;
+  // tables
+  float *d_angle = nullptr, *d_angle_inv = nullptr, *d_inc = nullptr;
+  float2 *d_cs = nullptr, *d_cs_inv = nullptr;
+  // single-scan staging
+  unsigned char *h_pin = nullptr;  // pinned: nodes | out (16 B / sample) | 2 x u32
+  unsigned char *d_nodes = nullptr, *d_out = nullptr;
+  uint32_t *d_small = nullptr;  // [0]=n, [1]=count, [2]=status
+  std::string err;
+};
+
+namespace {
+
+thread_local std::string g_create_err;
+
+#define RPL_HIP(ctx, call)                                                              \
+  do {                                                                                  \
+    hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+      return RPLGPU_ERR_HIP;                                                            \
+    }                                                                                   \
+  } while (0)
+
+rpl::KParams to_kparams(const rplgpu_params_t &p) {
+  rpl::KParams k;
+  k.is_new_protocol = p.is_new_protocol != 0;
+  k.inverted = p.inverted != 0;
+  k.scan_processing = p.scan_processing != 0;
+  k.clip_enable = p.clip_enable != 0;
+  k.q_min = p.q_min;
+  k.range_min = p.range_min;
+  k.range_max = p.range_max;
+  k.voxel_leaf = p.voxel_leaf;
+  k.ror_r2 = p.ror_radius * p.ror_radius;
+  k.ror_k = p.ror_min_neighbors;
+  // voxel fixed point: 2^-K = ulp(leaf), so L = leaf*2^K is the leaf's integer significand
+  k.vox_scale = 1.0;
+  k.vox_scale_f = 1.0f;
+  k.vox_L = 1;
+  k.vox_bias = 32768;
+  if (p.voxel_leaf > 0.0f && std::isfinite(p.voxel_leaf)) {
+    int K = 23 - std::ilogb(p.voxel_leaf);
+    k.vox_scale = std::ldexp(1.0, K);
+    k.vox_scale_f = (float)k.vox_scale;
+    k.vox_L = (int32_t)std::llround((double)p.voxel_leaf * k.vox_scale);
+  }
+  return k;
+}
+
+rpl::Tables tables_of(const rplgpu_ctx *c) {
+  rpl::Tables t;
+  t.angle = c->d_angle;
+  t.angle_inv = c->d_angle_inv;
+  t.cs = c->d_cs;
+  t.cs_inv = c->d_cs_inv;
+  return t;
+}
+
+// The reference's per-sample angle arithmetic, evaluated once per possible u16 input
+// with the same operand types (float / double) and the same order of operations:
+// src/rplidar_node.cpp:588-599 (conversion + wrap) and :646-651 (invert rule).
+void build_tables(std::vector<float> &angle, std::vector<float> &angle_inv,
+                  std::vector<float2> &cs, std::vector<float2> &cs_inv, std::vector<float> &inc) {
+  angle.resize(65536);
+  angle_inv.resize(65536);
+  cs.resize(65536);
+  cs_inv.resize(65536);
+  for (int q = 0; q < 65536; ++q) {
+    uint16_t angle_z_q14 = (uint16_t)q;
+    float angle_deg = angle_z_q14 * 90.0f / 16384.0f;
+    float angle_rad = angle_deg * (M_PI / 180.0f);
+    if (angle_rad < 0.0f) angle_rad += 2.0f * M_PI;
+    if (angle_rad >= 2.0f * M_PI) angle_rad -= 2.0f * M_PI;
+    float inv = (2.0f * M_PI) - angle_rad;
+    if (inv >= 2.0f * M_PI) inv -= 2.0f * M_PI;
+    angle[q] = angle_rad;
+    angle_inv[q] = inv;
+    cs[q] = make_float2((float)std::cos((double)angle_rad), (float)std::sin((double)angle_rad));
+    cs_inv[q] = make_float2((float)std::cos((double)inv), (float)std::sin((double)inv));
+  }
+  // angle_increment of Mode A for every possible beam count, :635-636
+  inc.resize(rpl::kMaxN + 1);
+  inc[0] = 0.0f;
+  for (uint32_t c = 1; c <= rpl::kMaxN; ++c)
+    inc[c] = static_cast<float>((2.0 * M_PI) / static_cast<double>(c));
+}
+
+template <class T>
+int32_t upload(rplgpu_ctx *c, T **dst, const std::vector<T> &src) {
+  RPL_HIP(c, hipMalloc((void **)dst, src.size() * sizeof(T)));
+  RPL_HIP(c, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return RPLGPU_OK;
+}
+
+void free_ctx(rplgpu_ctx *c) {
+  if (!c) return;
+  if (c->device >= 0) (void)hipSetDevice(c->device);
+  if (c->d_angle) (void)hipFree(c->d_angle);
+  if (c->d_angle_inv) (void)hipFree(c->d_angle_inv);
+  if (c->d_inc) (void)hipFree(c->d_inc);
+  if (c->d_cs) (void)hipFree(c->d_cs);
+  if (c->d_cs_inv) (void)hipFree(c->d_cs_inv);
+  if (c->d_nodes) (void)hipFree(c->d_nodes);
+  if (c->d_out) (void)hipFree(c->d_out);
+  if (c->d_small) (void)hipFree(c->d_small);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int32_t check_batch(rplgpu_ctx *c, const void *nodes, uint32_t n_stride, const void *n_per_scan,
+                    uint32_t B) {
+  if (!c) return RPLGPU_ERR_INVALID_ARG;
+  if (B == 0) return RPLGPU_OK;
+  if (!nodes || !n_per_scan || n_stride == 0) {
+    c->err = "null buffer or zero stride";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  if (B > c->max_b) {
+    c->err = "batch larger than max_batch given to rplgpu_create";
+    return RPLGPU_ERR_CAPACITY;
+  }
+  return RPLGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rplgpu_abi_version(void) { return RPLGPU_ABI_VERSION; }
+
+void rplgpu_default_params(rplgpu_params_t *p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->scan_processing = 1;  // code default, src/rplidar_node.cpp:280
+  p->range_min = 0.15f;    // :625
+  p->range_max = 12.0f;    // cached_current_max_range_ initial value, include/rplidar_node.hpp
+  p->voxel_leaf = 0.05f;
+  p->ror_radius = 0.10f;
+  p->ror_min_neighbors = 2;
+}
+
+void rplgpu_fill_meta(const rplgpu_params_t *p, uint32_t count, double scan_duration,
+                      rplgpu_scan_meta_t *meta) {
+  std::memset(meta, 0, sizeof(*meta));
+  if (count == 0) return;  // :611-613
+  meta->published = 1;
+  meta->count = count;
+  meta->angle_min = 0.0f;          // :623
+  meta->angle_max = 2.0f * M_PI;   // :624
+  meta->range_min = 0.15f;         // :625
+  meta->range_max = p->range_max;  // :626
+  meta->scan_time = scan_duration; // :627
+  if (p->scan_processing) {        // :634-638
+    size_t beam_count = count;
+    meta->angle_increment = static_cast<float>((2.0 * M_PI) / static_cast<double>(beam_count));
+    meta->time_increment = static_cast<float>(scan_duration / static_cast<double>(beam_count));
+  } else {                         // :665-669
+    size_t cnt = count;
+    double denom = static_cast<double>(cnt > 1 ? cnt - 1 : 1);
+    meta->angle_increment = static_cast<float>((2.0 * M_PI) / denom);
+    meta->time_increment = static_cast<float>(scan_duration / denom);
+  }
+}
+
+int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t max_batch,
+                      rplgpu_handle_t *out) {
+  if (!out) return RPLGPU_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (max_samples_per_scan == 0 || max_samples_per_scan > RPLGPU_MAX_SAMPLES_PER_SCAN ||
+      max_batch == 0)
+    return RPLGPU_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RPLGPU_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= ndev) return RPLGPU_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return RPLGPU_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RPLGPU_ERR_NO_DEVICE;  // CDNA4 only
+  if (hipSetDevice(device_id) != hipSuccess) return RPLGPU_ERR_NO_DEVICE;
+
+  rplgpu_ctx *c = new (std::nothrow) rplgpu_ctx();
+  if (!c) return RPLGPU_ERR_HIP;
+  c->device = device_id;
+  c->max_n = max_samples_per_scan;
+  c->max_b = max_batch;
+  auto fail = [&](int32_t code) {
+    g_create_err = c->err;
+    free_ctx(c);
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess)
+    return fail(RPLGPU_ERR_HIP);
+  c->stream = c->own_stream;
+
+  std::vector<float> angle, angle_inv, inc;
+  std::vector<float2> cs, cs_inv;
+  build_tables(angle, angle_inv, cs, cs_inv, inc);
+  // Sorting by q14 stands in for sorting by angle_rad (:607-609): require monotonicity.
+  for (int q = 1; q < 65536; ++q) {
+    if (!(angle[q] > angle[q - 1])) {
+      c->err = "angle table not strictly increasing";
+      return fail(RPLGPU_ERR_INVALID_ARG);
+    }
+  }
+  int32_t rc;
+  if ((rc = upload(c, &c->d_angle, angle)) || (rc = upload(c, &c->d_angle_inv, angle_inv)) ||
+      (rc = upload(c, &c->d_cs, cs)) || (rc = upload(c, &c->d_cs_inv, cs_inv)) ||
+      (rc = upload(c, &c->d_inc, inc)))
+    return fail(rc);
+
+  const size_t n = c->max_n;
+  if (hipHostMalloc((void **)&c->h_pin, n * 8 + n * 16 + 64, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void **)&c->d_nodes, n * 8) != hipSuccess ||
+      hipMalloc((void **)&c->d_out, n * 16) != hipSuccess ||
+      hipMalloc((void **)&c->d_small, 64) != hipSuccess) {
+    c->err = "staging allocation failed";
+    return fail(RPLGPU_ERR_HIP);
+  }
+  *out = c;
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_destroy(rplgpu_handle_t h) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  free_ctx(h);
+  return RPLGPU_OK;
+}
+
+const char *rplgpu_last_error(rplgpu_handle_t h) {
+  if (!h) return g_create_err.c_str();
+  return h->err.c_str();
+}
+
+int32_t rplgpu_set_stream(rplgpu_handle_t h, void *hip_stream) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_synchronize(rplgpu_handle_t h) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, hipStreamSynchronize(h->stream));
+  return RPLGPU_OK;
+}
+
+// ---- device-resident batches ----------------------------------------------------
+
+int32_t rplgpu_ascend_batch_dev(rplgpu_handle_t h, rplgpu_node_t *d_nodes, uint32_t n_stride,
+                                const uint32_t *d_n_per_scan, uint32_t B, uint32_t *d_status) {
+  int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
+  if (rc) return rc;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_ascend(h->stream, d_nodes, n_stride, d_n_per_scan, B, d_status));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_laserscan_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
+                                   uint32_t n_stride, const uint32_t *d_n_per_scan, uint32_t B,
+                                   const rplgpu_params_t *p, float *d_ranges,
+                                   float *d_intensities, uint32_t *d_beam_count) {
+  int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
+  if (rc) return rc;
+  if (!p || !d_ranges || !d_intensities || !d_beam_count) return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_laserscan(h->stream, d_nodes, n_stride, d_n_per_scan, B, to_kparams(*p),
+                                   tables_of(h), h->d_inc, d_ranges, d_intensities, d_beam_count));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
+                               const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
+                               float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,
+                               uint32_t *d_status) {
+  int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
+  if (rc) return rc;
+  if (!p || !d_xyzi || !d_n_points || out_stride == 0) return RPLGPU_ERR_INVALID_ARG;
+  if (p->ror_enable) {
+    h->err = "radius outlier removal (E5) is not implemented on the device yet";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  if (p->voxel_enable && !(p->voxel_leaf >= 1e-6f && p->voxel_leaf <= 1024.0f)) {
+    h->err = "voxel_leaf must be in [1e-6, 1024] m";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, to_kparams(*p),
+                               tables_of(h), p->voxel_enable != 0, d_xyzi, out_stride, d_n_points,
+                               d_status));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_pack_clouds_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t out_stride,
+                               const uint32_t *d_n_points, uint32_t B, float *d_packed,
+                               uint64_t *d_offsets) {
+  if (!h || !d_offsets) return RPLGPU_ERR_INVALID_ARG;
+  if (B && (!d_xyzi || !d_n_points || !d_packed)) return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_pack(h->stream, d_xyzi, out_stride, d_n_points, B, d_packed, d_offsets));
+  return RPLGPU_OK;
+}
+
+// ---- single scan, host buffers ----------------------------------------------------
+
+int32_t rplgpu_ascend(rplgpu_handle_t h, rplgpu_node_t *nodes, size_t n, uint32_t *sl_result) {
+  if (!h || (!nodes && n)) return RPLGPU_ERR_INVALID_ARG;
+  if (n > h->max_n) return RPLGPU_ERR_CAPACITY;
+  if (n == 0) {  // 0 == count -> SL_RESULT_OPERATION_FAIL (src/sdk/src/sl_lidar_driver.cpp:151)
+    if (sl_result) *sl_result = 0x80008001u;
+    return RPLGPU_OK;
+  }
+  RPL_HIP(h, hipSetDevice(h->device));
+  uint32_t *h_small = reinterpret_cast<uint32_t *>(h->h_pin + (size_t)h->max_n * 24);
+  std::memcpy(h->h_pin, nodes, n * 8);
+  h_small[0] = (uint32_t)n;
+  RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
+  RPL_HIP(h, rpl::launch_ascend(h->stream, h->d_nodes, (uint32_t)n, h->d_small, 1, h->d_small + 2));
+  RPL_HIP(h, hipMemcpyAsync(h->h_pin, h->d_nodes, n * 8, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h_small + 2, h->d_small + 2, 4, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipStreamSynchronize(h->stream));
+  const bool all_invalid = (h_small[2] & RPLGPU_SCAN_ALL_INVALID) != 0;
+  if (!all_invalid) std::memcpy(nodes, h->h_pin, n * 8);
+  if (sl_result) *sl_result = all_invalid ? 0x80008001u : 0u;
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_scan_to_laserscan(rplgpu_handle_t h, const rplgpu_node_t *nodes, size_t n,
+                                 const rplgpu_params_t *p, double scan_duration, float *ranges,
+                                 float *intensities, rplgpu_scan_meta_t *meta) {
+  if (!h || !p || !meta || (n && (!nodes || !ranges || !intensities))) return RPLGPU_ERR_INVALID_ARG;
+  if (n > h->max_n) return RPLGPU_ERR_CAPACITY;
+  std::memset(meta, 0, sizeof(*meta));
+  if (n == 0) return RPLGPU_OK;  // :561-563
+  RPL_HIP(h, hipSetDevice(h->device));
+  uint32_t *h_small = reinterpret_cast<uint32_t *>(h->h_pin + (size_t)h->max_n * 24);
+  unsigned char *h_out = h->h_pin + (size_t)h->max_n * 8;
+  std::memcpy(h->h_pin, nodes, n * 8);
+  h_small[0] = (uint32_t)n;
+  float *d_r = reinterpret_cast<float *>(h->d_out);
+  float *d_i = d_r + n;
+  RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
+  RPL_HIP(h, rpl::launch_laserscan(h->stream, h->d_nodes, (uint32_t)n, h->d_small, 1, to_kparams(*p),
+                                   tables_of(h), h->d_inc, d_r, d_i, h->d_small + 1));
+  RPL_HIP(h, hipMemcpyAsync(h_out, h->d_out, n * 8, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h_small + 1, h->d_small + 1, 4, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipStreamSynchronize(h->stream));
+  const uint32_t count = h_small[1];
+  rplgpu_fill_meta(p, count, scan_duration, meta);
+  if (count) {
+    std::memcpy(ranges, h_out, (size_t)count * 4);
+    std::memcpy(intensities, h_out + n * 4, (size_t)count * 4);
+  }
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_scan_to_cloud(rplgpu_handle_t h, const rplgpu_node_t *nodes, size_t n,
+                             const rplgpu_params_t *p, float *xyzi, uint32_t *n_points,
+                             uint32_t *status) {
+  if (!h || !p || !n_points || (n && (!nodes || !xyzi))) return RPLGPU_ERR_INVALID_ARG;
+  if (n > h->max_n) return RPLGPU_ERR_CAPACITY;
+  *n_points = 0;
+  if (status) *status = 0;
+  if (n == 0) return RPLGPU_OK;
+  uint32_t *h_small = reinterpret_cast<uint32_t *>(h->h_pin + (size_t)h->max_n * 24);
+  unsigned char *h_out = h->h_pin + (size_t)h->max_n * 8;
+  std::memcpy(h->h_pin, nodes, n * 8);
+  h_small[0] = (uint32_t)n;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
+  int32_t rc = rplgpu_cloud_batch_dev(h, reinterpret_cast<const rplgpu_node_t *>(h->d_nodes),
+                                      (uint32_t)n, h->d_small, 1, p,
+                                      reinterpret_cast<float *>(h->d_out), (uint32_t)n,
+                                      h->d_small + 1, h->d_small + 2);
+  if (rc) return rc;
+  RPL_HIP(h, hipMemcpyAsync(h_out, h->d_out, n * 16, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h_small + 1, h->d_small + 1, 8, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipStreamSynchronize(h->stream));
+  *n_points = h_small[1];
+  if (status) *status = h_small[2];
+  std::memcpy(xyzi, h_out, (size_t)h_small[1] * 16);
+  return (h_small[2] & (RPLGPU_SCAN_CELL_RANGE | RPLGPU_SCAN_TABLE_FULL)) ? RPLGPU_ERR_SCAN_OVERFLOW
+                                                                          : RPLGPU_OK;
+}
+
+}  // extern "C"

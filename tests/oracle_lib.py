@@ -1,0 +1,192 @@
+"""ctypes access to the CPU oracle (oracle/liboracle.so) and, when built, to the genuine
+reference libraries under oracle/_ref/.  TEST INFRASTRUCTURE — imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+
+NODE = np.dtype([("angle_z_q14", "<u2"), ("dist_mm_q2", "<u4"), ("quality", "u1"), ("flag", "u1")])
+
+
+class OParams(C.Structure):
+    _fields_ = [
+        ("is_new_protocol", C.c_int32), ("inverted", C.c_int32), ("scan_processing", C.c_int32),
+        ("clip_enable", C.c_int32), ("q_min", C.c_uint32), ("range_min", C.c_float),
+        ("range_max", C.c_float), ("voxel_leaf", C.c_float), ("ror_radius", C.c_float),
+        ("ror_min_neighbors", C.c_uint32), ("ror_enable", C.c_int32), ("voxel_enable", C.c_int32),
+    ]
+
+
+class OMeta(C.Structure):
+    _fields_ = [(k, C.c_float) for k in
+                "angle_min angle_max angle_increment time_increment scan_time range_min range_max".split()
+                ] + [("count", C.c_uint32), ("published", C.c_int32)]
+
+    def as_tuple(self):
+        return tuple(getattr(self, f[0]) for f in self._fields_)
+
+
+def params(**kw) -> OParams:
+    p = OParams(0, 0, 1, 0, 0, 0.15, 12.0, 0.05, 0.10, 2, 0, 0)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def copy_params(src) -> OParams:
+    """Field-by-field copy from the product's Params structure (same names)."""
+    return params(**{f[0]: getattr(src, f[0]) for f in OParams._fields_})
+
+
+class Oracle:
+    def __init__(self, lib: C.CDLL):
+        self.lib = lib
+        vp, sz = C.c_void_p, C.c_size_t
+        lib.orc_ascend.argtypes = [vp, sz]
+        lib.orc_ascend.restype = C.c_uint32
+        lib.orc_publish_scan.argtypes = [vp, sz, C.POINTER(OParams), C.c_double, vp, vp, C.POINTER(OMeta)]
+        lib.orc_publish_scan.restype = None
+        lib.orc_effective_max_range.argtypes = [C.c_float, C.c_float]
+        lib.orc_effective_max_range.restype = C.c_float
+        lib.orc_gen_dummy.argtypes = [C.c_uint32, vp]
+        lib.orc_gen_dummy.restype = None
+        lib.orc_scan_to_cloud.argtypes = [vp, sz, C.POINTER(OParams), vp]
+        lib.orc_scan_to_cloud.restype = sz
+        lib.orc_ror_mask.argtypes = [vp, sz, C.c_float, C.c_uint32, vp]
+        lib.orc_ror_mask.restype = None
+        lib.orc_voxel_grid.argtypes = [vp, sz, C.c_float, vp, vp, vp]
+        lib.orc_voxel_grid.restype = sz
+        lib.orc_cloud_pipeline.argtypes = [vp, sz, C.POINTER(OParams), vp, vp, vp]
+        lib.orc_cloud_pipeline.restype = sz
+        for name in ("orc_batch_ascend",):
+            getattr(lib, name).argtypes = [vp, sz, vp, sz, C.c_int]
+            getattr(lib, name).restype = C.c_uint64
+        for name in ("orc_batch_laserscan", "orc_batch_cloud"):
+            getattr(lib, name).argtypes = [vp, sz, vp, sz, C.POINTER(OParams), C.c_int]
+            getattr(lib, name).restype = C.c_uint64
+
+    def ascend(self, nodes: np.ndarray):
+        out = np.ascontiguousarray(nodes).copy()
+        res = self.lib.orc_ascend(out.ctypes.data, len(out))
+        return out, res
+
+    def publish_scan(self, nodes: np.ndarray, p: OParams, scan_duration: float = 0.1):
+        nodes = np.ascontiguousarray(nodes)
+        n = len(nodes)
+        r = np.full(max(n, 1), np.nan, np.float32)
+        i = np.full(max(n, 1), np.nan, np.float32)
+        m = OMeta()
+        self.lib.orc_publish_scan(nodes.ctypes.data, n, C.byref(p), scan_duration,
+                                  r.ctypes.data, i.ctypes.data, C.byref(m))
+        return r[: m.count], i[: m.count], m
+
+    def gen_dummy(self, scan_index: int = 0) -> np.ndarray:
+        out = np.zeros(360, NODE)
+        self.lib.orc_gen_dummy(scan_index, out.ctypes.data)
+        return out
+
+    def scan_to_cloud(self, nodes: np.ndarray, p: OParams) -> np.ndarray:
+        nodes = np.ascontiguousarray(nodes)
+        out = np.zeros((max(len(nodes), 1), 4), np.float32)
+        m = self.lib.orc_scan_to_cloud(nodes.ctypes.data, len(nodes), C.byref(p), out.ctypes.data)
+        return out[:m]
+
+    def voxel_grid(self, xyzi: np.ndarray, leaf: float):
+        xyzi = np.ascontiguousarray(xyzi, np.float32)
+        n = len(xyzi)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        cells = np.zeros((max(n, 1), 2), np.int32)
+        counts = np.zeros(max(n, 1), np.uint32)
+        m = self.lib.orc_voxel_grid(xyzi.ctypes.data, n, leaf, out.ctypes.data,
+                                    cells.ctypes.data, counts.ctypes.data)
+        return out[:m], cells[:m], counts[:m]
+
+    def cloud_pipeline(self, nodes: np.ndarray, p: OParams):
+        nodes = np.ascontiguousarray(nodes)
+        n = len(nodes)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        cells = np.zeros((max(n, 1), 2), np.int32)
+        counts = np.zeros(max(n, 1), np.uint32)
+        m = self.lib.orc_cloud_pipeline(nodes.ctypes.data, n, C.byref(p), out.ctypes.data,
+                                        cells.ctypes.data, counts.ctypes.data)
+        return out[:m], cells[:m], counts[:m]
+
+    def ror_mask(self, xyzi: np.ndarray, radius: float, k: int) -> np.ndarray:
+        xyzi = np.ascontiguousarray(xyzi, np.float32)
+        keep = np.zeros(max(len(xyzi), 1), np.uint8)
+        self.lib.orc_ror_mask(xyzi.ctypes.data, len(xyzi), radius, k, keep.ctypes.data)
+        return keep[: len(xyzi)].astype(bool)
+
+
+def build_oracle():
+    subprocess.run(["make", "-C", str(ORACLE_DIR), "all"], check=True, capture_output=True)
+
+
+def load_oracle() -> Oracle:
+    so = ORACLE_DIR / "liboracle.so"
+    src_newer = (not so.exists()) or any(
+        (ORACLE_DIR / f).stat().st_mtime > so.stat().st_mtime for f in ("oracle.cpp", "oracle.h"))
+    if src_newer:
+        build_oracle()
+    return Oracle(C.CDLL(str(so)))
+
+
+class RefLibs:
+    """Genuine reference code: SDK ascendScanData and RPlidarNode::publish_scan."""
+
+    def __init__(self, sl: C.CDLL, node: C.CDLL):
+        self.sl, self.node = sl, node
+        sl.ref_ascend.argtypes = [C.c_void_p, C.c_size_t]
+        sl.ref_ascend.restype = C.c_uint32
+        node.ref_publish_scan.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                          C.c_float, C.c_double, C.c_void_p, C.c_void_p,
+                                          C.POINTER(OMeta)]
+        node.ref_dummy_grab.argtypes = [C.c_void_p, C.c_size_t]
+
+    def ascend(self, nodes: np.ndarray):
+        out = np.ascontiguousarray(nodes).copy()
+        res = self.sl.ref_ascend(out.ctypes.data, len(out))
+        return out, res
+
+    def publish_scan(self, nodes, *, driver_kind: int, inverted: int, scan_processing: int,
+                     range_max: float = 12.0, scan_duration: float = 0.1):
+        nodes = np.ascontiguousarray(nodes)
+        n = len(nodes)
+        r = np.full(max(n, 1), np.nan, np.float32)
+        i = np.full(max(n, 1), np.nan, np.float32)
+        m = OMeta()
+        self.node.ref_publish_scan(nodes.ctypes.data, n, driver_kind, inverted, scan_processing,
+                                   range_max, scan_duration, r.ctypes.data, i.ctypes.data,
+                                   C.byref(m))
+        return r[: m.count], i[: m.count], m
+
+    def dummy_grab(self) -> np.ndarray:
+        out = np.zeros(360, NODE)
+        k = self.node.ref_dummy_grab(out.ctypes.data, 360)
+        assert k == 360
+        return out
+
+
+def load_ref():
+    a, b = ORACLE_DIR / "_ref" / "libslref.so", ORACLE_DIR / "_ref" / "libnoderef.so"
+    if not (a.exists() and b.exists()):
+        return None
+    return RefLibs(C.CDLL(str(a)), C.CDLL(str(b)))
+
+
+def canon_equal_angle_runs(nodes: np.ndarray) -> np.ndarray:
+    """Canonical form for comparing ascend outputs: inside every run of equal angle the
+    reference order is whatever introsort leaves (unstable), so sort such runs by the
+    remaining fields.  Angles themselves must already be ascending."""
+    key = np.lexsort((nodes["flag"], nodes["quality"], nodes["dist_mm_q2"], nodes["angle_z_q14"]))
+    srt = nodes[key]
+    return srt
