@@ -22,6 +22,8 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                               const Tables &T, float *xyzi, uint32_t out_stride,
                               uint32_t *n_points, uint32_t *status);
+hipError_t launch_validate_div(hipStream_t s, float d, float rd, uint32_t e_lo, uint32_t e_hi,
+                               uint32_t *d_mismatches);
 hipError_t launch_pack(hipStream_t s, const float *xyzi, uint32_t out_stride,
                        const uint32_t *n_points, uint32_t B, float *packed, uint64_t *offsets);
 

@@ -28,7 +28,11 @@ struct rplgpu_ctx {
   // single-scan staging
   unsigned char *h_pin = nullptr;  // pinned: nodes | out (16 B / sample) | 2 x u32
   unsigned char *d_nodes = nullptr, *d_out = nullptr;
-  uint32_t *d_small = nullptr;  // [0]=n, [1]=count, [2]=status
+  uint32_t *d_small = nullptr;  // [0]=n, [1]=count, [2]=status, [8]=divide-validation mismatches
+  // fast-divide validation cache (see k_validate_div)
+  bool div4000_ok = false;
+  float leaf_checked = 0.0f;
+  bool leaf_ok = false;
   std::string err;
 };
 
@@ -62,11 +66,14 @@ rpl::KParams to_kparams(const rplgpu_params_t &p) {
   k.vox_scale_f = 1.0f;
   k.vox_L = 1;
   k.vox_bias = 32768;
+  k.inv_leaf = 1.0f;
+  k.fast_div = 0;
   if (p.voxel_leaf > 0.0f && std::isfinite(p.voxel_leaf)) {
     int K = 23 - std::ilogb(p.voxel_leaf);
     k.vox_scale = std::ldexp(1.0, K);
     k.vox_scale_f = (float)k.vox_scale;
     k.vox_L = (int32_t)std::llround((double)p.voxel_leaf * k.vox_scale);
+    k.inv_leaf = 1.0f / p.voxel_leaf;
   }
   return k;
 }
@@ -144,6 +151,18 @@ int32_t check_batch(rplgpu_ctx *c, const void *nodes, uint32_t n_stride, const v
     c->err = "batch larger than max_batch given to rplgpu_create";
     return RPLGPU_ERR_CAPACITY;
   }
+  return RPLGPU_OK;
+}
+
+// Exhaustively compare the mul+2*FMA divide with the IEEE divide for divisor d on the
+// device (about 2.4e9 operands, a few ms).  Returns RPLGPU_OK and sets *ok.
+int32_t validate_divisor(rplgpu_ctx *c, float d, uint32_t e_lo, uint32_t e_hi, bool *ok) {
+  uint32_t zero = 0, bad = 1;
+  RPL_HIP(c, hipMemcpyAsync(c->d_small + 8, &zero, 4, hipMemcpyHostToDevice, c->stream));
+  RPL_HIP(c, rpl::launch_validate_div(c->stream, d, 1.0f / d, e_lo, e_hi, c->d_small + 8));
+  RPL_HIP(c, hipMemcpyAsync(&bad, c->d_small + 8, 4, hipMemcpyDeviceToHost, c->stream));
+  RPL_HIP(c, hipStreamSynchronize(c->stream));
+  *ok = (bad == 0);
   return RPLGPU_OK;
 }
 
@@ -240,6 +259,8 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
     c->err = "staging allocation failed";
     return fail(RPLGPU_ERR_HIP);
   }
+  // dist_mm_q2 / 4000.0f: operands are the integer-valued floats 1 .. 2^32
+  if (validate_divisor(c, 4000.0f, 127, 159, &c->div4000_ok) != RPLGPU_OK) return fail(RPLGPU_ERR_HIP);
   *out = c;
   return RPLGPU_OK;
 }
@@ -310,9 +331,18 @@ int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
     return RPLGPU_ERR_INVALID_ARG;
   }
   RPL_HIP(h, hipSetDevice(h->device));
-  RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, to_kparams(*p),
-                               tables_of(h), p->voxel_enable != 0, d_xyzi, out_stride, d_n_points,
-                               d_status));
+  rpl::KParams kp = to_kparams(*p);
+  if (p->voxel_enable) {
+    // the cheap divides are used only for divisors proven bit-identical on this device
+    if (h->leaf_checked != p->voxel_leaf) {
+      int32_t vrc = validate_divisor(h, p->voxel_leaf, 27, 167, &h->leaf_ok);  // 2^-100..2^40
+      if (vrc) return vrc;
+      h->leaf_checked = p->voxel_leaf;
+    }
+    kp.fast_div = (h->div4000_ok && h->leaf_ok) ? 1 : 0;
+  }
+  RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(h),
+                               p->voxel_enable != 0, d_xyzi, out_stride, d_n_points, d_status));
   return RPLGPU_OK;
 }
 
