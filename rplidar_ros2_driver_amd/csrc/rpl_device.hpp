@@ -48,6 +48,7 @@ struct KParams {
   int32_t vox_L;      // leaf * 2^K: the leaf's 24-bit significand, exact
   int32_t vox_bias;   // 2^15 keeps every offset non-negative (|rounding slop| < L*2^-9)
   float inv_leaf;     // RN(1 / voxel_leaf)
+  unsigned long long *dbg;  // optional per-block phase cycle counters (developer aid), or null
   int32_t fast_div;   // 1: the mul+2*FMA divides by 4000 and by leaf were validated on this
                       //    device to be bit-identical to the IEEE divide (see k_validate_div)
 };

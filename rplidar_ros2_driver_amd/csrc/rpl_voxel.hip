@@ -53,7 +53,7 @@ struct VoxelLds {
   uint4 rec[kRecCap];          // {key, sum_x, sum_y, count<<16 | intensity_sum}
   uint32_t rowstart[kRowCap];
   uint32_t rowfill[kRowCap];
-  uint32_t bucket[kRecCap];    // (ix << 16 | record index) grouped by row
+  alignas(16) uint32_t bucket[kRecCap];  // (ix << 16 | record index) grouped by row
   uint32_t wcount[kWaves];
   uint32_t band_lo[34], band_hi[34];
   uint32_t misc[16];  // 1 status, 2 overflow, 3 sp, 4 rowmin, 5 rowmax, 7 out_base
@@ -98,9 +98,13 @@ __device__ __forceinline__ uint32_t voxel_wave_pass(VoxelLds &L, uint32_t wcnt, 
   return wcnt + ntails;
 }
 
-// a / d with one multiply and two FMAs; `rd` = RN(1/d).  Bit-identical to the IEEE
-// divide for every input the validation kernel (rpl_kernels.hip: k_validate_div) has
-// checked for this divisor; callers only use it after that check passed.
+// a / d without v_div_scale / v_rcp / v_div_fmas / v_div_fixup: `rd` = RN(1/d), one
+// multiply, the exact FMA remainder and one FMA correction (Markstein: a faithful first
+// quotient plus the correctly rounded reciprocal give the correctly rounded quotient).
+// The claim is not taken on faith: k_validate_div below compares it bit for bit with the
+// IEEE divide over the whole operand range for the divisor in use, on this device, and
+// the kernels only take this path after that check passed.  (The sign of a zero quotient
+// may differ; every user takes floor() -> int of it, where -0 and +0 coincide.)
 __device__ __forceinline__ float div_by(float a, float d, float rd) {
   float q = a * rd;
   float e = fmaf(-q, d, a);
@@ -134,6 +138,13 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
   const float2 *cs = p.inverted ? T.cs_inv : T.cs;
   const uint32_t ishift = p.is_new_protocol ? 0u : 2u;
   uint32_t flags = 0;
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = clock64();
+#define RPL_MARK(i)                      \
+  {                                      \
+    unsigned long long now_ = clock64(); \
+    tacc[i] += now_ - t_mark;            \
+    t_mark = now_;                       \
+  }
 
   while (true) {
     // ---- pop a key band -----------------------------------------------------------
@@ -149,15 +160,23 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     }
     __syncthreads();
 
-    // ---- phase S: stream the scan, 4 x 8 B per thread in flight ----------------------
+    // ---- phase S: stream the scan; the next 4 x 8 B per thread are already in flight
+    //      while the current ones are processed (software prefetch across iterations)
     uint32_t wcnt = 0;
     constexpr int UNR = 4;
+    uint2 nxt[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      uint32_t i = (uint32_t)u * kBlock + threadIdx.x;
+      nxt[u] = (i < n) ? scan[i] : make_uint2(0u, 0u);
+    }
     for (uint32_t base = 0; base < n; base += kBlock * UNR) {
       uint2 v[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
-        uint32_t i = base + (uint32_t)u * kBlock + threadIdx.x;
-        v[u] = (i < n) ? scan[i] : make_uint2(0u, 0u);
+        v[u] = nxt[u];
+        uint32_t i = base + kBlock * UNR + (uint32_t)u * kBlock + threadIdx.x;
+        nxt[u] = (i < n) ? scan[i] : make_uint2(0u, 0u);
       }
       if (*(volatile uint32_t *)&L.misc[2]) break;  // band already known not to fit
 #pragma unroll
@@ -187,6 +206,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     }
     if (lane_id() == 0) L.wcount[wave_id()] = wcnt;
     __syncthreads();
+    RPL_MARK(0)
 
     auto bisect = [&]() {  // block-uniform: replace the band by its two halves
       if (threadIdx.x == 0) {
@@ -235,6 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     }
     for (uint32_t t = threadIdx.x; t < kRowCap; t += kBlock) L.rowstart[t] = 0u;
     __syncthreads();
+    RPL_MARK(1)
     rmin = L.misc[4];
     const uint32_t out_base = L.misc[7];
     uint32_t ncell = 0;
@@ -248,6 +269,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
       for (int k = 0; k < (int)kRecPerThread; ++k)
         if (mine[k].x != kEmptyKey) atomicAdd(&L.rowstart[(mine[k].x >> 16) - rmin], 1u);
       __syncthreads();
+      RPL_MARK(2)
       uint32_t nrec;
       {  // exclusive scan over kRowCap = 2 rows per thread
         uint32_t r0 = L.rowstart[2 * threadIdx.x], r1 = L.rowstart[2 * threadIdx.x + 1];
@@ -258,6 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
         L.rowfill[2 * threadIdx.x + 1] = ex + r0;
       }
       __syncthreads();
+      RPL_MARK(3)
 #pragma unroll
       for (int k = 0; k < (int)kRecPerThread; ++k) {
         if (mine[k].x != kEmptyKey) {
@@ -267,6 +290,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
         }
       }
       __syncthreads();
+      RPL_MARK(4)
       // rank inside the row, then permute the records in place (they are all in registers)
 #pragma unroll
       for (int k = 0; k < (int)kRecPerThread; ++k) {
@@ -281,6 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
         }
       }
       __syncthreads();
+      RPL_MARK(5)
       // heads of equal-key groups -> cell index; thread t owns sorted records [7t, 7t+7)
       const uint32_t r_lo = threadIdx.x * kRecPerThread;
       uint32_t headbits = 0, nheads = 0;
@@ -296,41 +321,48 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
         prevkey = key;
       }
       uint32_t cell = block_excl_scan(nheads, L.tmp, &ncell);
-      const double inv_scale = 1.0 / p.vox_scale;  // exact power of two
+      RPL_MARK(6)
+      // position of every cell's first record (the bucket array is free again)
 #pragma unroll
-      for (int k = 0; k < (int)kRecPerThread; ++k) {
-        if ((headbits >> k) & 1u) {
-          uint32_t r = r_lo + k;
-          const uint32_t key = L.rec[r].x;
-          uint64_t sx = 0, sy = 0;
-          uint32_t cnt = 0, isum = 0;
-          for (; r < nrec; ++r) {  // segmented sum over the records of this cell
-            uint4 q = L.rec[r];
-            if (q.x != key) break;
-            sx += q.y;
-            sy += q.z;
-            cnt += q.w >> 16;
-            isum += q.w & 0xFFFFu;
-          }
-          if (out_base + cell < out_stride) {
-            int ix = (int)(key & 0xFFFFu) - 32768, iy = (int)(key >> 16) - 32768;
-            // exact integer coordinate sums in units of 2^-K m
-            int64_t Sx = (int64_t)sx + (int64_t)cnt * ((int64_t)ix * p.vox_L - (int64_t)vbias);
-            int64_t Sy = (int64_t)sy + (int64_t)cnt * ((int64_t)iy * p.vox_L - (int64_t)vbias);
-            double dc = (double)cnt;
-            double cx = ((double)Sx * inv_scale) / dc;  // == (fp64 sum of x) / count of the spec
-            double cy = ((double)Sy * inv_scale) / dc;
-            out[out_base + cell] =
-                make_float4((float)cx, (float)cy, 0.0f, (float)((double)isum / dc));
-          }
-          ++cell;
+      for (int k = 0; k < (int)kRecPerThread; ++k)
+        if ((headbits >> k) & 1u) L.bucket[cell++] = r_lo + k;
+      __syncthreads();
+      // one cell per thread, coalesced 16-byte output rows
+      const double inv_scale = 1.0 / p.vox_scale;  // exact power of two
+      const uint32_t nemit = min(ncell, out_stride > out_base ? out_stride - out_base : 0u);
+      for (uint32_t c = threadIdx.x; c < nemit; c += kBlock) {
+        uint32_t r = L.bucket[c];
+        const uint32_t key = L.rec[r].x;
+        uint64_t sx = 0, sy = 0;
+        uint32_t cnt = 0, isum = 0;
+        for (; r < nrec; ++r) {  // segmented sum over the records of this cell
+          uint4 q = L.rec[r];
+          if (q.x != key) break;
+          sx += q.y;
+          sy += q.z;
+          cnt += q.w >> 16;
+          isum += q.w & 0xFFFFu;
         }
+        int ix = (int)(key & 0xFFFFu) - 32768, iy = (int)(key >> 16) - 32768;
+        // exact integer coordinate sums in units of 2^-K m
+        int64_t Sx = (int64_t)sx + (int64_t)cnt * ((int64_t)ix * p.vox_L - (int64_t)vbias);
+        int64_t Sy = (int64_t)sy + (int64_t)cnt * ((int64_t)iy * p.vox_L - (int64_t)vbias);
+        double dc = (double)cnt;
+        double cx = ((double)Sx * inv_scale) / dc;  // == (fp64 sum of x) / count of the spec
+        double cy = ((double)Sy * inv_scale) / dc;
+        out[out_base + c] = make_float4((float)cx, (float)cy, 0.0f, (float)((double)isum / dc));
       }
     }
     __syncthreads();
     if (threadIdx.x == 0) L.misc[7] = out_base + ncell;
     __syncthreads();
+    RPL_MARK(7)
   }
+  if (p.dbg && threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p.dbg[8 * b + i] = tacc[i];
+  }
+#undef RPL_MARK
 
   if (flags) atomicOr(&L.misc[1], flags);
   __syncthreads();
@@ -343,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
 
 // ------------------------------------------------------------------------------
 // Divisor validation: div_by(a, d, RN(1/d)) must equal the IEEE quotient a / d for
-// every fp32 `a` with biased exponent in [e_lo, e_hi] (both signs) and for +-0.
+// every fp32 `a` with biased exponent in [e_lo, e_hi] (both signs); +-0 must give a zero.
 // ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_validate_div(float d, float rd, uint32_t e_lo,
                                                       uint32_t e_hi, uint32_t *mismatches) {
@@ -359,8 +391,8 @@ __global__ __launch_bounds__(256) void k_validate_div(float d, float rd, uint32_
     bad += (__float_as_uint(div_by(na, d, rd)) != __float_as_uint(na / d));
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    bad += (__float_as_uint(div_by(0.0f, d, rd)) != __float_as_uint(0.0f / d));
-    bad += (__float_as_uint(div_by(-0.0f, d, rd)) != __float_as_uint(-0.0f / d));
+    bad += (div_by(0.0f, d, rd) != 0.0f);
+    bad += (div_by(-0.0f, d, rd) != 0.0f);
   }
   if (bad) atomicAdd(mismatches, bad);
 }

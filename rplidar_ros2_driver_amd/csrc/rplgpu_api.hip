@@ -33,6 +33,7 @@ struct rplgpu_ctx {
   bool div4000_ok = false;
   float leaf_checked = 0.0f;
   bool leaf_ok = false;
+  unsigned long long *dbg = nullptr;  // developer aid: per-block phase cycle counters
   std::string err;
 };
 
@@ -68,6 +69,7 @@ rpl::KParams to_kparams(const rplgpu_params_t &p) {
   k.vox_bias = 32768;
   k.inv_leaf = 1.0f;
   k.fast_div = 0;
+  k.dbg = nullptr;
   if (p.voxel_leaf > 0.0f && std::isfinite(p.voxel_leaf)) {
     int K = 23 - std::ilogb(p.voxel_leaf);
     k.vox_scale = std::ldexp(1.0, K);
@@ -284,6 +286,19 @@ int32_t rplgpu_set_stream(rplgpu_handle_t h, void *hip_stream) {
   return RPLGPU_OK;
 }
 
+// Developer aid (not part of rplgpu.h): device buffer of 2*B u64 receiving, per scan, the
+// shader cycles k_cloud_voxel spent in its streaming and ranking phases.  0 = fast divides
+// rejected, 1 = accepted, via rplgpu_debug_fast_div.
+int32_t rplgpu_debug_set_cycle_buffer(rplgpu_handle_t h, void *d_buf) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  h->dbg = (unsigned long long *)d_buf;
+  return RPLGPU_OK;
+}
+int32_t rplgpu_debug_fast_div(rplgpu_handle_t h) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  return (h->div4000_ok ? 1 : 0) | (h->leaf_ok ? 2 : 0);
+}
+
 int32_t rplgpu_synchronize(rplgpu_handle_t h) {
   if (!h) return RPLGPU_ERR_INVALID_ARG;
   RPL_HIP(h, hipSetDevice(h->device));
@@ -341,6 +356,7 @@ int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
     }
     kp.fast_div = (h->div4000_ok && h->leaf_ok) ? 1 : 0;
   }
+  kp.dbg = h->dbg;
   RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(h),
                                p->voxel_enable != 0, d_xyzi, out_stride, d_n_points, d_status));
   return RPLGPU_OK;

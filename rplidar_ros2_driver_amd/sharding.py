@@ -39,22 +39,26 @@ def allgather_clouds(packed: torch.Tensor, n_points: int, scan_counts: torch.Ten
     world = dist.get_world_size(group)
     dev = packed.device
     meta = torch.tensor([int(n_points), int(scan_counts.numel())], dtype=torch.int64, device=dev)
-    metas = torch.empty(world, 2, dtype=torch.int64, device=dev)
+    # outputs are allocated flat (concatenation along dim 0): the one layout both the
+    # nccl (RCCL) and gloo implementations of all_gather_into_tensor accept
+    metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(metas, meta, group=group)
-    metas_h = metas.cpu()
+    metas_h = metas.view(world, 2).cpu()
     max_pts = int(metas_h[:, 0].max())
     max_scans = int(metas_h[:, 1].max())
 
     send = packed[:max_pts] if packed.shape[0] >= max_pts else torch.cat(
         [packed, packed.new_zeros(max_pts - packed.shape[0], 4)])
-    send = send.contiguous()
-    recv = torch.empty(world, max_pts, 4, dtype=packed.dtype, device=dev)
+    send = send.contiguous().view(-1)
+    recv = torch.empty(world * max_pts * 4, dtype=packed.dtype, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, max_pts, 4)
 
     cnt_send = torch.zeros(max_scans, dtype=torch.int64, device=dev)
     cnt_send[: scan_counts.numel()] = scan_counts.to(torch.int64)
-    cnt_recv = torch.empty(world, max_scans, dtype=torch.int64, device=dev)
+    cnt_recv = torch.empty(world * max_scans, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(cnt_recv, cnt_send, group=group)
+    cnt_recv = cnt_recv.view(world, max_scans)
 
     clouds: List[torch.Tensor] = []
     counts: List[torch.Tensor] = []

@@ -1,0 +1,76 @@
+"""Shared raw-scan test inputs: the edge cases of SURVEY.md §8(d) plus seeded synthetic
+scans at the BASELINE shapes (360 / 8192 / 32000 / 32768 samples)."""
+import numpy as np
+
+from rplidar_ros2_driver_amd import NODE_DTYPE, synth
+
+
+def edge_scans():
+    """Edge cases of SURVEY.md §8(d)."""
+    rng = np.random.default_rng(7)
+    out = {}
+
+    def mk(n):
+        return np.zeros(n, NODE_DTYPE)
+
+    a = mk(64)
+    a["angle_z_q14"] = np.arange(64) * 1000
+    out["all_invalid"] = a
+    b = a.copy()
+    b["dist_mm_q2"][37] = 8000
+    b["quality"][37] = 88
+    out["single_valid"] = b
+    c = mk(1)
+    c["dist_mm_q2"] = 4000
+    c["angle_z_q14"] = 123
+    out["n1_valid"] = c
+    out["n1_invalid"] = mk(1)
+    d = mk(2)
+    d["angle_z_q14"] = [40000, 100]
+    d["dist_mm_q2"] = [0, 5000]
+    out["n2_lead_invalid"] = d
+    e = synth.make_scan(3, 0, 360, invalid_p=0.0)
+    e["dist_mm_q2"][:25] = 0
+    e["dist_mm_q2"][-30:] = 0
+    out["lead_trail_runs"] = e
+    f = synth.make_scan(3, 1, 500, invalid_p=0.2)
+    f["angle_z_q14"] = np.sort(rng.integers(0, 200, 500)).astype(np.uint16) * 300  # many duplicates
+    out["dup_angles"] = f
+    g = synth.make_scan(3, 2, 300)
+    g["angle_z_q14"][-1] = 65535
+    g["angle_z_q14"][0] = 0
+    g["dist_mm_q2"][0] = 7000
+    g["dist_mm_q2"][-1] = 9000
+    out["q14_extremes"] = g
+    h = mk(3)  # KAT-2 of SURVEY.md §8(c)
+    h["angle_z_q14"] = [0, 65535, 32768]
+    h["dist_mm_q2"] = [4000, 8000, 4]
+    h["quality"] = [200, 100, 4]
+    out["kat2"] = h
+    k = synth.make_scan(3, 3, 777, kind="uniform", jitter=400, rotate=True)
+    out["unsorted_uniform"] = k
+    m = mk(100)  # huge distances: u32 -> f32 rounding and equal dist_m from different dist_q2
+    m["angle_z_q14"] = (np.arange(100) // 2) * 600
+    m["dist_mm_q2"] = 0xFFFFFF00 + (np.arange(100) % 7)
+    m["quality"] = np.arange(100)
+    out["huge_dist"] = m
+    return out
+
+
+def gen_cases():
+    cases = dict(edge_scans())
+    cases["c1_like_360"] = synth.make_scan(11, 0, 360, invalid_p=0.05)
+    cases["ring_8192"] = synth.make_scan(11, 1, 8192)
+    cases["ring_8192_rot_jit"] = synth.make_scan(11, 2, 8192, jitter=30, rotate=True)
+    cases["c2_32000"] = synth.make_scan(11, 3, 32000)
+    cases["c2_32000_newproto"] = synth.make_scan(11, 4, 32000, new_protocol=True, jitter=3)
+    cases["full_32768_unsorted"] = synth.make_scan(11, 5, 32768, kind="uniform", jitter=2000,
+                                                   rotate=True, invalid_p=0.3)
+    return cases
+
+
+
+CASES = gen_cases()
+
+# cases small enough to ship as golden fixtures (inputs + genuine-reference outputs)
+GOLDEN_CASES = [k for k, v in CASES.items() if len(v) <= 1000]

@@ -1,0 +1,71 @@
+"""Generate the golden vectors in tests/golden/ from the GENUINE reference code.
+
+Run in the build container (needs /root/reference and `make -C oracle ref`):
+    python tests/golden/make_golden.py
+Outputs (committed, small):
+    ascend_golden.npz        inputs + outputs of the real SDK ascendScanData
+                             (oracle/_ref/libslref.so <- /root/reference/src/sdk)
+    publish_scan_golden.npz  inputs + outputs of the real RPlidarNode::publish_scan
+                             (oracle/_ref/libnoderef.so <- /root/reference/src/rplidar_node.cpp)
+                             for every {protocol, inverted, scan_processing} combination
+    dummy_golden.npz         the first three scans of the real DummyLidarDriver
+The GPU box has no /root/reference; tests there compare against these files.
+"""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+
+from tests import oracle_lib  # noqa: E402
+from tests.cases import CASES, GOLDEN_CASES  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+
+def main():
+    ref = oracle_lib.load_ref()
+    if ref is None:
+        raise SystemExit("oracle/_ref not built: run `make -C oracle ref` where /root/reference exists")
+
+    asc = {}
+    for name in GOLDEN_CASES:
+        nodes = CASES[name]
+        out, res = ref.ascend(nodes)
+        asc[f"{name}__in"] = nodes
+        asc[f"{name}__out"] = out
+        asc[f"{name}__res"] = np.uint32(res)
+    # KAT-1 of SURVEY.md §8(c)
+    kat = np.zeros(8, oracle_lib.NODE)
+    for i in range(8):
+        kat[i] = ((7 - i) * 8192, 0 if i % 3 == 0 else 4000 * (i + 1), 4 * i, 0)
+    out, res = ref.ascend(kat)
+    asc["kat1__in"], asc["kat1__out"], asc["kat1__res"] = kat, out, np.uint32(res)
+    np.savez_compressed(OUT / "ascend_golden.npz", **asc)
+
+    pub = {}
+    for name in GOLDEN_CASES:
+        nodes = CASES[name]
+        pub[f"{name}__in"] = nodes
+        for kind in (0, 1, 2):  # Dummy / Real OLD_TYPE / Real NEW_TYPE
+            for inv in (0, 1):
+                for sp in (0, 1):
+                    r, i, m = ref.publish_scan(nodes, driver_kind=kind, inverted=inv,
+                                               scan_processing=sp, range_max=40.0,
+                                               scan_duration=0.125)
+                    tag = f"{name}__k{kind}_i{inv}_s{sp}"
+                    pub[tag + "__ranges"] = r.copy()
+                    pub[tag + "__intens"] = i.copy()
+                    pub[tag + "__meta"] = np.frombuffer(bytes(m), np.uint8).copy()
+    np.savez_compressed(OUT / "publish_scan_golden.npz", **pub)
+
+    dummy = {f"scan{k}": ref.dummy_grab() for k in range(3)}  # static phase: 0.1, 0.2, 0.3
+    np.savez_compressed(OUT / "dummy_golden.npz", **dummy)
+    for f in ("ascend_golden.npz", "publish_scan_golden.npz", "dummy_golden.npz"):
+        print(f, (OUT / f).stat().st_size, "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the scan-index sharding and the
+variable-length all-gather of voxelised clouds (the same code path RCCL runs on GPUs).
+The per-rank clouds come from the oracle here (no GPU in this container); what is under
+test is the sharding arithmetic and the exchange."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+from rplidar_ros2_driver_amd import synth  # noqa: E402
+from rplidar_ros2_driver_amd.sharding import allgather_clouds, shard_range, split_by_scan  # noqa: E402
+
+
+def test_shard_range_covers_everything():
+    for total in (0, 1, 7, 8, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _local_clouds(lo, hi, n):
+    from tests import oracle_lib
+    orc = oracle_lib.load_oracle()
+    p = oracle_lib.params(clip_enable=1, range_max=40.0, voxel_enable=1)
+    clouds = []
+    for s in range(lo, hi):
+        out, _, _ = orc.cloud_pipeline(synth.make_scan(77, s, n), p)
+        clouds.append(out)
+    return clouds
+
+
+def _worker(rank, world, port, total, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(total, world, rank)
+        clouds = _local_clouds(lo, hi, n)
+        counts = torch.tensor([len(c) for c in clouds], dtype=torch.int32)
+        packed = torch.from_numpy(np.concatenate(clouds + [np.zeros((0, 4), np.float32)]))
+        cap = torch.zeros(int(counts.sum()) + 5, 4)  # capacity > valid rows, like the GPU buffer
+        cap[: len(packed)] = packed
+        got_clouds, got_counts = allgather_clouds(cap, int(counts.sum()), counts)
+        # every rank must now hold every scan's cloud, in scan order
+        full = []
+        for r in range(world):
+            full += split_by_scan(got_clouds[r], got_counts[r])
+        ref = _local_clouds(0, total, n)
+        ok = len(full) == total and all(
+            f.numpy().tobytes() == w.tobytes() for f, w in zip(full, ref))
+        q.put((rank, bool(ok), len(full)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allgather_clouds_world2_gloo():
+    world, total, n = 2, 5, 1500  # uneven shard: 3 + 2 scans
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), res

@@ -10,6 +10,8 @@ out = sys.argv[1]
 
 def short(name):
     name = name.split("(")[0]
+    if name.startswith("void "):
+        name = name[5:]
     return name.replace("rpl::", "")
 
 

@@ -1,0 +1,37 @@
+"""Developer aid: phase cycle breakdown of k_cloud_voxel on the bench workload."""
+import ctypes as C
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from rplidar_ros2_driver_amd import Params, RplGpu, synth, abi
+
+B, n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 32000
+batch = synth.make_batch(2026, B, n)
+dev = torch.device("cuda:0")
+d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
+d_xyzi = torch.empty(B, 8192, 4, dtype=torch.float32, device=dev)
+d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+d_dbg = torch.zeros(B, 8, dtype=torch.int64, device=dev)
+gpu = RplGpu(0, 32768, B)
+lib = abi.load_library()
+lib.rplgpu_debug_set_cycle_buffer(gpu._h, C.c_void_p(d_dbg.data_ptr()))
+p = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
+st = torch.cuda.Stream(); torch.cuda.set_stream(st); gpu.set_stream(st.cuda_stream)
+for it in range(3):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(st)
+    gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_xyzi.data_ptr(), 8192,
+                        d_np.data_ptr(), d_st.data_ptr())
+    b.record(st); torch.cuda.synchronize()
+    print("kernel ms", a.elapsed_time(b))
+print("fast_div flags", lib.rplgpu_debug_fast_div(gpu._h))
+dbg = d_dbg.cpu().numpy()
+names = ["stream", "load+rowminmax", "rowhist", "rowscan", "scatter", "rank+permute", "heads+scan", "emit"]
+for i, nm in enumerate(names):
+    print("  %-16s mean %8.0f  p50 %8.0f  p99 %8.0f" % (nm, dbg[:, i].mean(), np.median(dbg[:, i]), np.percentile(dbg[:, i], 99)))
+print("  total mean %.0f" % dbg.sum(1).mean())
+npts = d_np.cpu().numpy()
+print("cells mean", npts.mean(), "status", int(d_st.max()))
