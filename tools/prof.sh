@@ -7,7 +7,7 @@ TAG=${1:-x}; shift || true
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-cd /tmp; export TMPDIR=/tmp
+cd /tmp; export TMPDIR=/tmp; export RPL_SYNTH_CACHE=/tmp/rplc
 BENCH="python $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 $*"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH > $OUT/stats.log 2>&1
 i=0
