@@ -28,6 +28,7 @@ struct Tables {
   const float *angle_inv;  // after the invert rule of :646-651
   const float2 *cs;        // (float)cos((double)angle), (float)sin((double)angle)
   const float2 *cs_inv;    // same for the inverted angle
+  const double *rcp;       // rcp[c] = RN(1.0 / c), c = 1..32768 (voxel centroids), rcp[0] = 0
 };
 
 struct KParams {
@@ -48,6 +49,13 @@ struct KParams {
   int32_t vox_L;      // leaf * 2^K: the leaf's 24-bit significand, exact
   int32_t vox_bias;   // 2^15 keeps every offset non-negative (|rounding slop| < L*2^-9)
   float inv_leaf;     // RN(1 / voxel_leaf)
+  // E1 keep mask as an integer interval on dist_mm_q2 (host-derived, see make_keep_interval in
+  // rplgpu_api.hip): keep <=> (dist_q2 - d_lo) <= d_span (unsigned) && quality >= q_min.
+  // dist_m = RN(u32->f32(d)) / 4000 is monotone in d, so the float compares against range_min /
+  // range_max select exactly one interval of d; d_lo >= 1 also covers the d != 0 test of :584.
+  uint32_t d_lo;
+  uint32_t d_span;
+  int32_t cell_range_safe;  // 1: host proved |cell index| < 32767 for every kept sample
   unsigned long long *dbg;  // optional per-block phase cycle counters (developer aid), or null
   int32_t fast_div;   // 1: the mul+2*FMA divides by 4000 and by leaf were validated on this
                       //    device to be bit-identical to the IEEE divide (see k_validate_div)
@@ -68,13 +76,11 @@ __device__ __forceinline__ float nd_dist_m(uint32_t dist_q2) {
 __device__ __forceinline__ float nd_intensity(uint32_t quality, int is_new_protocol) {
   return is_new_protocol ? (float)quality : (float)(quality >> 2);
 }
-// keep mask: :584 plus the optional E1 clip
-__device__ __forceinline__ bool nd_keep(uint32_t dist_q2, uint32_t quality, float dist_m,
-                                        const KParams &p) {
-  bool k = dist_q2 != 0u;
-  if (p.clip_enable) {
-    k = k && (quality >= p.q_min) && (dist_m >= p.range_min) && (dist_m <= p.range_max);
-  }
+// keep mask: :584 plus the optional E1 clip, as one unsigned interval test on dist_mm_q2
+// (KParams::d_lo / d_span; quality threshold only when clipping)
+__device__ __forceinline__ bool nd_keep(uint32_t dist_q2, uint32_t quality, const KParams &p) {
+  bool k = (dist_q2 - p.d_lo) <= p.d_span;
+  if (p.clip_enable) k = k && (quality >= p.q_min);
   return k;
 }
 

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void k_laserscan(
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
     uint32_t d = nd_dist(v[j]);
-    if (nd_keep(d, nd_quality(v[j]), nd_dist_m(d), p)) kept |= 1u << j;
+    if (nd_keep(d, nd_quality(v[j]), p)) kept |= 1u << j;
   }
   const uint32_t count = publish_masks_and_scan(kept, s_mask, s_cbase, s_tmp);
   if (threadIdx.x == 0) beam_count[b] = count;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud(
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
     uint32_t d = nd_dist(v[j]);
-    if (nd_keep(d, nd_quality(v[j]), nd_dist_m(d), p)) kept |= 1u << j;
+    if (nd_keep(d, nd_quality(v[j]), p)) kept |= 1u << j;
   }
   const uint32_t count = publish_masks_and_scan(kept, s_mask, s_cbase, s_tmp);
   if (threadIdx.x == 0) {

@@ -1,24 +1,38 @@
 // rpl_voxel.hip — k_cloud_voxel: raw scan -> clipped, voxel-downsampled PointCloud2
-// (extensions E1 + E2 + E4 of SURVEY.md §8 a-ext) in ONE streaming pass over the
-// packed 8-byte nodes.  One 1024-thread workgroup owns one scan.
+// (extensions E1 + E2 + E4 of SURVEY.md §8 a-ext) in ONE streaming pass over the packed
+// 8-byte nodes (reference layout src/sdk/include/sl_lidar_cmd.h:272-278).  One 1024-thread
+// workgroup (16 wave64) owns one scan.
 //
-// Phase S (streaming, straight-line code, no data-dependent loops):
-//   8-byte node -> keep mask, dist_m, (cos,sin) LUT -> x, y -> cell (iy, ix) and the
-//   fixed-point offsets inside the cell.  A smooth ring visits a 5 cm cell ~10-200
-//   samples in a row, so consecutive lanes mostly share a cell: runs are detected with
-//   one DPP lane shift + ballots, their partial sums come from three DPP prefix scans,
-//   and only the LAST lane of a run writes one 16-byte run record to an LDS queue
-//   (each wave owns a private queue segment: no atomics, deterministic order).
+// The kernel is VALU-issue bound, not latency bound (profiles/r01): on gfx950 only the plain
+// VOP2 add/sub/mul/fma/and/or/lshr/mov forms issue in ~2.4 cycles per wave, every other
+// vector op (conversions, floor, compares, selects, DPP, packed fp32, v_mbcnt, VOP3) takes
+// ~4.2, and ds_bpermute 24.  Phase S is therefore written to minimise issue cycles:
+//
+// Phase S (streaming, straight-line code):
+//   * one global_load_dwordx4 per lane = TWO consecutive samples (A, B); the (cos, sin)
+//     table entries of the next round are fetched one round ahead;
+//   * keep mask = one unsigned interval test on dist_mm_q2 (host-derived, rpl_device.hpp);
+//   * x/y arithmetic on packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32): polar->XY, the two
+//     validated mul+FMA divides by the leaf, the exact in-cell remainder;
+//   * cell key without integer conversions: (floor + 2^23 + 32768) puts iy/ix + 32768 into
+//     the low mantissa bits, one v_perm_b32 packs (iy, ix) into the 32-bit sort key;
+//   * a smooth ring stays in a 5 cm cell for ~10-200 samples, so runs of equal keys are
+//     aggregated before anything is stored: A and B merge in the lane, lanes merge through
+//     three plain DPP prefix scans, and a lane whose run ends writes ONE 16-byte record
+//     {key, prefix_x, prefix_y, prefix_count|intensity|tag} to an LDS queue.  The record
+//     holds the wave-pass PREFIX, not the run sum: the run sum is prefix(this record) -
+//     prefix(previous record of the same wave-pass), recovered in phase R, which removes
+//     every cross-lane gather (ds_bpermute) and every segmented-scan mask from the hot loop.
 // Phase R (per scan, regular data-parallel passes over the <= 7168 run records):
-//   counting sort by row + rank inside the row -> records in (iy, ix) order ->
-//   segmented integer sums over equal keys -> one output point per cell.
+//   prefix -> run sums, counting sort by row + rank inside the row -> records in (iy, ix)
+//   order -> segmented integer sums over equal keys -> one output point per cell.
 //
 // Fixed point: offset = (x - ix*leaf) * 2^K + 2^15 with 2^-K = ulp(leaf) (K = 28 for
 // 5 cm).  One fp32 FMA yields x - ix*leaf EXACTLY whenever x is a multiple of 2^-K
 // (|x| >= 3 cm at K = 28), so the integer sums are exact and sum/count reproduces the
 // spec's fp64 running sum bit for bit; closer to the axes the per-point error is
-// <= 2^-(K+1) m (1.9e-9 m), far below the 1e-6 m bar.  Integer sums are order
-// independent, so the kernel is run-to-run deterministic.
+// <= 2^-K m (3.7e-9 m), far below the 1e-6 m bar.  Integer sums are order
+// independent, so the kernel is run-to-run deterministic although the queue order is not.
 //
 // A scan whose records do not fit (or that spans > 2048 rows) is processed in key
 // bands: the key range is bisected until a band fits, each band re-streaming the scan
@@ -28,17 +42,39 @@
 
 namespace rpl {
 
-constexpr uint32_t kRecPerWave = 448;                 // run records per wave segment
-constexpr uint32_t kRecCap = kRecPerWave * kWaves;    // 7168 records (112 KiB)
+constexpr uint32_t kRecCap = 7168;                    // run records per scan (112 KiB)
 constexpr uint32_t kRecPerThread = kRecCap / kBlock;  // 7
 constexpr uint32_t kRowCap = 2048;                    // rows the counting sort handles
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
+constexpr float kKeyMagic = 8421376.0f;               // 2^23 + 32768
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
   return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, false);
 }
-// inclusive wave64 prefix sum entirely in the VALU (DPP row shifts + row broadcasts)
+// Three independent inclusive wave64 prefix sums, interleaved so that every DPP read is two
+// issue slots behind the write it depends on (no s_nop needed) and every step is ONE
+// v_add_u32_dpp (hipcc splits the row_bcast:31 step into mov + mov_dpp + add).
+__device__ __forceinline__ void wave_incl_scan3_dpp(uint32_t &a, uint32_t &b, uint32_t &c) {
+#define RPL_STEP(CTRL)                                   \
+  "v_add_u32_dpp %0, %0, %0 " CTRL "\n"     \
+  "v_add_u32_dpp %1, %1, %1 " CTRL "\n"     \
+  "v_add_u32_dpp %2, %2, %2 " CTRL "\n"
+  // s_nop 1: the operands may have been written by the VALU instruction just before (a DPP
+  // read needs two wait states after a VALU write; the assembler does not add them here)
+  asm volatile("s_nop 1\n" RPL_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               RPL_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               RPL_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               RPL_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               RPL_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               RPL_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               : "+v"(a), "+v"(b), "+v"(c));
+#undef RPL_STEP
+}
+// single inclusive wave64 prefix sum (phase R, not on the hot path)
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
   v = dpp_add<0x111, 0xF>(v);  // row_shr:1
   v = dpp_add<0x112, 0xF>(v);  // row_shr:2
@@ -50,53 +86,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 }
 
 struct VoxelLds {
-  uint4 rec[kRecCap];          // {key, sum_x, sum_y, count<<16 | intensity_sum}
+  uint4 rec[kRecCap];  // S: {key, prefix_x, prefix_y, tag<<24 | prefix(count<<16 | intensity)}
+                       // R: {key, sum_x, sum_y, count<<16 | intensity_sum}
   uint32_t rowstart[kRowCap];
   uint32_t rowfill[kRowCap];
-  alignas(16) uint32_t bucket[kRecCap];  // (ix << 16 | record index) grouped by row
-  uint32_t wcount[kWaves];
+  alignas(16) uint32_t bucket[kRecCap + 8];  // (ix << 16 | record index) grouped by row
   uint32_t band_lo[34], band_hi[34];
-  uint32_t misc[16];  // 1 status, 2 overflow, 3 sp, 4 rowmin, 5 rowmax, 7 out_base
+  uint32_t misc[16];  // 0 queue tail, 1 status, 2 overflow, 3 sp, 4 rowmin, 5 rowmax, 7 out_base
   uint32_t tmp[32];
 };
-
-// One wave-pass of phase S: turn 64 (key, qx, qy, inten) items into run records.
-// `key == kEmptyKey` marks a lane that contributes nothing.  Returns the new record
-// count of this wave's queue segment (wave-uniform).
-__device__ __forceinline__ uint32_t voxel_wave_pass(VoxelLds &L, uint32_t wcnt, uint32_t key,
-                                                    uint32_t qx, uint32_t qy, uint32_t inten) {
-  const bool kept = key != kEmptyKey;
-  const uint64_t keptmask = __ballot(kept);
-  // previous lane's key (wave_shr:1); lane 0 sees "no key"
-  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)kEmptyKey, (int)key, 0x138,
-                                                              0xF, 0xF, false);
-  const uint64_t headmask = __ballot(kept && (key != prev));
-  const uint64_t cont = keptmask & ~headmask;         // lanes continuing the previous lane's run
-  const uint64_t tailmask = keptmask & ~(cont >> 1);  // kept lanes whose successor starts anew
-  const uint32_t lane = lane_id();
-
-  const uint32_t ci = kept ? ((1u << 16) | inten) : 0u;  // [count : 16 | intensity sum : 16]
-  const uint32_t Px = wave_incl_scan_dpp(qx);
-  const uint32_t Py = wave_incl_scan_dpp(qy);
-  const uint32_t Pc = wave_incl_scan_dpp(ci);
-  // exclusive prefix at the head lane of my run
-  const uint64_t below = headmask & ((2ull << lane) - 1ull);
-  const int h = 63 - __builtin_clzll(below | 1ull);
-  const uint32_t Ex = (uint32_t)__shfl((int)(Px - qx), h, 64);
-  const uint32_t Ey = (uint32_t)__shfl((int)(Py - qy), h, 64);
-  const uint32_t Ec = (uint32_t)__shfl((int)(Pc - ci), h, 64);
-
-  const uint32_t ntails = (uint32_t)__popcll(tailmask);
-  if (wcnt + ntails > kRecPerWave) {  // wave-uniform: queue segment full -> bisect the band
-    if (lane == 0) L.misc[2] = 1u;
-    return wcnt;
-  }
-  if ((tailmask >> lane) & 1ull) {
-    const uint32_t pos = wcnt + (uint32_t)__popcll(tailmask & lanemask_lt());
-    L.rec[wave_id() * kRecPerWave + pos] = make_uint4(key, Px - Ex, Py - Ey, Pc - Ec);
-  }
-  return wcnt + ntails;
-}
 
 // a / d without v_div_scale / v_rcp / v_div_fmas / v_div_fixup: `rd` = RN(1/d), one
 // multiply, the exact FMA remainder and one FMA correction (Markstein: a faithful first
@@ -104,14 +102,296 @@ __device__ __forceinline__ uint32_t voxel_wave_pass(VoxelLds &L, uint32_t wcnt, 
 // The claim is not taken on faith: k_validate_div below compares it bit for bit with the
 // IEEE divide over the whole operand range for the divisor in use, on this device, and
 // the kernels only take this path after that check passed.  (The sign of a zero quotient
-// may differ; every user takes floor() -> int of it, where -0 and +0 coincide.)
+// may differ; every user takes floor() of it, where -0 and +0 coincide.)
 __device__ __forceinline__ float div_by(float a, float d, float rd) {
   float q = a * rd;
   float e = fmaf(-q, d, a);
   return fmaf(e, rd, q);
 }
+__device__ __forceinline__ f2 div_by2(f2 a, float d, float rd) {
+  const f2 dd = {d, d}, rr = {rd, rd};
+  f2 q = a * rr;
+  f2 e = __builtin_elementwise_fma(-q, dd, a);
+  return __builtin_elementwise_fma(e, rr, q);
+}
 
-template <bool FAST_DIV>
+// Per-sample arithmetic of phase S for one 8-byte node (lo, hi) and its table entry `c`.
+// Outputs the sort key (kEmptyKey when the sample is dropped) and the three quantities
+// that are summed per cell.  `flags` collects RPLGPU_SCAN_CELL_RANGE.
+template <bool FAST_DIV, bool BAND, bool SAFE, bool HASQ>
+__device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c, const KParams &p,
+                                             uint32_t q_min16, uint32_t ibfe_off,
+                                             uint32_t ibfe_w, uint32_t klo, uint32_t khi,
+                                             uint32_t &key, uint32_t &qx, uint32_t &qy,
+                                             uint32_t &ci, uint32_t &flags) {
+  const uint32_t d = __builtin_amdgcn_alignbit(hi, lo, 16);  // unaligned u32 at byte 2
+  key = kEmptyKey;
+  qx = 0u;
+  qy = 0u;
+  ci = 0u;
+  bool kept = (d - p.d_lo) <= p.d_span;                      // E1 (and :584)
+  if (HASQ) kept = kept && ((hi & 0x00FF0000u) >= q_min16);
+  bool taken = false;
+  if (kept) {
+    const float df = __uint2float_rn(d);
+    const float dm = FAST_DIV ? div_by(df, 4000.0f, 0.00025f) : df / 4000.0f;  // :590
+    const f2 cv = {c.x, c.y};
+    const f2 xy = cv * dm;                                                       // E2
+    f2 t;
+    if (FAST_DIV) {
+      t = div_by2(xy, p.voxel_leaf, p.inv_leaf);                                 // E4 cell
+    } else {
+      t.x = xy.x / p.voxel_leaf;
+      t.y = xy.y / p.voxel_leaf;
+    }
+    const f2 f = {__builtin_floorf(t.x), __builtin_floorf(t.y)};
+    bool ok = true;
+    if (!SAFE) {
+      ok = (fabsf(f.x) < 32767.0f) && (fabsf(f.y) < 32767.0f);
+      if (!ok) flags |= RPLGPU_SCAN_CELL_RANGE;
+    }
+    // iy + 32768 | ix + 32768 from the mantissas of f + (2^23 + 32768)
+    const uint32_t kx = __float_as_uint(f.x + kKeyMagic);
+    const uint32_t ky = __float_as_uint(f.y + kKeyMagic);
+    const uint32_t k = __builtin_amdgcn_perm(ky, kx, 0x05040100u);
+    if (BAND) ok = ok && (k >= klo) && (k <= khi);
+    if (ok) {
+      taken = true;
+      const f2 lf = {p.voxel_leaf, p.voxel_leaf};
+      const f2 r = __builtin_elementwise_fma(-f, lf, xy);  // x - ix*leaf, exact
+      const f2 o = r * p.vox_scale_f;
+      key = k;
+      qx = (uint32_t)((int)o.x + p.vox_bias);
+      qy = (uint32_t)((int)o.y + p.vox_bias);
+      ci = (1u << 16) | ((hi >> ibfe_off) & ibfe_w);  // count | intensity (:591-592)
+    }
+  }
+  return taken;
+}
+
+// Cross-lane part of one wave-pass over 128 samples: lane l holds samples A = 2l, B = 2l+1
+// (okA / okB: the sample survived the keep mask and carries a real key).
+// Returns false when the record queue is full (wave-uniform).
+__device__ __forceinline__ bool voxel_pair_pass(VoxelLds &L, uint32_t tag, bool okA, uint32_t keyA,
+                                                uint32_t xA, uint32_t yA, uint32_t cA, bool okB,
+                                                uint32_t keyB, uint32_t xB, uint32_t yB,
+                                                uint32_t cB) {
+  // lane l+1's first key; lane 63 sees a value no key can take (its run always ends)
+  const uint32_t nextA = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)keyA, 0x130,
+                                                               0xF, 0xF, false);  // wave_shl:1
+  const bool e1 = okA && (keyA != keyB);   // a run ends at A
+  const bool e2 = okB && (keyB != nextA);  // a run ends at B
+  const uint64_t m1 = __builtin_amdgcn_ballot_w64(e1), m2 = __builtin_amdgcn_ballot_w64(e2);
+  const uint32_t total = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+  if (total == 0u) return true;  // wave-uniform: nothing kept in this pass
+  // reserve queue slots: one LDS atomic by lane 0, its round trip overlaps the scans below
+  // (hand-placed so that the compiler's atomic optimiser does not wait for it right away)
+  uint32_t base = 0u;
+  if (lane_id() == 0) {
+    asm volatile("ds_add_rtn_u32 %0, %1, %2"
+                 : "=v"(base)
+                 : "v"((uint32_t)(uintptr_t)&L.misc[0]), "v"(total)
+                 : "memory");
+  }
+  uint32_t Px = xA + xB, Py = yA + yB, Pc = cA + cB;
+  wave_incl_scan3_dpp(Px, Py, Pc);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(base)::"memory");
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  if (base + total > kRecCap) return false;  // wave-uniform: queue full -> bisect the band
+  const uint32_t mb1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+  const uint32_t mb2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+  const uint32_t pos1 = base + mb1 + mb2;  // records are queued in sample order
+  uint32_t pos2;                           // pos1 + (e1 ? 1 : 0): the ballot is the carry-in
+  uint64_t carry_out;
+  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(pos2), "=s"(carry_out) : "v"(pos1), "s"(m1));
+  if (e1) L.rec[pos1] = make_uint4(keyA, Px - xB, Py - yB, (Pc - cB) | tag);
+  if (e2) L.rec[pos2] = make_uint4(keyB, Px, Py, Pc | tag);
+  return true;
+}
+
+// ------------------------------------------------------------------------------
+// Phase R for one key band: the queue of run records -> output cells in (iy, ix) order.
+// Returns 0 = done (ncell written to *ncell_out), 1 = the band must be bisected (too many rows).
+// ------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, const double *rcp,
+                                              float4 *__restrict__ out, uint32_t out_stride,
+                                              uint32_t b, uint32_t *ncell_out) {
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = clock64();
+#define RPL_MARK(i)                      \
+  {                                      \
+    unsigned long long now_ = clock64(); \
+    tacc[i] += now_ - t_mark;            \
+    t_mark = now_;                       \
+  }
+  auto flush_dbg = [&]() {
+    if (p.dbg && threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 1; i < 8; ++i) atomicAdd(&p.dbg[8 * b + i], tacc[i]);
+    }
+  };
+  const int vbias = p.vox_bias;
+  const uint32_t nrec = L.misc[0];
+  if (p.dbg && threadIdx.x == 0) tacc[7] += (unsigned long long)nrec << 40;  // developer aid
+  // thread t owns the queue records t, t + 1024, ... (a wave's seven 64-record slices come
+  // from seven different parts of the scan, which balances the ranking work below);
+  // prefix -> run sum against the record just before it when both come from the same
+  // wave-pass (equal tags)
+  uint4 mine[kRecPerThread];
+  uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
+#pragma unroll
+  for (int k = 0; k < (int)kRecPerThread; ++k) {
+    const uint32_t idx = threadIdx.x + (uint32_t)k * kBlock;
+    const bool ok = idx < nrec;
+    const uint4 raw = L.rec[ok ? idx : 0u];
+    const uint4 pr = L.rec[(ok && idx > 0u) ? idx - 1u : 0u];
+    const bool same = ok && idx > 0u && (((raw.w ^ pr.w) >> 24) == 0u);
+    uint4 m = raw;
+    m.y -= same ? pr.y : 0u;
+    m.z -= same ? pr.z : 0u;
+    m.w = (raw.w & 0x00FFFFFFu) - (same ? (pr.w & 0x00FFFFFFu) : 0u);
+    if (!ok) m = make_uint4(kEmptyKey, 0u, 0u, 0u);
+    mine[k] = m;
+    if (ok) {
+      rmin = min(rmin, m.x >> 16);
+      rmax = max(rmax, m.x >> 16);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    rmin = min(rmin, (uint32_t)__shfl_xor((int)rmin, d, 64));
+    rmax = max(rmax, (uint32_t)__shfl_xor((int)rmax, d, 64));
+  }
+  if (lane_id() == 0 && rmin != 0xFFFFFFFFu) {
+    atomicMin(&L.misc[4], rmin);
+    atomicMax(&L.misc[5], rmax);
+  }
+  for (uint32_t t = threadIdx.x; t < kRowCap; t += kBlock) L.rowstart[t] = 0u;
+  __syncthreads();  // every prefix was read before any record slot is rewritten below
+  RPL_MARK(1)
+  rmin = L.misc[4];
+  const uint32_t out_base = L.misc[7];
+  uint32_t ncell = 0;
+  if (rmin != 0xFFFFFFFFu) {  // at least one record (block-uniform)
+    if (L.misc[5] - rmin + 1u > kRowCap) {
+      flush_dbg();
+      return 1u;
+    }
+    // counting sort over rows
+#pragma unroll
+    for (int k = 0; k < (int)kRecPerThread; ++k)
+      if (mine[k].x != kEmptyKey) atomicAdd(&L.rowstart[(mine[k].x >> 16) - rmin], 1u);
+    __syncthreads();
+    RPL_MARK(2)
+    {  // exclusive scan over kRowCap = 2 rows per thread
+      uint32_t r0 = L.rowstart[2 * threadIdx.x], r1 = L.rowstart[2 * threadIdx.x + 1];
+      uint32_t tot;
+      uint32_t ex = block_excl_scan(r0 + r1, L.tmp, &tot);
+      L.rowstart[2 * threadIdx.x] = ex;
+      L.rowstart[2 * threadIdx.x + 1] = ex + r0;
+      L.rowfill[2 * threadIdx.x] = ex;
+      L.rowfill[2 * threadIdx.x + 1] = ex + r0;
+    }
+    __syncthreads();
+    RPL_MARK(3)
+#pragma unroll
+    for (int k = 0; k < (int)kRecPerThread; ++k) {
+      if (mine[k].x != kEmptyKey) {
+        uint32_t idx = threadIdx.x + (uint32_t)k * kBlock;
+        uint32_t pos = atomicAdd(&L.rowfill[(mine[k].x >> 16) - rmin], 1u);
+        L.bucket[pos] = (mine[k].x << 16) | idx;  // (ix, record index): unique
+      }
+    }
+    __syncthreads();
+    RPL_MARK(4)
+    // rank inside the row = number of smaller entries of the same row (rows are short on
+    // ring-like scans: the first 8 entries are compared without a loop), then permute the
+    // records in place (they are all in registers; nobody reads rec now)
+#pragma unroll
+    for (int k = 0; k < (int)kRecPerThread; ++k) {
+      if (mine[k].x != kEmptyKey) {
+        const uint32_t idx = threadIdx.x + (uint32_t)k * kBlock;
+        const uint32_t row = (mine[k].x >> 16) - rmin;
+        const uint32_t me = (mine[k].x << 16) | idx;
+        const uint32_t s0 = L.rowstart[row], s1 = L.rowfill[row];
+        uint32_t rank = s0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+          const uint32_t v = L.bucket[s0 + j];  // in bounds: the array is padded by 8
+          rank += ((s0 + j < s1) && (v < me)) ? 1u : 0u;
+        }
+        for (uint32_t m = s0 + 8u; m < s1; ++m) rank += (L.bucket[m] < me);
+        L.rec[rank] = mine[k];
+      }
+    }
+    __syncthreads();
+    RPL_MARK(5)
+    // heads of equal-key groups -> cell index; thread t owns sorted records [7t, 7t+7)
+    const uint32_t r_lo = threadIdx.x * kRecPerThread;
+    uint32_t headbits = 0, nheads = 0;
+    uint32_t prevkey = (r_lo > 0 && r_lo <= nrec) ? L.rec[r_lo - 1].x : kEmptyKey;
+#pragma unroll
+    for (int k = 0; k < (int)kRecPerThread; ++k) {
+      uint32_t r = r_lo + k;
+      uint32_t key = (r < nrec) ? L.rec[r].x : kEmptyKey;
+      if (r < nrec && key != prevkey) {
+        headbits |= 1u << k;
+        ++nheads;
+      }
+      prevkey = key;
+    }
+    uint32_t cell = block_excl_scan(nheads, L.tmp, &ncell);
+    RPL_MARK(6)
+    // position of every cell's first record (the bucket array is free again)
+#pragma unroll
+    for (int k = 0; k < (int)kRecPerThread; ++k)
+      if ((headbits >> k) & 1u) L.bucket[cell++] = r_lo + k;
+    __syncthreads();
+    // one cell per thread, coalesced 16-byte output rows.  All sums are exact in fp64
+    // (integers below 2^53); the quotient by the count uses the host-built correctly
+    // rounded reciprocal + one FMA remainder + one FMA correction (Markstein), which is the
+    // correctly rounded quotient, i.e. the spec's (fp64 sum) / count.
+    const double inv_scale = 1.0 / p.vox_scale;  // exact power of two
+    const double dL = (double)p.vox_L, dbias = (double)vbias;
+    const uint32_t nemit = min(ncell, out_stride > out_base ? out_stride - out_base : 0u);
+    for (uint32_t c = threadIdx.x; c < nemit; c += kBlock) {
+      uint32_t r = L.bucket[c];
+      uint4 q = L.rec[r];
+      const uint32_t key = q.x;
+      double sx = 0.0, sy = 0.0;
+      uint32_t cw = 0;
+      do {  // segmented sum over the records of this cell
+        sx += (double)q.y;
+        sy += (double)q.z;
+        cw += q.w;
+        if (++r >= nrec) break;
+        q = L.rec[r];
+      } while (q.x == key);
+      const uint32_t cnt = cw >> 16, isum = cw & 0xFFFFu;
+      const double ix = (double)((int)(key & 0xFFFFu) - 32768);
+      const double iy = (double)((int)(key >> 16) - 32768);
+      const double dc = (double)cnt, rc = rcp[cnt];
+      const double Sx = fma(dc, ix * dL - dbias, sx);  // coordinate sums in units of 2^-K m
+      const double Sy = fma(dc, iy * dL - dbias, sy);
+      const double si = (double)isum;
+      double qx = Sx * rc, qy = Sy * rc, qi = si * rc;
+      qx = fma(fma(-qx, dc, Sx), rc, qx);
+      qy = fma(fma(-qy, dc, Sy), rc, qy);
+      qi = fma(fma(-qi, dc, si), rc, qi);
+      out[out_base + c] = make_float4((float)(qx * inv_scale), (float)(qy * inv_scale), 0.0f,
+                                      (float)qi);
+    }
+  }
+  __syncthreads();
+  RPL_MARK(7)
+  flush_dbg();
+#undef RPL_MARK
+  *ncell_out = ncell;
+  return 0u;
+}
+
+template <bool FAST_DIV, bool SAFE>
 __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, float4 *__restrict__ xyzi, uint32_t out_stride,
@@ -131,12 +411,10 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
   }
   __syncthreads();
 
-  const float leaf = p.voxel_leaf;
-  const float rleaf = p.inv_leaf;
-  const float vscale = p.vox_scale_f;
-  const int vbias = p.vox_bias;
   const float2 *cs = p.inverted ? T.cs_inv : T.cs;
-  const uint32_t ishift = p.is_new_protocol ? 0u : 2u;
+  const uint32_t ishift = p.is_new_protocol ? 0u : 2u;  // :591-592
+  const uint32_t ibfe_off = 16u + ishift, ibfe_w = 0xFFu >> ishift;  // shift, mask
+  const uint32_t q_min16 = p.clip_enable ? (min(p.q_min, 256u) << 16) : 0u;
   uint32_t flags = 0;
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = clock64();
 #define RPL_MARK(i)                      \
@@ -146,6 +424,20 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     t_mark = now_;                       \
   }
 
+  // lane l of a round owns the sample pair (2i, 2i+1), i = round*1024 + thread
+  const uint32_t npairs = (n + 1u) >> 1;
+  // Bounds-checked buffer resource over this scan's n*8 bytes: a pair (or its second node)
+  // beyond the scan reads as zero, i.e. dist 0, which the keep test drops.  Every lane
+  // always issues the load, so the compiler's vmcnt bookkeeping is exact and the prefetch
+  // distance below is really kept.
+  const __amdgpu_buffer_rsrc_t scan_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
+  auto load_pair = [&](uint32_t i) -> uint4 {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)(i * 16u), 0, 0);
+    return make_uint4(t.x, t.y, t.z, t.w);
+  };
+
+  bool first_band = true;
   while (true) {
     // ---- pop a key band -----------------------------------------------------------
     const uint32_t sp = L.misc[3];
@@ -153,6 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     const uint32_t klo = L.band_lo[sp - 1], khi = L.band_hi[sp - 1];
     __syncthreads();
     if (threadIdx.x == 0) {
+      L.misc[0] = 0u;
       L.misc[2] = 0u;
       L.misc[3] = sp - 1;
       L.misc[4] = 0xFFFFFFFFu;
@@ -160,51 +453,40 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     }
     __syncthreads();
 
-    // ---- phase S: stream the scan; the next 4 x 8 B per thread are already in flight
-    //      while the current ones are processed (software prefetch across iterations)
-    uint32_t wcnt = 0;
-    constexpr int UNR = 4;
-    uint2 nxt[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      uint32_t i = (uint32_t)u * kBlock + threadIdx.x;
-      nxt[u] = (i < n) ? scan[i] : make_uint2(0u, 0u);
-    }
-    for (uint32_t base = 0; base < n; base += kBlock * UNR) {
-      uint2 v[UNR];
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        v[u] = nxt[u];
-        uint32_t i = base + kBlock * UNR + (uint32_t)u * kBlock + threadIdx.x;
-        nxt[u] = (i < n) ? scan[i] : make_uint2(0u, 0u);
+    // ---- phase S: raw pairs two rounds ahead, table entries one round ahead -------------
+    {
+      uint4 w1 = load_pair(threadIdx.x);
+      uint4 w2 = load_pair(kBlock + threadIdx.x);
+      float2 cA1 = cs[w1.x & 0xFFFFu], cB1 = cs[w1.z & 0xFFFFu];
+      uint32_t round = 0;
+      bool fits = true;  // wave-uniform: this wave has not seen the queue overflow
+      for (uint32_t base = 0; base < npairs && fits; base += kBlock, ++round) {
+        const uint4 w = w1;
+        const float2 cA = cA1, cB = cB1;
+        w1 = w2;
+        cA1 = cs[w1.x & 0xFFFFu];
+        cB1 = cs[w1.z & 0xFFFFu];
+        w2 = load_pair(base + 2u * kBlock + threadIdx.x);
+        uint32_t keyA, xA, yA, ciA, keyB, xB, yB, ciB;
+        bool okA, okB;
+#define RPL_SAMPLES(BAND, HASQ)                                                                   \
+  okA = voxel_sample<FAST_DIV, BAND, SAFE, HASQ>(w.x, w.y, cA, p, q_min16, ibfe_off, ibfe_w, klo, \
+                                                 khi, keyA, xA, yA, ciA, flags);                  \
+  okB = voxel_sample<FAST_DIV, BAND, SAFE, HASQ>(w.z, w.w, cB, p, q_min16, ibfe_off, ibfe_w, klo, \
+                                                 khi, keyB, xB, yB, ciB, flags);
+        if (first_band) {
+          if (q_min16) { RPL_SAMPLES(false, true) } else { RPL_SAMPLES(false, false) }
+        } else {
+          RPL_SAMPLES(true, true)
+        }
+#undef RPL_SAMPLES
+        // tag: (round, wave) — two neighbouring queue reservations never share it
+        const uint32_t tag = (((round & 15u) << 4) | wave_id()) << 24;
+        fits = voxel_pair_pass(L, tag, okA, keyA, xA, yA, ciA, okB, keyB, xB, yB, ciB);
       }
-      if (*(volatile uint32_t *)&L.misc[2]) break;  // band already known not to fit
-#pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const uint32_t d = nd_dist(v[u]);
-        const uint32_t qual = nd_quality(v[u]);
-        const float df = __uint2float_rn(d);
-        const float dm = FAST_DIV ? div_by(df, 4000.0f, 0.00025f) : df / 4000.0f;  // :590
-        bool kept = nd_keep(d, qual, dm, p);                                         // E1
-        const float2 c = cs[nd_q14(v[u])];
-        const float x = dm * c.x, y = dm * c.y;                                      // E2
-        const float tx = FAST_DIV ? div_by(x, leaf, rleaf) : x / leaf;               // E4 cell
-        const float ty = FAST_DIV ? div_by(y, leaf, rleaf) : y / leaf;
-        const float fx = floorf(tx), fy = floorf(ty);
-        const bool inrange = (fabsf(fx) < 32767.0f) && (fabsf(fy) < 32767.0f);
-        if (kept && !inrange) flags |= RPLGPU_SCAN_CELL_RANGE;
-        uint32_t key = ((uint32_t)((int)fy + 32768) << 16) | (uint32_t)((int)fx + 32768);
-        kept = kept && inrange && (key >= klo) && (key <= khi);
-        const int ox = (int)rintf(fmaf(-fx, leaf, x) * vscale) + vbias;
-        const int oy = (int)rintf(fmaf(-fy, leaf, y) * vscale) + vbias;
-        const uint32_t qx = kept ? (uint32_t)min(max(ox, 0), 0x1FFFFFF) : 0u;
-        const uint32_t qy = kept ? (uint32_t)min(max(oy, 0), 0x1FFFFFF) : 0u;
-        const uint32_t inten = kept ? (qual >> ishift) : 0u;
-        key = kept ? key : kEmptyKey;
-        wcnt = voxel_wave_pass(L, wcnt, key, qx, qy, inten);
-      }
+      if (!fits && lane_id() == 0) L.misc[2] = 1u;  // band does not fit
     }
-    if (lane_id() == 0) L.wcount[wave_id()] = wcnt;
+    first_band = false;
     __syncthreads();
     RPL_MARK(0)
 
@@ -229,139 +511,19 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
       continue;
     }
 
-    // ---- phase R ---------------------------------------------------------------------
-    // my (up to 7) records: linear index -> (wave segment, slot)
-    uint4 mine[kRecPerThread];
-    uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
-#pragma unroll
-    for (int k = 0; k < (int)kRecPerThread; ++k) {
-      uint32_t idx = threadIdx.x + (uint32_t)k * kBlock;
-      uint32_t w = idx / kRecPerWave, j = idx - w * kRecPerWave;
-      bool ok = j < L.wcount[w];
-      mine[k] = ok ? L.rec[idx] : make_uint4(kEmptyKey, 0u, 0u, 0u);
-      if (ok) {
-        rmin = min(rmin, mine[k].x >> 16);
-        rmax = max(rmax, mine[k].x >> 16);
-      }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      rmin = min(rmin, (uint32_t)__shfl_xor((int)rmin, d, 64));
-      rmax = max(rmax, (uint32_t)__shfl_xor((int)rmax, d, 64));
-    }
-    if (lane_id() == 0 && rmin != 0xFFFFFFFFu) {
-      atomicMin(&L.misc[4], rmin);
-      atomicMax(&L.misc[5], rmax);
-    }
-    for (uint32_t t = threadIdx.x; t < kRowCap; t += kBlock) L.rowstart[t] = 0u;
-    __syncthreads();
-    RPL_MARK(1)
-    rmin = L.misc[4];
-    const uint32_t out_base = L.misc[7];
+    // ---- phase R (out of line) ----------------------------------------------------------
     uint32_t ncell = 0;
-    if (rmin != 0xFFFFFFFFu) {  // at least one record (block-uniform)
-      if (L.misc[5] - rmin + 1u > kRowCap) {
-        bisect();
-        continue;
-      }
-      // counting sort over rows
-#pragma unroll
-      for (int k = 0; k < (int)kRecPerThread; ++k)
-        if (mine[k].x != kEmptyKey) atomicAdd(&L.rowstart[(mine[k].x >> 16) - rmin], 1u);
-      __syncthreads();
-      RPL_MARK(2)
-      uint32_t nrec;
-      {  // exclusive scan over kRowCap = 2 rows per thread
-        uint32_t r0 = L.rowstart[2 * threadIdx.x], r1 = L.rowstart[2 * threadIdx.x + 1];
-        uint32_t ex = block_excl_scan(r0 + r1, L.tmp, &nrec);
-        L.rowstart[2 * threadIdx.x] = ex;
-        L.rowstart[2 * threadIdx.x + 1] = ex + r0;
-        L.rowfill[2 * threadIdx.x] = ex;
-        L.rowfill[2 * threadIdx.x + 1] = ex + r0;
-      }
-      __syncthreads();
-      RPL_MARK(3)
-#pragma unroll
-      for (int k = 0; k < (int)kRecPerThread; ++k) {
-        if (mine[k].x != kEmptyKey) {
-          uint32_t idx = threadIdx.x + (uint32_t)k * kBlock;
-          uint32_t pos = atomicAdd(&L.rowfill[(mine[k].x >> 16) - rmin], 1u);
-          L.bucket[pos] = (mine[k].x << 16) | idx;  // (ix, record index): unique
-        }
-      }
-      __syncthreads();
-      RPL_MARK(4)
-      // rank inside the row, then permute the records in place (they are all in registers)
-#pragma unroll
-      for (int k = 0; k < (int)kRecPerThread; ++k) {
-        if (mine[k].x != kEmptyKey) {
-          uint32_t idx = threadIdx.x + (uint32_t)k * kBlock;
-          uint32_t row = (mine[k].x >> 16) - rmin;
-          uint32_t me = (mine[k].x << 16) | idx;
-          uint32_t s0 = L.rowstart[row], s1 = L.rowfill[row];
-          uint32_t rank = s0;
-          for (uint32_t m = s0; m < s1; ++m) rank += (L.bucket[m] < me);
-          L.rec[rank] = mine[k];
-        }
-      }
-      __syncthreads();
-      RPL_MARK(5)
-      // heads of equal-key groups -> cell index; thread t owns sorted records [7t, 7t+7)
-      const uint32_t r_lo = threadIdx.x * kRecPerThread;
-      uint32_t headbits = 0, nheads = 0;
-      uint32_t prevkey = (r_lo > 0 && r_lo <= nrec) ? L.rec[r_lo - 1].x : kEmptyKey;
-#pragma unroll
-      for (int k = 0; k < (int)kRecPerThread; ++k) {
-        uint32_t r = r_lo + k;
-        uint32_t key = (r < nrec) ? L.rec[r].x : kEmptyKey;
-        if (r < nrec && key != prevkey) {
-          headbits |= 1u << k;
-          ++nheads;
-        }
-        prevkey = key;
-      }
-      uint32_t cell = block_excl_scan(nheads, L.tmp, &ncell);
-      RPL_MARK(6)
-      // position of every cell's first record (the bucket array is free again)
-#pragma unroll
-      for (int k = 0; k < (int)kRecPerThread; ++k)
-        if ((headbits >> k) & 1u) L.bucket[cell++] = r_lo + k;
-      __syncthreads();
-      // one cell per thread, coalesced 16-byte output rows
-      const double inv_scale = 1.0 / p.vox_scale;  // exact power of two
-      const uint32_t nemit = min(ncell, out_stride > out_base ? out_stride - out_base : 0u);
-      for (uint32_t c = threadIdx.x; c < nemit; c += kBlock) {
-        uint32_t r = L.bucket[c];
-        const uint32_t key = L.rec[r].x;
-        uint64_t sx = 0, sy = 0;
-        uint32_t cnt = 0, isum = 0;
-        for (; r < nrec; ++r) {  // segmented sum over the records of this cell
-          uint4 q = L.rec[r];
-          if (q.x != key) break;
-          sx += q.y;
-          sy += q.z;
-          cnt += q.w >> 16;
-          isum += q.w & 0xFFFFu;
-        }
-        int ix = (int)(key & 0xFFFFu) - 32768, iy = (int)(key >> 16) - 32768;
-        // exact integer coordinate sums in units of 2^-K m
-        int64_t Sx = (int64_t)sx + (int64_t)cnt * ((int64_t)ix * p.vox_L - (int64_t)vbias);
-        int64_t Sy = (int64_t)sy + (int64_t)cnt * ((int64_t)iy * p.vox_L - (int64_t)vbias);
-        double dc = (double)cnt;
-        double cx = ((double)Sx * inv_scale) / dc;  // == (fp64 sum of x) / count of the spec
-        double cy = ((double)Sy * inv_scale) / dc;
-        out[out_base + c] = make_float4((float)cx, (float)cy, 0.0f, (float)((double)isum / dc));
-      }
+    if (voxel_reduce(L, p, T.rcp, out, out_stride, b, &ncell)) {
+      bisect();
+      continue;
     }
+    const uint32_t out_base = L.misc[7];
     __syncthreads();
     if (threadIdx.x == 0) L.misc[7] = out_base + ncell;
     __syncthreads();
-    RPL_MARK(7)
+    t_mark = clock64();
   }
-  if (p.dbg && threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) p.dbg[8 * b + i] = tacc[i];
-  }
+  if (p.dbg && threadIdx.x == 0) atomicAdd(&p.dbg[8 * b], tacc[0]);
 #undef RPL_MARK
 
   if (flags) atomicOr(&L.misc[1], flags);
@@ -376,6 +538,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
 // ------------------------------------------------------------------------------
 // Divisor validation: div_by(a, d, RN(1/d)) must equal the IEEE quotient a / d for
 // every fp32 `a` with biased exponent in [e_lo, e_hi] (both signs); +-0 must give a zero.
+// The packed form (v_pk_mul_f32 / v_pk_fma_f32) is checked in the same sweep.
 // ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_validate_div(float d, float rd, uint32_t e_lo,
                                                       uint32_t e_hi, uint32_t *mismatches) {
@@ -387,8 +550,10 @@ __global__ __launch_bounds__(256) void k_validate_div(float d, float rd, uint32_
     uint32_t bits = ((uint32_t)(e_lo + (uint32_t)(t >> 23)) << 23) | (uint32_t)(t & (per_exp - 1));
     float a = __uint_as_float(bits);
     float na = __uint_as_float(bits | 0x80000000u);
+    const f2 q2 = div_by2(f2{a, na}, d, rd);
+    bad += (__float_as_uint(q2.x) != __float_as_uint(a / d));
+    bad += (__float_as_uint(q2.y) != __float_as_uint(na / d));
     bad += (__float_as_uint(div_by(a, d, rd)) != __float_as_uint(a / d));
-    bad += (__float_as_uint(div_by(na, d, rd)) != __float_as_uint(na / d));
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     bad += (div_by(0.0f, d, rd) != 0.0f);
@@ -409,13 +574,15 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               const Tables &T, float *xyzi, uint32_t out_stride,
                               uint32_t *n_points, uint32_t *status) {
   if (B == 0) return hipSuccess;
+#define RPL_LAUNCH_VOXEL(FD, SF)                                                              \
+  hipLaunchKernelGGL((k_cloud_voxel<FD, SF>), dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, \
+                     n_stride, n_per_scan, p, T, (float4 *)xyzi, out_stride, n_points, status)
   if (p.fast_div) {
-    hipLaunchKernelGGL(k_cloud_voxel<true>, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes,
-                       n_stride, n_per_scan, p, T, (float4 *)xyzi, out_stride, n_points, status);
+    if (p.cell_range_safe) RPL_LAUNCH_VOXEL(true, true); else RPL_LAUNCH_VOXEL(true, false);
   } else {
-    hipLaunchKernelGGL(k_cloud_voxel<false>, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes,
-                       n_stride, n_per_scan, p, T, (float4 *)xyzi, out_stride, n_points, status);
+    if (p.cell_range_safe) RPL_LAUNCH_VOXEL(false, true); else RPL_LAUNCH_VOXEL(false, false);
   }
+#undef RPL_LAUNCH_VOXEL
   return hipGetLastError();
 }
 

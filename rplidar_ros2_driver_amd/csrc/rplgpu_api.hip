@@ -25,6 +25,7 @@ struct rplgpu_ctx {
   // tables
   float *d_angle = nullptr, *d_angle_inv = nullptr, *d_inc = nullptr;
   float2 *d_cs = nullptr, *d_cs_inv = nullptr;
+  double *d_rcp = nullptr;
   // single-scan staging
   unsigned char *h_pin = nullptr;  // pinned: nodes | out (16 B / sample) | 2 x u32
   unsigned char *d_nodes = nullptr, *d_out = nullptr;
@@ -50,6 +51,32 @@ thread_local std::string g_create_err;
     }                                                                                   \
   } while (0)
 
+// dist_m exactly as src/rplidar_node.cpp:590 evaluates it (u32 -> f32 RNE, IEEE divide).
+inline float host_dist_m(uint32_t d) { return static_cast<float>(d) / 4000.0f; }
+
+// E1 keep mask as an interval of dist_mm_q2.  dist_m is monotone non-decreasing in d, so
+//   {d : d != 0 && dist_m(d) >= range_min && dist_m(d) <= range_max} = [lo, hi]
+// found by bisection with the very float expression the per-sample test would use.
+// Returns false when the set is empty (also for NaN thresholds).
+bool make_keep_interval(float range_min, float range_max, uint32_t *lo, uint32_t *hi) {
+  const uint32_t dmax = 0xFFFFFFFFu;
+  if (!(host_dist_m(dmax) >= range_min)) return false;  // also catches NaN
+  if (!(host_dist_m(1u) <= range_max)) return false;
+  uint32_t a = 1u, b = dmax;  // smallest d with dist_m(d) >= range_min
+  while (a < b) {
+    uint32_t m = a + (b - a) / 2;
+    if (host_dist_m(m) >= range_min) b = m; else a = m + 1;
+  }
+  *lo = a;
+  a = 1u, b = dmax;  // largest d with dist_m(d) <= range_max
+  while (a < b) {
+    uint32_t m = a + (b - a + 1) / 2;
+    if (host_dist_m(m) <= range_max) a = m; else b = m - 1;
+  }
+  *hi = a;
+  return *lo <= *hi;
+}
+
 rpl::KParams to_kparams(const rplgpu_params_t &p) {
   rpl::KParams k;
   k.is_new_protocol = p.is_new_protocol != 0;
@@ -70,6 +97,20 @@ rpl::KParams to_kparams(const rplgpu_params_t &p) {
   k.inv_leaf = 1.0f;
   k.fast_div = 0;
   k.dbg = nullptr;
+  k.d_lo = 1u;  // :584 alone: dist_mm_q2 != 0
+  k.d_span = 0xFFFFFFFEu;
+  k.cell_range_safe = 0;
+  if (k.clip_enable) {
+    uint32_t lo, hi;
+    if (make_keep_interval(p.range_min, p.range_max, &lo, &hi)) {
+      k.d_lo = lo;
+      k.d_span = hi - lo;
+      if (p.voxel_leaf > 0.0f && host_dist_m(hi) / p.voxel_leaf < 32000.0f) k.cell_range_safe = 1;
+    } else {
+      k.d_span = 0u;
+      k.q_min = 256u;  // no quality byte reaches 256: nothing is kept
+    }
+  }
   if (p.voxel_leaf > 0.0f && std::isfinite(p.voxel_leaf)) {
     int K = 23 - std::ilogb(p.voxel_leaf);
     k.vox_scale = std::ldexp(1.0, K);
@@ -86,6 +127,7 @@ rpl::Tables tables_of(const rplgpu_ctx *c) {
   t.angle_inv = c->d_angle_inv;
   t.cs = c->d_cs;
   t.cs_inv = c->d_cs_inv;
+  t.rcp = c->d_rcp;
   return t;
 }
 
@@ -133,6 +175,7 @@ void free_ctx(rplgpu_ctx *c) {
   if (c->d_inc) (void)hipFree(c->d_inc);
   if (c->d_cs) (void)hipFree(c->d_cs);
   if (c->d_cs_inv) (void)hipFree(c->d_cs_inv);
+  if (c->d_rcp) (void)hipFree(c->d_rcp);
   if (c->d_nodes) (void)hipFree(c->d_nodes);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_small) (void)hipFree(c->d_small);
@@ -247,8 +290,12 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
       return fail(RPLGPU_ERR_INVALID_ARG);
     }
   }
+  // correctly rounded fp64 reciprocals of every possible per-cell sample count (IEEE divide)
+  std::vector<double> rcp(rpl::kMaxN + 1);
+  rcp[0] = 0.0;
+  for (uint32_t k = 1; k <= rpl::kMaxN; ++k) rcp[k] = 1.0 / static_cast<double>(k);
   int32_t rc;
-  if ((rc = upload(c, &c->d_angle, angle)) || (rc = upload(c, &c->d_angle_inv, angle_inv)) ||
+  if ((rc = upload(c, &c->d_rcp, rcp)) || (rc = upload(c, &c->d_angle, angle)) || (rc = upload(c, &c->d_angle_inv, angle_inv)) ||
       (rc = upload(c, &c->d_cs, cs)) || (rc = upload(c, &c->d_cs_inv, cs_inv)) ||
       (rc = upload(c, &c->d_inc, inc)))
     return fail(rc);

@@ -21,6 +21,7 @@ lib.rplgpu_debug_set_cycle_buffer(gpu._h, C.c_void_p(d_dbg.data_ptr()))
 p = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
 st = torch.cuda.Stream(); torch.cuda.set_stream(st); gpu.set_stream(st.cuda_stream)
 for it in range(3):
+    d_dbg.zero_()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(st)
     gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_xyzi.data_ptr(), 8192,
@@ -29,6 +30,9 @@ for it in range(3):
     print("kernel ms", a.elapsed_time(b))
 print("fast_div flags", lib.rplgpu_debug_fast_div(gpu._h))
 dbg = d_dbg.cpu().numpy()
+nrec = dbg[:, 7] >> 40
+dbg[:, 7] &= (1 << 40) - 1
+print("records/scan mean %.0f p50 %.0f p90 %.0f p99 %.0f max %d" % (nrec.mean(), np.median(nrec), np.percentile(nrec, 90), np.percentile(nrec, 99), nrec.max()))
 names = ["stream", "load+rowminmax", "rowhist", "rowscan", "scatter", "rank+permute", "heads+scan", "emit"]
 for i, nm in enumerate(names):
     print("  %-16s mean %8.0f  p50 %8.0f  p99 %8.0f" % (nm, dbg[:, i].mean(), np.median(dbg[:, i]), np.percentile(dbg[:, i], 99)))
