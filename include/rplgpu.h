@@ -13,7 +13,8 @@
  *         Q2mm->m, quality->intensity, sort, Mode A min-binning / Mode B raw mapping)
  *         -> rplgpu_scan_to_laserscan / rplgpu_laserscan_batch_dev
  *   ext polar->Cartesian PointCloud2 (x,y,z,intensity FLOAT32, point_step 16) with
- *         quality/range clip, radius-outlier removal and voxel-grid downsample
+ *         quality/range clip (E1), radius-outlier removal (E5, applied before the voxel
+ *         grid) and voxel-grid downsample (E4)
  *         (not in the reference; spec in SURVEY.md §8 a-ext / DESIGN.md)
  *         -> rplgpu_scan_to_cloud / rplgpu_cloud_batch_dev
  *

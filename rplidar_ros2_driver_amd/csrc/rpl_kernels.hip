@@ -303,8 +303,9 @@ __global__ __launch_bounds__(kBlock) void k_laserscan(
 // ------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_cloud(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
-    KParams p, Tables T, float4 *__restrict__ xyzi, uint32_t out_stride,
-    uint32_t *__restrict__ n_points, uint32_t *__restrict__ status) {
+    KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
+    float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
+    uint32_t *__restrict__ status) {
   __shared__ uint64_t s_mask[kChunks];
   __shared__ uint32_t s_cbase[kChunks];
   __shared__ uint32_t s_tmp[32];
@@ -321,6 +322,15 @@ __global__ __launch_bounds__(kBlock) void k_cloud(
   for (int j = 0; j < kIters; ++j) {
     uint32_t d = nd_dist(v[j]);
     if (nd_keep(d, nd_quality(v[j]), p)) kept |= 1u << j;
+  }
+  if (keepmask) {  // E5: the radius-outlier mask replaces the E1 mask (it already includes it)
+    const uint32_t *m = keepmask + (size_t)b * mask_stride;
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t word = 2u * ((uint32_t)(j * kWaves) + wave_id()) + (lane_id() >> 5);
+      const uint32_t bits = (word < mask_stride) ? m[word] : 0u;
+      if (!((bits >> (lane_id() & 31u)) & 1u)) kept &= ~(1u << j);
+    }
   }
   const uint32_t count = publish_masks_and_scan(kept, s_mask, s_cbase, s_tmp);
   if (threadIdx.x == 0) {
@@ -399,15 +409,16 @@ hipError_t launch_laserscan(hipStream_t s, const void *nodes, uint32_t n_stride,
 
 hipError_t launch_cloud(hipStream_t s, const void *nodes, uint32_t n_stride,
                         const uint32_t *n_per_scan, uint32_t B, const KParams &p, const Tables &T,
-                        bool voxel, float *xyzi, uint32_t out_stride, uint32_t *n_points,
-                        uint32_t *status) {
+                        bool voxel, const uint32_t *keepmask, uint32_t mask_stride, float *xyzi,
+                        uint32_t out_stride, uint32_t *n_points, uint32_t *status) {
   if (B == 0) return hipSuccess;
   if (voxel) {
-    return launch_cloud_voxel(s, nodes, n_stride, n_per_scan, B, p, T, xyzi, out_stride, n_points,
-                              status);
+    return launch_cloud_voxel(s, nodes, n_stride, n_per_scan, B, p, T, keepmask, mask_stride, xyzi,
+                              out_stride, n_points, status);
   } else {
     hipLaunchKernelGGL(k_cloud, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
-                       n_per_scan, p, T, (float4 *)xyzi, out_stride, n_points, status);
+                       n_per_scan, p, T, keepmask, mask_stride, (float4 *)xyzi, out_stride,
+                       n_points, status);
   }
   return hipGetLastError();
 }

@@ -14,14 +14,19 @@ hipError_t launch_laserscan(hipStream_t s, const void *nodes, uint32_t n_stride,
                             const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                             const Tables &T, const float *inc_table, float *ranges, float *intens,
                             uint32_t *beam_count);
+// `keepmask` (optional): one bit per sample from launch_ror_mask, `mask_stride` words per scan.
 hipError_t launch_cloud(hipStream_t s, const void *nodes, uint32_t n_stride,
                         const uint32_t *n_per_scan, uint32_t B, const KParams &p, const Tables &T,
-                        bool voxel, float *xyzi, uint32_t out_stride, uint32_t *n_points,
-                        uint32_t *status);
+                        bool voxel, const uint32_t *keepmask, uint32_t mask_stride, float *xyzi,
+                        uint32_t out_stride, uint32_t *n_points, uint32_t *status);
 hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_stride,
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
-                              const Tables &T, float *xyzi, uint32_t out_stride,
-                              uint32_t *n_points, uint32_t *status);
+                              const Tables &T, const uint32_t *keepmask, uint32_t mask_stride,
+                              float *xyzi, uint32_t out_stride, uint32_t *n_points,
+                              uint32_t *status);
+hipError_t launch_ror_mask(hipStream_t s, const void *nodes, uint32_t n_stride,
+                           const uint32_t *n_per_scan, uint32_t B, const KParams &p,
+                           const Tables &T, uint32_t *mask, uint32_t mask_stride);
 hipError_t launch_validate_div(hipStream_t s, float d, float rd, uint32_t e_lo, uint32_t e_hi,
                                uint32_t *d_mismatches);
 hipError_t launch_pack(hipStream_t s, const float *xyzi, uint32_t out_stride,

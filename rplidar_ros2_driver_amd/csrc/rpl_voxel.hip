@@ -394,8 +394,9 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
 template <bool FAST_DIV, bool SAFE>
 __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
-    KParams p, Tables T, float4 *__restrict__ xyzi, uint32_t out_stride,
-    uint32_t *__restrict__ n_points, uint32_t *__restrict__ status) {
+    KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
+    float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
+    uint32_t *__restrict__ status) {
   __shared__ VoxelLds L;
 
   const uint32_t b = blockIdx.x;
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     return make_uint4(t.x, t.y, t.z, t.w);
   };
 
+  const uint32_t *ror_bits = keepmask ? keepmask + (size_t)b * mask_stride : nullptr;
   bool first_band = true;
   while (true) {
     // ---- pop a key band -----------------------------------------------------------
@@ -461,12 +463,21 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
       uint32_t round = 0;
       bool fits = true;  // wave-uniform: this wave has not seen the queue overflow
       for (uint32_t base = 0; base < npairs && fits; base += kBlock, ++round) {
-        const uint4 w = w1;
+        const uint4 w0 = w1;
         const float2 cA = cA1, cB = cB1;
         w1 = w2;
         cA1 = cs[w1.x & 0xFFFFu];
         cB1 = cs[w1.z & 0xFFFFu];
         w2 = load_pair(base + 2u * kBlock + threadIdx.x);
+        uint4 w = w0;
+        if (keepmask) {  // E5 mask (one bit per sample): a dropped sample gets dist 0
+          const uint32_t pi = base + threadIdx.x;  // pair index -> bits 2*pi, 2*pi + 1
+          const uint32_t word = pi >> 4;
+          const uint32_t bits = (word < mask_stride) ? ror_bits[word] : 0u;
+          const uint32_t two = (bits >> ((pi & 15u) * 2u)) & 3u;
+          if (!(two & 1u)) { w.x &= 0x0000FFFFu; w.y &= 0xFFFF0000u; }
+          if (!(two & 2u)) { w.z &= 0x0000FFFFu; w.w &= 0xFFFF0000u; }
+        }
         uint32_t keyA, xA, yA, ciA, keyB, xB, yB, ciB;
         bool okA, okB;
 #define RPL_SAMPLES(BAND, HASQ)                                                                   \
@@ -571,12 +582,14 @@ hipError_t launch_validate_div(hipStream_t s, float d, float rd, uint32_t e_lo, 
 
 hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_stride,
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
-                              const Tables &T, float *xyzi, uint32_t out_stride,
-                              uint32_t *n_points, uint32_t *status) {
+                              const Tables &T, const uint32_t *keepmask, uint32_t mask_stride,
+                              float *xyzi, uint32_t out_stride, uint32_t *n_points,
+                              uint32_t *status) {
   if (B == 0) return hipSuccess;
 #define RPL_LAUNCH_VOXEL(FD, SF)                                                              \
   hipLaunchKernelGGL((k_cloud_voxel<FD, SF>), dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, \
-                     n_stride, n_per_scan, p, T, (float4 *)xyzi, out_stride, n_points, status)
+                     n_stride, n_per_scan, p, T, keepmask, mask_stride, (float4 *)xyzi, out_stride, \
+                     n_points, status)
   if (p.fast_div) {
     if (p.cell_range_safe) RPL_LAUNCH_VOXEL(true, true); else RPL_LAUNCH_VOXEL(true, false);
   } else {

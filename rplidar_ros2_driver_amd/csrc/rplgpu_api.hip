@@ -29,6 +29,7 @@ struct rplgpu_ctx {
   // single-scan staging
   unsigned char *h_pin = nullptr;  // pinned: nodes | out (16 B / sample) | 2 x u32
   unsigned char *d_nodes = nullptr, *d_out = nullptr;
+  uint32_t *d_rormask = nullptr;  // E5 keep bits, max_b scans x kMaskStride words
   uint32_t *d_small = nullptr;  // [0]=n, [1]=count, [2]=status, [8]=divide-validation mismatches
   // fast-divide validation cache (see k_validate_div)
   bool div4000_ok = false;
@@ -39,6 +40,8 @@ struct rplgpu_ctx {
 };
 
 namespace {
+
+constexpr uint32_t kMaskStride = rpl::kMaxN / 32u;  // keep-mask words per scan
 
 thread_local std::string g_create_err;
 
@@ -179,6 +182,7 @@ void free_ctx(rplgpu_ctx *c) {
   if (c->d_nodes) (void)hipFree(c->d_nodes);
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_small) (void)hipFree(c->d_small);
+  if (c->d_rormask) (void)hipFree(c->d_rormask);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -384,8 +388,8 @@ int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
   int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
   if (rc) return rc;
   if (!p || !d_xyzi || !d_n_points || out_stride == 0) return RPLGPU_ERR_INVALID_ARG;
-  if (p->ror_enable) {
-    h->err = "radius outlier removal (E5) is not implemented on the device yet";
+  if (p->ror_enable && !(p->ror_radius > 0.0f && p->ror_radius <= 1.0e6f)) {
+    h->err = "ror_radius must be in (0, 1e6] m";
     return RPLGPU_ERR_INVALID_ARG;
   }
   if (p->voxel_enable && !(p->voxel_leaf >= 1e-6f && p->voxel_leaf <= 1024.0f)) {
@@ -404,8 +408,17 @@ int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
     kp.fast_div = (h->div4000_ok && h->leaf_ok) ? 1 : 0;
   }
   kp.dbg = h->dbg;
+  const uint32_t *mask = nullptr;
+  if (p->ror_enable) {  // E5 before E4: per-sample keep bits, then the cloud kernels apply them
+    if (!h->d_rormask)
+      RPL_HIP(h, hipMalloc((void **)&h->d_rormask, (size_t)h->max_b * kMaskStride * 4u));
+    RPL_HIP(h, rpl::launch_ror_mask(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
+                                    tables_of(h), h->d_rormask, kMaskStride));
+    mask = h->d_rormask;
+  }
   RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(h),
-                               p->voxel_enable != 0, d_xyzi, out_stride, d_n_points, d_status));
+                               p->voxel_enable != 0, mask, kMaskStride, d_xyzi, out_stride,
+                               d_n_points, d_status));
   return RPLGPU_OK;
 }
 

@@ -156,6 +156,77 @@ def test_cloud_xyz_matches_oracle(gpu, oracle, name, inverted):
         assert np.max(np.abs(got[:, :2] - want[:, :2])) <= XYZ_TOL
 
 
+# --------------------------------------------------------------------------- E5 radius outliers
+def _ror_cases():
+    rng = np.random.default_rng(99)
+    cases = {
+        "ring_noise_4000": synth.make_scan(41, 0, 4000, noise_m=0.08, r0_range=(4.0, 5.0)),
+        "uniform_777": CASES["unsorted_uniform"],
+        "ring_8192_rot_jit": CASES["ring_8192_rot_jit"],
+        "c1_like_360": CASES["c1_like_360"],
+        "kat2": CASES["kat2"],
+        "all_invalid": CASES["all_invalid"],
+        "single_valid": CASES["single_valid"],
+        "near_origin": synth.make_scan(41, 1, 3000, r0_range=(0.16, 0.3)),
+    }
+    sp = synth.make_scan(41, 2, 6000, r0_range=(10.0, 12.0))  # isolated returns in empty space
+    hole = rng.random(6000) < 0.9
+    sp["dist_mm_q2"][hole] = 0
+    cases["sparse_6000"] = sp
+    return cases
+
+
+ROR_CASES = _ror_cases()
+
+
+@pytest.mark.parametrize("inverted", [0, 1])
+@pytest.mark.parametrize("name", list(ROR_CASES))
+def test_ror_cloud_matches_oracle(gpu, oracle, name, inverted):
+    """E5: the keep mask is integer work -> the surviving cloud must be bit-identical."""
+    nodes = ROR_CASES[name]
+    p = Params.defaults(inverted=inverted, clip_enable=1, range_min=0.15, range_max=40.0,
+                        ror_enable=1, ror_radius=0.10, ror_min_neighbors=2)
+    want = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(p))
+    got, status = gpu.scan_to_cloud(nodes, p)
+    assert status == 0
+    assert got.shape == want.shape
+    assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("radius,k", [(0.05, 1), (0.03, 4), (0.10, 3)])
+def test_ror_parameters(gpu, oracle, radius, k):
+    nodes = ROR_CASES["ring_noise_4000"]
+    p = Params.defaults(clip_enable=1, range_max=40.0, ror_enable=1, ror_radius=radius,
+                        ror_min_neighbors=k)
+    want = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(p))
+    base = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(
+        Params.defaults(clip_enable=1, range_max=40.0)))
+    got, status = gpu.scan_to_cloud(nodes, p)
+    assert status == 0 and got.tobytes() == want.tobytes()
+    assert 0 < len(want) < len(base)  # the filter really removes something here
+
+
+def test_ror_then_voxel_matches_oracle(gpu, oracle):
+    """C5 pipeline: E1 clip -> E5 radius outlier removal -> E4 voxel grid."""
+    for name in ("ring_noise_4000", "sparse_6000", "ring_8192_rot_jit"):
+        nodes = ROR_CASES[name]
+        p = Params.defaults(clip_enable=1, range_max=40.0, ror_enable=1, voxel_enable=1)
+        want, wcells, _ = oracle.cloud_pipeline(nodes, oracle_lib.copy_params(p))
+        got, status = gpu.scan_to_cloud(nodes, p)
+        assert status == 0 and len(got) == len(want)
+        if len(want):
+            assert np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2])) <= XYZ_TOL
+            assert got[:, 3].tobytes() == want[:, 3].tobytes()
+
+
+def test_ror_full_scan_32000(gpu, oracle):
+    nodes = synth.make_scan(43, 0, 32000, noise_m=0.05)
+    p = Params.defaults(clip_enable=1, range_max=40.0, ror_enable=1)
+    want = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(p))  # O(n^2): ~1e9 pair tests
+    got, status = gpu.scan_to_cloud(nodes, p)
+    assert status == 0 and got.tobytes() == want.tobytes()
+
+
 def _cells_of(xyzi, leaf):
     leaf = np.float32(leaf)
     ix = np.floor(xyzi[:, 0] / leaf).astype(np.int32)
@@ -290,6 +361,39 @@ def test_batch_dev_matches_single_scan_and_oracle(gpu, oracle):
             assert oracle_lib.canon_equal_angle_runs(asc[b, : lens[b]]).tobytes() == \
                 oracle_lib.canon_equal_angle_runs(want).tobytes()
         assert asc[b, lens[b]:].tobytes() == batch[b, lens[b]:].tobytes()  # tail untouched
+
+
+def test_c5_eight_sensors_fused_cloud(gpu, oracle):
+    """BASELINE config 5 on one device: 8 sensors x one 32 000-sample scan each, E1 clip ->
+    E5 radius-outlier removal -> E4 voxel grid, packed into ONE fused cloud (sensor order;
+    the reference only ever publishes the identity base_link->frame_id transform,
+    src/rplidar_node.cpp:183-197)."""
+    torch = _torch()
+    S, n = 8, 32000
+    batch = np.stack([synth.make_scan(500 + s, 0, n, noise_m=0.03, jitter=2) for s in range(S)])
+    dev = torch.device("cuda:0")
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(S, n * 8)).to(dev)
+    d_len = torch.full((S,), n, dtype=torch.int32, device=dev)
+    p = Params.defaults(clip_enable=1, range_max=40.0, ror_enable=1, voxel_enable=1)
+    out_stride = 16384
+    d_xyzi = torch.zeros(S, out_stride, 4, dtype=torch.float32, device=dev)
+    d_np = torch.zeros(S, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(S, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+    d_packed = torch.zeros(S * out_stride, 4, dtype=torch.float32, device=dev)
+    gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), S, p, d_xyzi.data_ptr(),
+                        out_stride, d_np.data_ptr(), d_st.data_ptr())
+    gpu.pack_clouds_dev(d_xyzi.data_ptr(), out_stride, d_np.data_ptr(), S, d_packed.data_ptr(),
+                        d_off.data_ptr())
+    gpu.synchronize()
+    assert int(d_st.max()) == 0
+    off = d_off.cpu().numpy()
+    fused = d_packed.cpu().numpy()[: off[S]]
+    want = [oracle.cloud_pipeline(batch[s], oracle_lib.copy_params(p))[0] for s in range(S)]
+    assert [int(off[s + 1] - off[s]) for s in range(S)] == [len(w) for w in want]
+    ref = np.concatenate(want)
+    assert np.max(np.abs(fused[:, :2].astype(np.float64) - ref[:, :2])) <= XYZ_TOL
+    assert fused[:, 3].tobytes() == ref[:, 3].tobytes()
 
 
 def test_full_size_properties(gpu):
