@@ -1,0 +1,109 @@
+// host_selftest — drives the C++ host mirror (rplgpu_host.hpp) exactly the way the patched
+// node would: grab_scan_data-style ascend, then the publish_scan body and the
+// PointCloud2 extension, on a raw scan read from a file (8-byte nodes), and dumps the
+// resulting messages as flat binary so that a test can compare them with the oracle.
+//
+//   host_selftest <nodes.bin> <out.bin> <is_new> <inverted> <scan_processing> <ascend 0|1> <cloud 0|1|2>
+//   out.bin: u32 published, 7 x f32 meta, u32 count, ranges[count], intensities[count],
+//            u32 sl_result, u32 n_points, xyzi[4*n_points]
+//   no arguments: config-1 smoke run (3 Dummy scans through the whole path).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+#include "rplgpu_host.hpp"
+
+namespace {
+struct PointField {
+  std::string name;
+  uint32_t offset = 0;
+  uint8_t datatype = 0;
+  uint32_t count = 0;
+};
+struct LaserScan {  // field names of sensor_msgs/msg/LaserScan
+  float angle_min = 0, angle_max = 0, angle_increment = 0, time_increment = 0, scan_time = 0;
+  float range_min = 0, range_max = 0;
+  std::vector<float> ranges, intensities;
+};
+struct PointCloud2 {  // field names of sensor_msgs/msg/PointCloud2
+  uint32_t height = 0, width = 0;
+  std::vector<PointField> fields;
+  bool is_bigendian = false;
+  uint32_t point_step = 0, row_step = 0;
+  std::vector<uint8_t> data;
+  bool is_dense = false;
+};
+}  // namespace
+
+int main(int argc, char **argv) {
+  rplgpu_host::ScanPath path;
+  if (!path.configure(0, 32768)) {
+    std::fprintf(stderr, "configure failed: %s\n", path.last_error().c_str());
+    return 2;
+  }
+  if (argc < 8) {
+    float phase = 0.0f;
+    std::vector<rplgpu_node_t> nodes;
+    rplgpu_host::ScanConfig cfg;
+    cfg.cached_current_max_range = 40.0f;  // Dummy hw limit, src/lidar_driver_wrapper.cpp:439
+    for (int s = 0; s < 3; ++s) {
+      rplgpu_host::dummy_scan(phase, nodes);
+      LaserScan msg;
+      if (!path.fill_laser_scan(nodes, cfg, 0.1, msg) || msg.ranges.size() != 360) {
+        std::fprintf(stderr, "dummy scan %d failed: %s\n", s, path.last_error().c_str());
+        return 3;
+      }
+      std::printf("dummy scan %d: %zu beams, ranges[0]=%.6f intensities[0]=%.1f\n", s,
+                  msg.ranges.size(), msg.ranges[0], msg.intensities[0]);
+    }
+    return 0;
+  }
+  std::FILE *f = std::fopen(argv[1], "rb");
+  if (!f) return 4;
+  std::fseek(f, 0, SEEK_END);
+  const long bytes = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  std::vector<rplgpu_node_t> nodes(static_cast<size_t>(bytes) / 8);
+  if (!nodes.empty() && std::fread(nodes.data(), 8, nodes.size(), f) != nodes.size()) return 4;
+  std::fclose(f);
+
+  rplgpu_host::ScanConfig cfg;
+  cfg.is_new_protocol = std::atoi(argv[3]) != 0;
+  cfg.inverted = std::atoi(argv[4]) != 0;
+  cfg.scan_processing = std::atoi(argv[5]) != 0;
+  cfg.cached_current_max_range = 40.0f;
+  uint32_t sl_result = 0;
+  if (std::atoi(argv[6])) sl_result = path.ascendScanData(nodes.data(), nodes.size());  // S1
+
+  LaserScan msg;
+  const bool published = path.fill_laser_scan(nodes, cfg, 0.125, msg);  // S3
+  PointCloud2 cloud;
+  const int cloud_mode = std::atoi(argv[7]);
+  if (cloud_mode) {
+    cfg.clip_enable = true;
+    cfg.voxel_enable = cloud_mode == 2;
+    if (!path.fill_point_cloud2(nodes, cfg, cloud) && !nodes.empty()) {
+      std::fprintf(stderr, "cloud failed: %s\n", path.last_error().c_str());
+      return 5;
+    }
+  }
+  std::FILE *o = std::fopen(argv[2], "wb");
+  if (!o) return 6;
+  const uint32_t pub = published ? 1u : 0u, count = static_cast<uint32_t>(msg.ranges.size());
+  const float meta[7] = {msg.angle_min, msg.angle_max, msg.angle_increment, msg.time_increment,
+                         msg.scan_time, msg.range_min, msg.range_max};
+  std::fwrite(&pub, 4, 1, o);
+  std::fwrite(meta, 4, 7, o);
+  std::fwrite(&count, 4, 1, o);
+  std::fwrite(msg.ranges.data(), 4, count, o);
+  std::fwrite(msg.intensities.data(), 4, count, o);
+  std::fwrite(&sl_result, 4, 1, o);
+  std::fwrite(&cloud.width, 4, 1, o);
+  std::fwrite(cloud.data.data(), 1, cloud.data.size(), o);
+  // the (possibly ascended) nodes, so the caller can check S1 as well
+  std::fwrite(nodes.data(), 8, nodes.size(), o);
+  std::fclose(o);
+  return 0;
+}

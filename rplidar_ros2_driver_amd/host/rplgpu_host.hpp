@@ -1,0 +1,230 @@
+// rplgpu_host.hpp — C++ host side of the MI355X scan path, mirroring the reference's own
+// call sites so that the node keeps its ROS 2 surface and only the per-sample loops move.
+//
+// Reference seams (citations relative to the reference tree):
+//   S1  drv_->ascendScanData(buf, count)            src/lidar_driver_wrapper.cpp:329
+//         -> rplgpu_host::ScanPath::ascendScanData(buf, count)
+//   S3  RPlidarNode::publish_scan body :568-680      src/rplidar_node.cpp
+//         -> rplgpu_host::ScanPath::fill_laser_scan(nodes, ..., scan_msg)   (everything up to,
+//            but not including, scan_pub_->publish(scan_msg) at :682)
+//   ext PointCloud2 (x, y, z, intensity FLOAT32; point_step 16) with clip / radius-outlier /
+//         voxel grid -> rplgpu_host::ScanPath::fill_point_cloud2(nodes, ..., cloud_msg)
+//
+// Header only, no ROS dependency: the message types are template parameters, so the same
+// code compiles against sensor_msgs::msg::LaserScan / PointCloud2 in the node and against
+// plain stand-ins in tests.  Everything goes through the C ABI of librplgpu.so
+// (include/rplgpu.h); there is no CPU implementation here — on any error the functions return
+// false and leave the message untouched, and the caller keeps its own CPU loop as fallback
+// (INTEGRATION.md).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "rplgpu.h"
+
+namespace rplgpu_host {
+
+// Any 8-byte node type with the SDK layout (sl_lidar_response_measurement_node_hq_t,
+// src/sdk/include/sl_lidar_cmd.h:272-278) can be passed; it is reinterpreted, never copied
+// field by field.
+template <class NodeT>
+inline const rplgpu_node_t *as_nodes(const NodeT *p) {
+  static_assert(sizeof(NodeT) == sizeof(rplgpu_node_t), "node must be the packed 8-byte SDK record");
+  return reinterpret_cast<const rplgpu_node_t *>(p);
+}
+template <class NodeT>
+inline rplgpu_node_t *as_nodes(NodeT *p) {
+  static_assert(sizeof(NodeT) == sizeof(rplgpu_node_t), "node must be the packed 8-byte SDK record");
+  return reinterpret_cast<rplgpu_node_t *>(p);
+}
+
+// The scalars publish_scan reads from the node (params_, driver_, cached range).
+struct ScanConfig {
+  bool is_new_protocol = false;     // RealLidarDriver && NEW_TYPE, src/rplidar_node.cpp:577-581
+  bool inverted = false;            // params_.inverted, :646,:676
+  bool scan_processing = true;      // params_.scan_processing, :632 (code default :280)
+  float cached_current_max_range = 12.0f;  // :626
+  // extensions (all off == the reference's behaviour)
+  bool clip_enable = false;
+  uint32_t q_min = 0;
+  float range_min = 0.15f;
+  bool ror_enable = false;
+  float ror_radius = 0.10f;
+  uint32_t ror_min_neighbors = 2;
+  bool voxel_enable = false;
+  float voxel_leaf = 0.05f;
+
+  rplgpu_params_t to_params() const {
+    rplgpu_params_t p;
+    rplgpu_default_params(&p);
+    p.is_new_protocol = is_new_protocol;
+    p.inverted = inverted;
+    p.scan_processing = scan_processing;
+    p.clip_enable = clip_enable;
+    p.q_min = q_min;
+    p.range_min = range_min;
+    p.range_max = cached_current_max_range;
+    p.ror_enable = ror_enable;
+    p.ror_radius = ror_radius;
+    p.ror_min_neighbors = ror_min_neighbors;
+    p.voxel_enable = voxel_enable;
+    p.voxel_leaf = voxel_leaf;
+    return p;
+  }
+};
+
+// One per node instance (created in on_configure, destroyed in on_cleanup): owns one
+// rplgpu handle, i.e. one HIP stream and its staging.  Not thread safe: the node calls it
+// from its single scan thread (src/rplidar_node.cpp:222).
+class ScanPath {
+ public:
+  ScanPath() = default;
+  ScanPath(const ScanPath &) = delete;
+  ScanPath &operator=(const ScanPath &) = delete;
+  ~ScanPath() { cleanup(); }
+
+  // on_configure (src/rplidar_node.cpp:116): bind to a device.  The SDK never hands out more
+  // than 8192 nodes per scan (src/lidar_driver_wrapper.cpp:316-318).
+  bool configure(int device_id = 0, uint32_t max_samples_per_scan = 8192) {
+    cleanup();
+    const int32_t rc = rplgpu_create(device_id, max_samples_per_scan, 1, &h_);
+    if (rc != RPLGPU_OK) {
+      last_error_ = std::string("rplgpu_create failed (") + std::to_string(rc) + "): " +
+                    rplgpu_last_error(nullptr);
+      h_ = nullptr;
+      return false;
+    }
+    max_n_ = max_samples_per_scan;
+    ranges_.resize(max_n_);
+    intens_.resize(max_n_);
+    xyzi_.resize(static_cast<size_t>(max_n_) * 4);
+    return true;
+  }
+  // on_cleanup (:244)
+  void cleanup() {
+    if (h_) rplgpu_destroy(h_);
+    h_ = nullptr;
+  }
+  bool ready() const { return h_ != nullptr; }
+  const std::string &last_error() const { return last_error_; }
+
+  // == sl::ILidarDriver::ascendScanData (src/sdk/include/sl_lidar_driver.h:477): in place,
+  // returns the SDK's sl_result (0 = SL_RESULT_OK, 0x80008001 = SL_RESULT_OPERATION_FAIL when
+  // every node is invalid, buffer untouched).  0x80008000 | other on a device error.
+  template <class NodeT>
+  uint32_t ascendScanData(NodeT *nodebuffer, size_t count) {
+    uint32_t sl_result = 0x80008001u;
+    if (!h_ || rplgpu_ascend(h_, as_nodes(nodebuffer), count, &sl_result) != RPLGPU_OK) {
+      note_error();
+      return 0x80008002u;  // SL_RESULT_OPERATION_TIMEOUT class: "did not happen"
+    }
+    return sl_result;
+  }
+
+  // == the body of RPlidarNode::publish_scan, src/rplidar_node.cpp:561-680.  Fills every
+  // field of `scan_msg` that the reference fills except header.stamp / header.frame_id
+  // (:620-621, the caller has them).  Returns false when the reference would have returned
+  // without publishing (:561-563, :611-613) or on a device error (see last_error()).
+  template <class NodeT, class LaserScanT>
+  bool fill_laser_scan(const std::vector<NodeT> &nodes, const ScanConfig &cfg,
+                       double scan_duration, LaserScanT &scan_msg) {
+    if (nodes.empty()) return false;  // :561-563
+    if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
+    const rplgpu_params_t p = cfg.to_params();
+    rplgpu_scan_meta_t meta;
+    if (rplgpu_scan_to_laserscan(h_, as_nodes(nodes.data()), nodes.size(), &p, scan_duration,
+                                 ranges_.data(), intens_.data(), &meta) != RPLGPU_OK)
+      return note_error();
+    if (!meta.published) return false;  // :611-613
+    scan_msg.angle_min = meta.angle_min;              // :623
+    scan_msg.angle_max = meta.angle_max;              // :624
+    scan_msg.range_min = meta.range_min;              // :625
+    scan_msg.range_max = meta.range_max;              // :626
+    scan_msg.scan_time = meta.scan_time;              // :627
+    scan_msg.angle_increment = meta.angle_increment;  // :635 / :666
+    scan_msg.time_increment = meta.time_increment;    // :637 / :668
+    scan_msg.ranges.assign(ranges_.begin(), ranges_.begin() + meta.count);
+    scan_msg.intensities.assign(intens_.begin(), intens_.begin() + meta.count);
+    return true;
+  }
+
+  // ext: fills a sensor_msgs/PointCloud2-shaped message (fields x, y, z, intensity FLOAT32 at
+  // offsets 0/4/8/12, point_step 16, height 1, is_dense, little endian).  `PointFieldT` is
+  // sensor_msgs::msg::PointField (datatype 7 == FLOAT32).
+  template <class NodeT, class PointCloud2T>
+  bool fill_point_cloud2(const std::vector<NodeT> &nodes, const ScanConfig &cfg,
+                         PointCloud2T &cloud_msg) {
+    if (nodes.empty()) return false;
+    if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
+    const rplgpu_params_t p = cfg.to_params();
+    uint32_t n_points = 0, status = 0;
+    const int32_t rc = rplgpu_scan_to_cloud(h_, as_nodes(nodes.data()), nodes.size(), &p,
+                                            xyzi_.data(), &n_points, &status);
+    if (rc != RPLGPU_OK) return note_error();
+    using FieldT = typename std::remove_reference<decltype(cloud_msg.fields)>::type::value_type;
+    cloud_msg.fields.clear();
+    static const char *const names[4] = {"x", "y", "z", "intensity"};
+    for (uint32_t f = 0; f < 4; ++f) {
+      FieldT pf;
+      pf.name = names[f];
+      pf.offset = 4 * f;
+      pf.datatype = 7;  // sensor_msgs/PointField FLOAT32
+      pf.count = 1;
+      cloud_msg.fields.push_back(pf);
+    }
+    cloud_msg.height = 1;
+    cloud_msg.width = n_points;
+    cloud_msg.point_step = 16;
+    cloud_msg.row_step = 16 * n_points;
+    cloud_msg.is_bigendian = false;
+    cloud_msg.is_dense = true;
+    cloud_msg.data.resize(static_cast<size_t>(n_points) * 16);
+    if (n_points) std::memcpy(cloud_msg.data.data(), xyzi_.data(), static_cast<size_t>(n_points) * 16);
+    return true;
+  }
+
+ private:
+  bool fail(const char *msg) {
+    last_error_ = msg;
+    return false;
+  }
+  bool note_error() {
+    last_error_ = h_ ? rplgpu_last_error(h_) : "rplgpu handle not configured";
+    return false;
+  }
+  rplgpu_handle_t h_ = nullptr;
+  uint32_t max_n_ = 0;
+  std::vector<float> ranges_, intens_, xyzi_;
+  std::string last_error_;
+};
+
+// == DummyLidarDriver::grab_scan_data's synthetic ring (src/lidar_driver_wrapper.cpp:441-471),
+// the reference's only fake backend (config 1): 360 nodes, one per degree, 2 m +- 0.5 m,
+// quality 200, phase advancing 0.1 rad per scan.  `phase` is the caller's copy of the
+// reference's function-static accumulator.
+template <class NodeT>
+inline void dummy_scan(float &phase, std::vector<NodeT> &nodes) {
+  static_assert(sizeof(NodeT) == 8, "node must be the packed 8-byte SDK record");
+  const int count = 360;
+  nodes.clear();
+  nodes.reserve(count);
+  phase += 0.1f;  // :450
+  for (int i = 0; i < count; ++i) {
+    rplgpu_node_t nd;
+    nd.angle_z_q14 = static_cast<uint16_t>(static_cast<float>(i) * 16384.0f / 90.0f);  // :456
+    const float dist_meters = 2.0f + 0.5f * std::sin(static_cast<float>(i) * 3.141592f / 180.0f + phase);
+    nd.dist_mm_q2 = static_cast<uint32_t>(dist_meters * 1000.0f * 4.0f);               // :463
+    nd.quality = 200;                                                                  // :464
+    nd.flag = 0;
+    NodeT out;
+    std::memcpy(&out, &nd, 8);
+    nodes.push_back(out);
+  }
+}
+
+}  // namespace rplgpu_host
