@@ -29,6 +29,22 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+TRAFFIC_JSON = ROOT / "profiles" / "traffic.json"  # PMC-derived HBM bytes per launch (tools/prof.sh)
+
+
+def measured_traffic(kernel: str, B: int, n: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/prof_summary.py from separate --pmc runs of this
+    very command, with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md), or None when
+    no profile of this workload shape is on record."""
+    try:
+        rec = json.loads(TRAFFIC_JSON.read_text())
+    except Exception:
+        return None, None
+    ent = rec.get(kernel)
+    if not ent or ent.get("scans") != B or ent.get("samples_per_scan") != n:
+        return None, None
+    return int(ent["hbm_bytes_per_launch"]), ent.get("source")
 
 
 def parse_args():
@@ -72,18 +88,39 @@ def cpu_baseline(batch_np, lens_np, params, target_s):
     t, _ = run(probe, cores)
     rate = probe * n / max(t, 1e-9)
     nscans = int(min(B, max(probe, rate * target_s / n)))
-    t_all, tot = run(nscans, cores)
-    t_one_scans = min(nscans, max(4, nscans // max(cores, 1)))
+    # the sample is bounded by the batch; repeat it so that the timing covers ~target_s of
+    # wall time at most and take the best pass (the box's cores are shared with nothing else)
+    passes, t_all, tot, spent = 0, float("inf"), 0, 0.0
+    while passes < 3 or (spent < min(target_s, 6.0) and passes < 12):
+        tp, tot = run(nscans, cores)
+        t_all = min(t_all, tp)
+        spent += tp
+        passes += 1
+    t_one_scans = min(nscans, 32)
     t_one, _ = run(t_one_scans, 1)
+    # the reference's own per-scan loop (ascendScanData + publish_scan Mode A), same threads
+    pl = oracle_lib.copy_params(params)
+    pl.clip_enable = 0
+    nodes = np.ascontiguousarray(batch_np[:nscans]).copy()
+    lens = np.ascontiguousarray(lens_np[:nscans].astype(np.uint32))
+    t0 = time.perf_counter()
+    orc.lib.orc_batch_ascend(nodes.ctypes.data, n, lens.ctypes.data, nscans, cores)
+    t_asc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    orc.lib.orc_batch_laserscan(nodes.ctypes.data, n, lens.ctypes.data, nscans, C.byref(pl), cores)
+    t_ls = time.perf_counter() - t0
     return {
         "value": round(nscans * n / t_all / 1e6, 3),
         "unit": "Mpoints/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"first {nscans} scans x {n} samples of the same batch, "
-                  f"{t_all:.2f} s wall, {cores} threads over scans (g++ -O2)",
+        "sample": f"first {nscans} scans x {n} samples of the same batch, best of {passes} "
+                  f"passes ({t_all:.2f} s wall each, {cores * t_all:.0f} core-seconds), "
+                  f"{cores} threads over scans (g++ -O2 oracle, clip + polar->XYZ + voxel)",
         "single_thread_value": round(t_one_scans * n / t_one / 1e6, 3),
         "cells_out": tot,
+        "reference_path_ascend_mpts": round(nscans * n / t_asc / 1e6, 1),
+        "reference_path_laserscan_mpts": round(nscans * n / t_ls / 1e6, 1),
     }
 
 
@@ -118,7 +155,8 @@ def main():
     batch_np = synth.make_batch(args.seed, B, n, first_scan=lo)
     gen_s = time.perf_counter() - t0
     lens_np = np.full(B, n, np.int32)
-    d_nodes = torch.from_numpy(batch_np.view(np.uint8).reshape(B, n * 8)).to(dev)
+    h_nodes = torch.from_numpy(batch_np.view(np.uint8).reshape(B, n * 8))
+    d_nodes = h_nodes.to(dev)
     d_len = torch.from_numpy(lens_np).to(dev)
     d_xyzi = torch.empty(B, out_stride, 4, dtype=torch.float32, device=dev)
     d_np = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -165,6 +203,24 @@ def main():
 
     status = int(d_st.max().item())
     cells_local = int(d_off[B].item())
+
+    # PCIe-inclusive rate (NOT `value`): the same batch handed over as a pinned host buffer
+    h2d_ms = None
+    if rank == 0 and world == 1:
+        try:
+            h_pin = h_nodes.pin_memory()
+            d_tmp = torch.empty_like(d_nodes)
+            d_tmp.copy_(h_pin, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            d_tmp.copy_(h_pin, non_blocking=True)
+            b_.record(stream)
+            torch.cuda.synchronize(dev)
+            h2d_ms = a.elapsed_time(b_)
+            del d_tmp, h_pin
+        except Exception:
+            h2d_ms = None
 
     # ---- dominant kernel alone: HIP events on the launch stream, per launch -------------
     reps = max(args.steps, 5)
@@ -221,6 +277,7 @@ def main():
         cpu = cpu_baseline(batch_np, lens_np, params, args.cpu_seconds)
 
     if rank == 0:
+        traffic, traffic_src = measured_traffic("k_cloud_voxel", B, n)
         ms_per_step = elapsed / args.steps * 1e3
         value = B_total * n / (elapsed / args.steps) / 1e6
         line = {
@@ -251,7 +308,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms_avg": round(k_ms_avg, 4),
                 "kernel_ms_min": round(k_ms[0], 4),
                 "algorithmic_bytes": algo_bytes,
@@ -260,6 +318,9 @@ def main():
             "status_bits": status,
             "cells_out_rank0": cells_local,
             "host_gen_s": round(gen_s, 2),
+            "h2d_ms_pinned": None if h2d_ms is None else round(h2d_ms, 3),
+            "value_incl_pcie_h2d": None if h2d_ms is None else round(
+                B_total * n / ((ms_per_step + h2d_ms) * 1e-3) / 1e6, 1),
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
