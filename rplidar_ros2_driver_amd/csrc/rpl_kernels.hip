@@ -24,12 +24,18 @@ __device__ __forceinline__ uint32_t sample_index(int j) {
   return ((uint32_t)(j * kWaves) + wave_id()) * 64u + lane_id();
 }
 
+// Bounds-checked buffer loads over the scan's n*8 bytes: a sample beyond the scan reads as
+// zero (dist 0 = invalid), every lane always issues the load (no exec branches, no saved
+// addresses).
+typedef uint32_t k_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void load_scan(const uint2 *__restrict__ scan, uint32_t n,
                                           uint2 (&v)[kIters]) {
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
-    uint32_t i = sample_index(j);
-    v[j] = (i < n) ? scan[i] : make_uint2(0u, 0u);
+    const k_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(sample_index(j) * 8u), 0, 0);
+    v[j] = make_uint2(t.x, t.y);
   }
 }
 
@@ -57,25 +63,26 @@ __device__ __forceinline__ uint32_t sample_rank(int j, const uint64_t *s_mask,
   return s_cbase[c] + (uint32_t)__popcll(s_mask[c] & lanemask_lt());
 }
 
-// Sort `count` composite keys (value<<16 | sample index) held in s_keys[0..count)
-// unless they are already ascending, then turn the array into the inverse map
-// s_keys[sample index] = sorted position.  Keys are unique, so the order is the
-// stable (value, input index) order.  `count` <= 32768.  Block-uniform control flow.
-__device__ __forceinline__ void sort_keys_to_positions(uint32_t *s_keys, uint32_t count,
-                                                       uint32_t *s_flag) {
+// True when the `count` composite keys (value<<16 | sample index) in s_keys[0..count) are
+// not ascending.  Block-uniform result; contains barriers.
+__device__ __forceinline__ bool keys_unsorted(const uint32_t *s_keys, uint32_t count,
+                                              uint32_t *s_flag) {
   if (threadIdx.x == 0) *s_flag = 0u;
   __syncthreads();
   uint32_t bad = 0;
   for (uint32_t t = threadIdx.x; t + 1 < count; t += kBlock) bad |= (s_keys[t] > s_keys[t + 1]);
   if (bad) atomicOr(s_flag, 1u);
   __syncthreads();
-  bool unsorted = *s_flag != 0u;
-  uint32_t N = count;
-  if (unsorted) {
-    N = next_pow2(count);
-    for (uint32_t t = count + threadIdx.x; t < N; t += kBlock) s_keys[t] = 0xFFFFFFFFu;
-    block_bitonic_sort(s_keys, N);  // starts and ends with a barrier
-  }
+  return *s_flag != 0u;
+}
+
+// Sort the keys (unique, so the order is the stable (value, input index) order), then turn
+// the array into the inverse map s_keys[sample index] = sorted position.  `count` <= 32768.
+// Only called for unsorted input: already ascending scans (the usual case) never get here.
+__device__ __forceinline__ void sort_keys_to_positions(uint32_t *s_keys, uint32_t count) {
+  const uint32_t N = next_pow2(count);
+  for (uint32_t t = count + threadIdx.x; t < N; t += kBlock) s_keys[t] = 0xFFFFFFFFu;
+  block_bitonic_sort(s_keys, N);  // starts and ends with a barrier
   // inverse map through registers (the array is read completely before it is rewritten)
   uint32_t mine[kIters];
 #pragma unroll
@@ -179,7 +186,13 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
 
   // std::sort by float angle (:181) == sort by q14 (getAngle is exact and monotone).
   // Equal angles: the reference order is whatever introsort leaves; ours is input order.
-  sort_keys_to_positions(s_keys, n, &s_misc[2]);
+  if (!keys_unsorted(s_keys, n, &s_misc[2])) {  // already ascending: only the filled angles move
+#pragma unroll
+    for (int j = 0; j < kIters; ++j)
+      if ((changed >> j) & 1u) scan[sample_index(j)] = v[j];
+    return;
+  }
+  sort_keys_to_positions(s_keys, n);
 
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
@@ -192,15 +205,14 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
 }
 
 // ------------------------------------------------------------------------------
-// k_laserscan — publish_scan body (one workgroup per scan)
+// k_laserscan_raw — publish_scan Mode B, scan_processing = false (one workgroup per scan);
+// Mode A lives in rpl_laserscan.hip
 // ------------------------------------------------------------------------------
-constexpr uint32_t kBinCap = 16384;  // u64 bins per round (128 KiB of LDS)
-
-__global__ __launch_bounds__(kBlock) void k_laserscan(
+__global__ __launch_bounds__(kBlock) void k_laserscan_raw(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
-    KParams p, Tables T, const float *__restrict__ inc_table, float *__restrict__ ranges,
-    float *__restrict__ intens, uint32_t *__restrict__ beam_count) {
-  __shared__ uint64_t s_big[kBinCap];  // Mode A: u64 bins; Mode B: 32768 u32 keys
+    KParams p, float *__restrict__ ranges, float *__restrict__ intens,
+    uint32_t *__restrict__ beam_count) {
+  __shared__ uint32_t s_keys[kMaxN];
   __shared__ uint64_t s_mask[kChunks];
   __shared__ uint32_t s_cbase[kChunks];
   __shared__ uint32_t s_tmp[32];
@@ -225,75 +237,24 @@ __global__ __launch_bounds__(kBlock) void k_laserscan(
   if (threadIdx.x == 0) beam_count[b] = count;
   if (count == 0) return;  // :611-613 nothing published
 
-  const float *lut = p.inverted ? T.angle_inv : T.angle;
-
-  if (p.scan_processing) {
-    // ---- Mode A (:632-662): min-reduce into beam_count angular bins.
-    // key = dist_m bits | q14 | input index: the u64 minimum is the first strict
-    // minimum in (angle, input order), i.e. the reference's winner.
-    const float inc = inc_table[count];  // (float)(2*pi / (double)count), host-evaluated
-    for (uint32_t lo = 0; lo < count; lo += kBinCap) {
-      const uint32_t hi = min(count, lo + kBinCap);
-      for (uint32_t t = threadIdx.x; t < hi - lo; t += kBlock) s_big[t] = ~0ull;
-      __syncthreads();
+  // ---- Mode B (:663-680): sorted order, reversed unless inverted.
 #pragma unroll
-      for (int j = 0; j < kIters; ++j) {
-        if ((kept >> j) & 1u) {
-          uint32_t q = nd_q14(v[j]);
-          float angle = lut[q];
-          int idx = (int)((angle - 0.0f) / inc);  // :653-654, fp32 IEEE divide
-          if (idx >= (int)lo && idx < (int)hi) {  // :656 guard (idx < beam_count)
-            uint64_t key = ((uint64_t)__float_as_uint(nd_dist_m(nd_dist(v[j]))) << 32) |
-                           (uint64_t)((q << 16) | sample_index(j));
-            atomicMin((unsigned long long *)&s_big[idx - (int)lo], (unsigned long long)key);
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < kIters; ++j) {
-        if ((kept >> j) & 1u) {
-          uint32_t q = nd_q14(v[j]);
-          float angle = lut[q];
-          int idx = (int)((angle - 0.0f) / inc);
-          if (idx >= (int)lo && idx < (int)hi) {
-            float dm = nd_dist_m(nd_dist(v[j]));
-            uint64_t key = ((uint64_t)__float_as_uint(dm) << 32) |
-                           (uint64_t)((q << 16) | sample_index(j));
-            if (s_big[idx - (int)lo] == key) {
-              out_r[idx] = dm;
-              out_i[idx] = nd_intensity(nd_quality(v[j]), p.is_new_protocol);
-            }
-          }
-        }
-      }
-      for (uint32_t t = threadIdx.x; t < hi - lo; t += kBlock) {
-        if (s_big[t] == ~0ull) {  // :640-641 defaults
-          out_r[lo + t] = __uint_as_float(0x7F800000u);
-          out_i[lo + t] = 0.0f;
-        }
-      }
-      __syncthreads();
+  for (int j = 0; j < kIters; ++j) {
+    if ((kept >> j) & 1u) {
+      s_keys[sample_rank(j, s_mask, s_cbase)] = (nd_q14(v[j]) << 16) | sample_index(j);
     }
-  } else {
-    // ---- Mode B (:663-680): sorted order, reversed unless inverted.
-    uint32_t *s_keys = reinterpret_cast<uint32_t *>(s_big);
+  }
+  __syncthreads();
+  const bool unsorted = keys_unsorted(s_keys, count, &s_tmp[20]);
+  if (unsorted) sort_keys_to_positions(s_keys, count);
 #pragma unroll
-    for (int j = 0; j < kIters; ++j) {
-      if ((kept >> j) & 1u) {
-        s_keys[sample_rank(j, s_mask, s_cbase)] = (nd_q14(v[j]) << 16) | sample_index(j);
-      }
-    }
-    __syncthreads();
-    sort_keys_to_positions(s_keys, count, &s_tmp[20]);
-#pragma unroll
-    for (int j = 0; j < kIters; ++j) {
-      if ((kept >> j) & 1u) {
-        uint32_t pos = s_keys[sample_index(j)];
-        uint32_t idx = p.inverted ? pos : (count - 1u - pos);  // :676
-        out_r[idx] = nd_dist_m(nd_dist(v[j]));
-        out_i[idx] = nd_intensity(nd_quality(v[j]), p.is_new_protocol);
-      }
+  for (int j = 0; j < kIters; ++j) {
+    if ((kept >> j) & 1u) {
+      // ascending input: the sorted position is the rank among the kept samples
+      uint32_t pos = unsorted ? s_keys[sample_index(j)] : sample_rank(j, s_mask, s_cbase);
+      uint32_t idx = p.inverted ? pos : (count - 1u - pos);  // :676
+      out_r[idx] = nd_dist_m(nd_dist(v[j]));
+      out_i[idx] = nd_intensity(nd_quality(v[j]), p.is_new_protocol);
     }
   }
 }
@@ -397,13 +358,12 @@ hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const ui
   return hipGetLastError();
 }
 
-hipError_t launch_laserscan(hipStream_t s, const void *nodes, uint32_t n_stride,
-                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
-                            const Tables &T, const float *inc_table, float *ranges, float *intens,
-                            uint32_t *beam_count) {
+hipError_t launch_laserscan_raw(hipStream_t s, const void *nodes, uint32_t n_stride,
+                                const uint32_t *n_per_scan, uint32_t B, const KParams &p,
+                                float *ranges, float *intens, uint32_t *beam_count) {
   if (B == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_laserscan, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
-                     n_per_scan, p, T, inc_table, ranges, intens, beam_count);
+  hipLaunchKernelGGL(k_laserscan_raw, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
+                     n_per_scan, p, ranges, intens, beam_count);
   return hipGetLastError();
 }
 

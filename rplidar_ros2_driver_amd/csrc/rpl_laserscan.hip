@@ -1,0 +1,194 @@
+// rpl_laserscan.hip — k_laserscan_a: the body of RPlidarNode::publish_scan in Mode A
+// (scan_processing = true), reference src/rplidar_node.cpp:568-662, one 1024-thread
+// workgroup per scan, one pass over HBM: 8 B read per sample, 8 B written per beam.
+//
+// What the reference does per scan                       what happens here
+//   LOOP 1 (:583-602) keep dist != 0, convert units      interval test on dist_mm_q2 while the scan
+//                                                        is loaded into registers (16 x dwordx4 per
+//                                                        lane = 32 samples), block count -> beam_count
+//   std::sort by angle_rad (:607-609)                    nothing: the winner of a bin is defined by a
+//                                                        key, not by the visiting order (below)
+//   index = (int)((angle - 0) / angle_increment) (:653)  angle from the host-built table (bit-exact by
+//                                                        construction), divide = IEEE fp32 divide, or
+//                                                        mul + 2 FMA when k_validate_idx proved it
+//                                                        identical for EVERY (beam count, angle word)
+//   if dist < ranges[index] take (strict <) (:657-660)   LDS ds_min_u64 on
+//                                                          dist_m bits | angle word | intensity byte
+//                                                        = first strict minimum in angle order; among
+//                                                        samples with identical (dist_m, angle) the
+//                                                        reference's winner is introsort's (unstable):
+//                                                        ours is the smallest intensity, whatever the
+//                                                        input order (deterministic, order-free)
+//   ranges.assign(+inf), intensities.assign(0) (:640)    bins never hit flush as (+inf, 0)
+//
+// The input need not be sorted.  A window of 16 384 bins (128 KiB of LDS) is flushed with
+// coalesced stores; scans with more beams take a second window over the cached bin indices
+// (two u16 per VGPR), so no sample is converted twice.
+#include "rpl_device.hpp"
+#include "rpl_launch.hpp"
+
+namespace rpl {
+
+constexpr uint32_t kLsWin = 16384;  // u64 bins per window
+constexpr int kLsPairs = 16;        // dwordx4 (two samples) per lane: 16 * 1024 * 2 = 32768
+
+typedef uint32_t ls_u32x4 __attribute__((ext_vector_type(4)));
+
+// a / d as mul + exact FMA remainder + FMA correction with rd = RN(1/d) (Markstein); only
+// used after k_validate_idx has compared it with the IEEE divide on this device for every
+// operand pair that can occur.
+__device__ __forceinline__ float ls_div(float a, float d, float rd) {
+  float q = a * rd;
+  float e = fmaf(-q, d, a);
+  return fmaf(e, rd, q);
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void k_laserscan_a(
+    const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
+    KParams p, Tables T, const float *__restrict__ inc_table, const float *__restrict__ rinc_table,
+    float *__restrict__ ranges, float *__restrict__ intens, uint32_t *__restrict__ beam_count) {
+  __shared__ unsigned long long s_bins[kLsWin];
+  __shared__ uint32_t s_cnt;
+
+  const uint32_t b = blockIdx.x;
+  const uint32_t n = min(n_per_scan[b], kMaxN);
+  const uint2 *scan = nodes + (size_t)b * n_stride;
+  float *out_r = ranges + (size_t)b * n_stride;
+  float *out_i = intens + (size_t)b * n_stride;
+
+  if (threadIdx.x == 0) s_cnt = 0u;
+
+  // Bounds-checked buffer resource over the scan's n*8 bytes: what lies beyond reads as
+  // zero = dist 0 = dropped by the keep test (d_lo >= 1).
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
+  uint4 w[kLsPairs];
+#pragma unroll
+  for (int j = 0; j < kLsPairs; ++j) {
+    const ls_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(
+        rsrc, (int)(((uint32_t)j * kBlock + threadIdx.x) * 16u), 0, 0);
+    w[j] = make_uint4(t.x, t.y, t.z, t.w);
+  }
+  const uint32_t q_min16 = p.clip_enable ? (min(p.q_min, 256u) << 16) : 0u;
+  auto keep = [&](uint32_t lo, uint32_t hi) -> bool {  // :584 (+ the optional E1 clip)
+    const uint32_t d = __builtin_amdgcn_alignbit(hi, lo, 16);
+    return ((d - p.d_lo) <= p.d_span) && ((hi & 0x00FF0000u) >= q_min16);
+  };
+
+  // LOOP 1: beam_count = number of kept samples (:634)
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < kLsPairs; ++j) {
+    c += keep(w[j].x, w[j].y) ? 1u : 0u;
+    c += keep(w[j].z, w[j].w) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
+  __syncthreads();  // s_cnt = 0 visible
+  if (lane_id() == 0 && c) atomicAdd(&s_cnt, c);
+  __syncthreads();
+  const uint32_t count = s_cnt;
+  if (threadIdx.x == 0) beam_count[b] = count;
+  if (count == 0) return;  // :611-613 nothing published
+
+  const float *lut = p.inverted ? T.angle_inv : T.angle;  // :588-599, :646-651
+  const float inc = inc_table[count];                     // (float)(2*pi / (double)count), :635
+  const float rinc = rinc_table[count];
+
+  const uint32_t ishift = p.is_new_protocol ? 16u : 18u;  // :591-592 quality or quality >> 2
+  const uint32_t imask = p.is_new_protocol ? 0xFFu : 0x3Fu;
+
+  // Every sample becomes its 64-bit bin key IN PLACE (w[j] = {lowA, hiA, lowB, hiB}):
+  //   hi = dist_m bits (:590), low = angle word << 16 | intensity byte << 8,
+  // plus its bin index, two u16 per register (0xFFFF = not kept / guard :656).
+  uint32_t idxp[kLsPairs];
+#pragma unroll
+  for (int j = 0; j < kLsPairs; ++j) {
+    const uint4 ww = w[j];
+    const float aA = lut[ww.x & 0xFFFFu], aB = lut[ww.z & 0xFFFFu];
+    const float tA = FAST ? ls_div(aA, inc, rinc) : aA / inc;  // :653-654 (angle - 0.0f == angle)
+    const float tB = FAST ? ls_div(aB, inc, rinc) : aB / inc;
+    uint32_t iA = (uint32_t)(int)tA, iB = (uint32_t)(int)tB;
+    if (!(keep(ww.x, ww.y) && iA < count)) iA = 0xFFFFu;
+    if (!(keep(ww.z, ww.w) && iB < count)) iB = 0xFFFFu;
+    idxp[j] = iA | (iB << 16);
+    const float dfA = __uint2float_rn(__builtin_amdgcn_alignbit(ww.y, ww.x, 16));
+    const float dfB = __uint2float_rn(__builtin_amdgcn_alignbit(ww.w, ww.z, 16));
+    const float dmA = FAST ? ls_div(dfA, 4000.0f, 0.00025f) : dfA / 4000.0f;  // :590
+    const float dmB = FAST ? ls_div(dfB, 4000.0f, 0.00025f) : dfB / 4000.0f;
+    w[j] = make_uint4((ww.x << 16) | (((ww.y >> ishift) & imask) << 8), __float_as_uint(dmA),
+                      (ww.z << 16) | (((ww.w >> ishift) & imask) << 8), __float_as_uint(dmB));
+    if (j & 1) __builtin_amdgcn_sched_barrier(0);  // keep the conversion in place, 4 table loads in flight
+  }
+  auto key64 = [](uint32_t low, uint32_t hi) -> unsigned long long {
+    return ((unsigned long long)hi << 32) | (unsigned long long)low;
+  };
+
+  for (uint32_t lo = 0; lo < count; lo += kLsWin) {
+    const uint32_t nb = min(kLsWin, count - lo);
+    for (uint32_t t = threadIdx.x; t < nb; t += kBlock) s_bins[t] = ~0ull;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kLsPairs; ++j) {
+      const uint32_t rA = (idxp[j] & 0xFFFFu) - lo, rB = (idxp[j] >> 16) - lo;
+      if (rA < kLsWin) atomicMin(&s_bins[rA], key64(w[j].x, w[j].y));
+      if (rB < kLsWin) atomicMin(&s_bins[rB], key64(w[j].z, w[j].w));
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < nb; t += kBlock) {
+      const unsigned long long k = s_bins[t];
+      const uint32_t hi = (uint32_t)(k >> 32), low = (uint32_t)k;
+      const bool empty = hi == 0xFFFFFFFFu;  // no dist_m has this bit pattern (:640-641)
+      out_r[lo + t] = __uint_as_float(empty ? 0x7F800000u : hi);
+      out_i[lo + t] = empty ? 0.0f : (float)((low >> 8) & 0xFFu);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------
+// k_validate_idx: for every beam count c <= max_count and every angle word (both tables),
+// the bin index from the mul+2*FMA divide must equal the one from the IEEE divide.
+// One block per beam count.
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_validate_idx(const float *__restrict__ angle,
+                                                      const float *__restrict__ angle_inv,
+                                                      const float *__restrict__ inc_table,
+                                                      const float *__restrict__ rinc_table,
+                                                      uint32_t *mismatches) {
+  const uint32_t c = blockIdx.x + 1u;
+  const float inc = inc_table[c], rinc = rinc_table[c];
+  uint32_t bad = 0;
+  for (uint32_t q = threadIdx.x; q < 65536u; q += 256u) {
+    const float a0 = angle[q], a1 = angle_inv[q];
+    bad += ((int)ls_div(a0, inc, rinc) != (int)(a0 / inc));
+    bad += ((int)ls_div(a1, inc, rinc) != (int)(a1 / inc));
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+hipError_t launch_validate_idx(hipStream_t s, const Tables &T, const float *inc_table,
+                               const float *rinc_table, uint32_t max_count,
+                               uint32_t *d_mismatches) {
+  if (max_count == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_validate_idx, dim3(max_count), dim3(256), 0, s, T.angle, T.angle_inv,
+                     inc_table, rinc_table, d_mismatches);
+  return hipGetLastError();
+}
+
+hipError_t launch_laserscan_a(hipStream_t s, const void *nodes, uint32_t n_stride,
+                              const uint32_t *n_per_scan, uint32_t B, const KParams &p,
+                              const Tables &T, const float *inc_table, const float *rinc_table,
+                              bool fast, float *ranges, float *intens, uint32_t *beam_count) {
+  if (B == 0) return hipSuccess;
+  if (fast)
+    hipLaunchKernelGGL(k_laserscan_a<true>, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes,
+                       n_stride, n_per_scan, p, T, inc_table, rinc_table, ranges, intens, beam_count);
+  else
+    hipLaunchKernelGGL(k_laserscan_a<false>, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes,
+                       n_stride, n_per_scan, p, T, inc_table, rinc_table, ranges, intens, beam_count);
+  return hipGetLastError();
+}
+
+}  // namespace rpl

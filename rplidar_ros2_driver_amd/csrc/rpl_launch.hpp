@@ -10,10 +10,18 @@ namespace rpl {
 
 hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
                          uint32_t B, uint32_t *status);
-hipError_t launch_laserscan(hipStream_t s, const void *nodes, uint32_t n_stride,
-                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
-                            const Tables &T, const float *inc_table, float *ranges, float *intens,
-                            uint32_t *beam_count);
+// publish_scan Mode A (rpl_laserscan.hip); `fast`: the mul+2*FMA divides were validated
+hipError_t launch_laserscan_a(hipStream_t s, const void *nodes, uint32_t n_stride,
+                              const uint32_t *n_per_scan, uint32_t B, const KParams &p,
+                              const Tables &T, const float *inc_table, const float *rinc_table,
+                              bool fast, float *ranges, float *intens, uint32_t *beam_count);
+hipError_t launch_validate_idx(hipStream_t s, const Tables &T, const float *inc_table,
+                               const float *rinc_table, uint32_t max_count,
+                               uint32_t *d_mismatches);
+// publish_scan Mode B (rpl_kernels.hip)
+hipError_t launch_laserscan_raw(hipStream_t s, const void *nodes, uint32_t n_stride,
+                                const uint32_t *n_per_scan, uint32_t B, const KParams &p,
+                                float *ranges, float *intens, uint32_t *beam_count);
 // `keepmask` (optional): one bit per sample from launch_ror_mask, `mask_stride` words per scan.
 hipError_t launch_cloud(hipStream_t s, const void *nodes, uint32_t n_stride,
                         const uint32_t *n_per_scan, uint32_t B, const KParams &p, const Tables &T,

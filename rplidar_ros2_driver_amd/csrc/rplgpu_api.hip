@@ -23,7 +23,7 @@ struct rplgpu_ctx {
   hipStream_t stream = nullptr;
   uint32_t max_n = 0, max_b = 0;
   // tables
-  float *d_angle = nullptr, *d_angle_inv = nullptr, *d_inc = nullptr;
+  float *d_angle = nullptr, *d_angle_inv = nullptr, *d_inc = nullptr, *d_rinc = nullptr;
   float2 *d_cs = nullptr, *d_cs_inv = nullptr;
   double *d_rcp = nullptr;
   // single-scan staging
@@ -35,6 +35,7 @@ struct rplgpu_ctx {
   bool div4000_ok = false;
   float leaf_checked = 0.0f;
   bool leaf_ok = false;
+  bool idx_checked = false, idx_ok = false;  // Mode A bin-index divide, see k_validate_idx
   unsigned long long *dbg = nullptr;  // developer aid: per-block phase cycle counters
   std::string err;
 };
@@ -138,7 +139,8 @@ rpl::Tables tables_of(const rplgpu_ctx *c) {
 // with the same operand types (float / double) and the same order of operations:
 // src/rplidar_node.cpp:588-599 (conversion + wrap) and :646-651 (invert rule).
 void build_tables(std::vector<float> &angle, std::vector<float> &angle_inv,
-                  std::vector<float2> &cs, std::vector<float2> &cs_inv, std::vector<float> &inc) {
+                  std::vector<float2> &cs, std::vector<float2> &cs_inv, std::vector<float> &inc,
+                  std::vector<float> &rinc) {
   angle.resize(65536);
   angle_inv.resize(65536);
   cs.resize(65536);
@@ -161,6 +163,10 @@ void build_tables(std::vector<float> &angle, std::vector<float> &angle_inv,
   inc[0] = 0.0f;
   for (uint32_t c = 1; c <= rpl::kMaxN; ++c)
     inc[c] = static_cast<float>((2.0 * M_PI) / static_cast<double>(c));
+  // RN(1 / angle_increment) (IEEE fp32 divide) for the validated mul+2*FMA bin-index divide
+  rinc.resize(rpl::kMaxN + 1);
+  rinc[0] = 0.0f;
+  for (uint32_t c = 1; c <= rpl::kMaxN; ++c) rinc[c] = 1.0f / inc[c];
 }
 
 template <class T>
@@ -176,6 +182,7 @@ void free_ctx(rplgpu_ctx *c) {
   if (c->d_angle) (void)hipFree(c->d_angle);
   if (c->d_angle_inv) (void)hipFree(c->d_angle_inv);
   if (c->d_inc) (void)hipFree(c->d_inc);
+  if (c->d_rinc) (void)hipFree(c->d_rinc);
   if (c->d_cs) (void)hipFree(c->d_cs);
   if (c->d_cs_inv) (void)hipFree(c->d_cs_inv);
   if (c->d_rcp) (void)hipFree(c->d_rcp);
@@ -212,6 +219,34 @@ int32_t validate_divisor(rplgpu_ctx *c, float d, uint32_t e_lo, uint32_t e_hi, b
   RPL_HIP(c, hipMemcpyAsync(&bad, c->d_small + 8, 4, hipMemcpyDeviceToHost, c->stream));
   RPL_HIP(c, hipStreamSynchronize(c->stream));
   *ok = (bad == 0);
+  return RPLGPU_OK;
+}
+
+// publish_scan on the handle's stream: Mode A (rpl_laserscan.hip) or Mode B.  The cheap
+// bin-index divide of Mode A is used only after it was compared with the IEEE divide for
+// every (beam count <= max_n, angle word, inverted or not) on this device, once per handle.
+int32_t run_laserscan(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride,
+                      const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t &p,
+                      float *d_ranges, float *d_intens, uint32_t *d_beam_count) {
+  const rpl::KParams kp = to_kparams(p);
+  if (!p.scan_processing) {
+    RPL_HIP(c, rpl::launch_laserscan_raw(c->stream, d_nodes, n_stride, d_n_per_scan, B, kp, d_ranges,
+                                         d_intens, d_beam_count));
+    return RPLGPU_OK;
+  }
+  if (!c->idx_checked) {
+    uint32_t zero = 0, bad = 1;
+    RPL_HIP(c, hipMemcpyAsync(c->d_small + 8, &zero, 4, hipMemcpyHostToDevice, c->stream));
+    RPL_HIP(c, rpl::launch_validate_idx(c->stream, tables_of(c), c->d_inc, c->d_rinc, c->max_n,
+                                        c->d_small + 8));
+    RPL_HIP(c, hipMemcpyAsync(&bad, c->d_small + 8, 4, hipMemcpyDeviceToHost, c->stream));
+    RPL_HIP(c, hipStreamSynchronize(c->stream));
+    c->idx_ok = (bad == 0);
+    c->idx_checked = true;
+  }
+  RPL_HIP(c, rpl::launch_laserscan_a(c->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(c),
+                                     c->d_inc, c->d_rinc, c->idx_ok && c->div4000_ok, d_ranges,
+                                     d_intens, d_beam_count));
   return RPLGPU_OK;
 }
 
@@ -284,9 +319,9 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
     return fail(RPLGPU_ERR_HIP);
   c->stream = c->own_stream;
 
-  std::vector<float> angle, angle_inv, inc;
+  std::vector<float> angle, angle_inv, inc, rinc;
   std::vector<float2> cs, cs_inv;
-  build_tables(angle, angle_inv, cs, cs_inv, inc);
+  build_tables(angle, angle_inv, cs, cs_inv, inc, rinc);
   // Sorting by q14 stands in for sorting by angle_rad (:607-609): require monotonicity.
   for (int q = 1; q < 65536; ++q) {
     if (!(angle[q] > angle[q - 1])) {
@@ -301,7 +336,7 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   int32_t rc;
   if ((rc = upload(c, &c->d_rcp, rcp)) || (rc = upload(c, &c->d_angle, angle)) || (rc = upload(c, &c->d_angle_inv, angle_inv)) ||
       (rc = upload(c, &c->d_cs, cs)) || (rc = upload(c, &c->d_cs_inv, cs_inv)) ||
-      (rc = upload(c, &c->d_inc, inc)))
+      (rc = upload(c, &c->d_inc, inc)) || (rc = upload(c, &c->d_rinc, rinc)))
     return fail(rc);
 
   const size_t n = c->max_n;
@@ -347,7 +382,7 @@ int32_t rplgpu_debug_set_cycle_buffer(rplgpu_handle_t h, void *d_buf) {
 }
 int32_t rplgpu_debug_fast_div(rplgpu_handle_t h) {
   if (!h) return RPLGPU_ERR_INVALID_ARG;
-  return (h->div4000_ok ? 1 : 0) | (h->leaf_ok ? 2 : 0);
+  return (h->div4000_ok ? 1 : 0) | (h->leaf_ok ? 2 : 0) | (h->idx_ok ? 4 : 0);
 }
 
 int32_t rplgpu_synchronize(rplgpu_handle_t h) {
@@ -376,9 +411,8 @@ int32_t rplgpu_laserscan_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nod
   if (rc) return rc;
   if (!p || !d_ranges || !d_intensities || !d_beam_count) return RPLGPU_ERR_INVALID_ARG;
   RPL_HIP(h, hipSetDevice(h->device));
-  RPL_HIP(h, rpl::launch_laserscan(h->stream, d_nodes, n_stride, d_n_per_scan, B, to_kparams(*p),
-                                   tables_of(h), h->d_inc, d_ranges, d_intensities, d_beam_count));
-  return RPLGPU_OK;
+  return run_laserscan(h, d_nodes, n_stride, d_n_per_scan, B, *p, d_ranges, d_intensities,
+                       d_beam_count);
 }
 
 int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
@@ -473,8 +507,9 @@ int32_t rplgpu_scan_to_laserscan(rplgpu_handle_t h, const rplgpu_node_t *nodes, 
   float *d_i = d_r + n;
   RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
   RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
-  RPL_HIP(h, rpl::launch_laserscan(h->stream, h->d_nodes, (uint32_t)n, h->d_small, 1, to_kparams(*p),
-                                   tables_of(h), h->d_inc, d_r, d_i, h->d_small + 1));
+  if (int32_t lrc = run_laserscan(h, h->d_nodes, (uint32_t)n, h->d_small, 1, *p, d_r, d_i,
+                                  h->d_small + 1))
+    return lrc;
   RPL_HIP(h, hipMemcpyAsync(h_out, h->d_out, n * 8, hipMemcpyDeviceToHost, h->stream));
   RPL_HIP(h, hipMemcpyAsync(h_small + 1, h->d_small + 1, 4, hipMemcpyDeviceToHost, h->stream));
   RPL_HIP(h, hipStreamSynchronize(h->stream));
