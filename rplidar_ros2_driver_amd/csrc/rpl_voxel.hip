@@ -243,20 +243,32 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
 #pragma unroll
   for (int k = 0; k < (int)kRecPerThread; ++k) {
     const uint32_t idx = threadIdx.x + (uint32_t)k * kBlock;
-    const bool ok = idx < nrec;
-    const uint4 raw = L.rec[ok ? idx : 0u];
-    const uint4 pr = L.rec[(ok && idx > 0u) ? idx - 1u : 0u];
-    const bool same = ok && idx > 0u && (((raw.w ^ pr.w) >> 24) == 0u);
-    uint4 m = raw;
-    m.y -= same ? pr.y : 0u;
-    m.z -= same ? pr.z : 0u;
-    m.w = (raw.w & 0x00FFFFFFu) - (same ? (pr.w & 0x00FFFFFFu) : 0u);
-    if (!ok) m = make_uint4(kEmptyKey, 0u, 0u, 0u);
-    mine[k] = m;
-    if (ok) {
-      rmin = min(rmin, m.x >> 16);
-      rmax = max(rmax, m.x >> 16);
+    uint4 m = make_uint4(kEmptyKey, 0u, 0u, 0u);
+    // whole 64-record slices beyond the queue tail are skipped (wave-uniform: the mean queue
+    // holds 3.1 k of 7168 records); the previous record comes from the lane to the left
+    if ((idx & ~63u) < nrec) {
+      const bool ok = idx < nrec;
+      const uint4 raw = L.rec[idx];  // idx < kRecCap always
+      uint4 pr;
+      pr.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw.y, 0x138, 0xF, 0xF, false);
+      pr.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw.z, 0x138, 0xF, 0xF, false);
+      pr.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw.w, 0x138, 0xF, 0xF, false);
+      if (lane_id() == 0u && idx > 0u) {
+        const uint4 t = L.rec[idx - 1u];
+        pr.y = t.y; pr.z = t.z; pr.w = t.w;
+      }
+      const bool same = ok && idx > 0u && (((raw.w ^ pr.w) >> 24) == 0u);
+      m = raw;
+      m.y -= same ? pr.y : 0u;
+      m.z -= same ? pr.z : 0u;
+      m.w = (raw.w & 0x00FFFFFFu) - (same ? (pr.w & 0x00FFFFFFu) : 0u);
+      if (!ok) m = make_uint4(kEmptyKey, 0u, 0u, 0u);
+      if (ok) {
+        rmin = min(rmin, m.x >> 16);
+        rmax = max(rmax, m.x >> 16);
+      }
     }
+    mine[k] = m;
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
@@ -357,21 +369,33 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
     const uint32_t nemit = min(ncell, out_stride > out_base ? out_stride - out_base : 0u);
     for (uint32_t c = threadIdx.x; c < nemit; c += kBlock) {
       uint32_t r = L.bucket[c];
-      uint4 q = L.rec[r];
-      const uint32_t key = q.x;
-      double sx = 0.0, sy = 0.0;
-      uint32_t cw = 0;
-      do {  // segmented sum over the records of this cell
-        sx += (double)q.y;
-        sy += (double)q.z;
-        cw += q.w;
-        if (++r >= nrec) break;
-        q = L.rec[r];
-      } while (q.x == key);
+      // a cell is 1.13 records on average: fetch the head and the two records behind it in one
+      // round trip, continue serially only when all three belong to the cell
+      const uint4 q0 = L.rec[r];
+      const uint4 q1 = L.rec[min(r + 1u, kRecCap - 1u)];
+      const uint4 q2 = L.rec[min(r + 2u, kRecCap - 1u)];
+      const uint32_t key = q0.x;
+      const bool m1 = (r + 1u < nrec) && (q1.x == key);
+      const bool m2 = m1 && (r + 2u < nrec) && (q2.x == key);
+      double sx = (double)q0.y, sy = (double)q0.z;
+      uint32_t cw = q0.w;
+      if (m1) { sx += (double)q1.y; sy += (double)q1.z; cw += q1.w; }
+      if (m2) {
+        sx += (double)q2.y; sy += (double)q2.z; cw += q2.w;
+        for (r += 3u; r < nrec; ++r) {  // segmented sum over the rest of this cell's records
+          const uint4 q = L.rec[r];
+          if (q.x != key) break;
+          sx += (double)q.y;
+          sy += (double)q.z;
+          cw += q.w;
+        }
+      }
       const uint32_t cnt = cw >> 16, isum = cw & 0xFFFFu;
       const double ix = (double)((int)(key & 0xFFFFu) - 32768);
       const double iy = (double)((int)(key >> 16) - 32768);
-      const double dc = (double)cnt, rc = rcp[cnt];
+      // RN(1/count): the IEEE fp64 divide is correctly rounded, i.e. exactly the entry of the
+      // host-built reciprocal table; a dependent table gather (L2 latency) per cell costs more
+      const double dc = (double)cnt, rc = 1.0 / dc;
       const double Sx = fma(dc, ix * dL - dbias, sx);  // coordinate sums in units of 2^-K m
       const double Sy = fma(dc, iy * dL - dbias, sy);
       const double si = (double)isum;
@@ -434,7 +458,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
   const __amdgpu_buffer_rsrc_t scan_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
   auto load_pair = [&](uint32_t i) -> uint4 {
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)(i * 16u), 0, 0);
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)(i * 16u), 0, 2);
     return make_uint4(t.x, t.y, t.z, t.w);
   };
 
