@@ -118,6 +118,42 @@ uint64_t orc_batch_cloud(const orc_node_t *nodes, size_t n_stride,
                          const uint32_t *n_per_scan, size_t B,
                          const orc_params_t *p, int threads);
 
+
+/* =====================================================================================
+ * SURVEY.md §8(f) rows 1-2 — the step before the hot path: sample-data unpackers
+ * (src/sdk/src/dataunpacker/unpacker/handler_*.cpp) and scan assembly
+ * (ScanDataHolder, src/sdk/src/sl_lidar_driver.cpp:236-360).  Restated in
+ * oracle_unpack.cpp; PINNED against the reference's own code (oracle/_ref/libunpackref.so).
+ * ===================================================================================== */
+/* answer types: src/sdk/include/sl_lidar_cmd.h:144-151 */
+#define ORC_ANS_MEASUREMENT 0x81
+#define ORC_ANS_CAPSULED 0x82
+#define ORC_ANS_HQ 0x83
+#define ORC_ANS_CAPSULED_ULTRA 0x84
+#define ORC_ANS_DENSE_CAPSULED 0x85
+#define ORC_ANS_ULTRA_DENSE_CAPSULED 0x86
+
+typedef struct orc_unpack_state {
+  int32_t last_sync_bit; /* dense: static lastNodeSyncBit; ultra-dense: _last_node_sync_bit */
+  int32_t last_dist_q2;  /* ultra-dense: _last_dist_q2 */
+} orc_unpack_state_t;
+
+size_t orc_frame_size(uint8_t ans_type);
+size_t orc_frame_stream(uint8_t ans_type, const uint8_t *bytes, size_t nbytes,
+                        uint32_t *frame_off, uint8_t *gap, size_t cap);
+size_t orc_unpack_frames(uint8_t ans_type, const uint8_t *bytes, const uint32_t *frame_off,
+                         const uint8_t *gap, size_t nframes, uint32_t sample_duration_us,
+                         orc_unpack_state_t *st, orc_node_t *out, size_t cap,
+                         uint32_t *reset_at, size_t reset_cap, size_t *n_reset,
+                         uint32_t *n_checksum_err);
+size_t orc_unpack(uint8_t ans_type, const uint8_t *bytes, size_t nbytes,
+                  uint32_t sample_duration_us, orc_unpack_state_t *st, orc_node_t *out,
+                  size_t cap, uint32_t *reset_at, size_t reset_cap, size_t *n_reset,
+                  uint32_t *n_checksum_err);
+size_t orc_segment(const orc_node_t *nodes, size_t n, const uint32_t *reset_at, size_t n_reset,
+                   size_t max_count, orc_node_t *out, size_t out_cap, uint32_t *scan_off,
+                   size_t scan_cap);
+
 #ifdef __cplusplus
 }
 #endif

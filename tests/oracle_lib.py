@@ -79,6 +79,78 @@ class Oracle:
         res = self.lib.orc_ascend(out.ctypes.data, len(out))
         return out, res
 
+    # ---- unpackers + scan assembly (oracle_unpack.cpp) ------------------
+    def _bind_unpack(self):
+        lib, vp, sz = self.lib, C.c_void_p, C.c_size_t
+        if getattr(lib, "_unpack_bound", False):
+            return
+        lib.orc_frame_size.argtypes = [C.c_uint8]
+        lib.orc_frame_size.restype = sz
+        lib.orc_frame_stream.argtypes = [C.c_uint8, vp, sz, vp, vp, sz]
+        lib.orc_frame_stream.restype = sz
+        lib.orc_unpack_frames.argtypes = [C.c_uint8, vp, vp, vp, sz, C.c_uint32, vp, vp, sz, vp,
+                                          sz, C.POINTER(sz), C.POINTER(C.c_uint32)]
+        lib.orc_unpack_frames.restype = sz
+        lib.orc_unpack.argtypes = [C.c_uint8, vp, sz, C.c_uint32, vp, vp, sz, vp, sz,
+                                   C.POINTER(sz), C.POINTER(C.c_uint32)]
+        lib.orc_unpack.restype = sz
+        lib.orc_segment.argtypes = [vp, sz, vp, sz, sz, vp, sz, vp, sz]
+        lib.orc_segment.restype = sz
+        lib._unpack_bound = True
+
+    def frame_stream(self, ans: int, data: np.ndarray):
+        self._bind_unpack()
+        data = np.ascontiguousarray(data, np.uint8)
+        S = self.lib.orc_frame_size(ans)
+        cap = len(data) // S + 1
+        off = np.zeros(cap, np.uint32)
+        gap = np.zeros(cap, np.uint8)
+        nf = self.lib.orc_frame_stream(ans, data.ctypes.data, len(data), off.ctypes.data,
+                                       gap.ctypes.data, cap)
+        return off[:nf], gap[:nf]
+
+    def unpack_frames(self, ans: int, data, off, gap, sample_duration_us: int = 125,
+                      state=(0, 0)):
+        self._bind_unpack()
+        data = np.ascontiguousarray(data, np.uint8)
+        off = np.ascontiguousarray(off, np.uint32)
+        gap = np.ascontiguousarray(gap, np.uint8)
+        cap = len(off) * 96 + 1
+        out = np.zeros(cap, NODE)
+        rst = np.zeros(len(off) + 1, np.uint32)
+        st = np.array(state, np.int32)
+        nr, ne = C.c_size_t(0), C.c_uint32(0)
+        n = self.lib.orc_unpack_frames(ans, data.ctypes.data, off.ctypes.data, gap.ctypes.data,
+                                       len(off), sample_duration_us, st.ctypes.data,
+                                       out.ctypes.data, cap, rst.ctypes.data, len(rst),
+                                       C.byref(nr), C.byref(ne))
+        return out[:n], rst[: nr.value], int(ne.value), (int(st[0]), int(st[1]))
+
+    def unpack(self, ans: int, data, sample_duration_us: int = 125, state=(0, 0)):
+        self._bind_unpack()
+        data = np.ascontiguousarray(data, np.uint8)
+        S = self.lib.orc_frame_size(ans)
+        cap = (len(data) // S + 1) * 96 + 1
+        out = np.zeros(cap, NODE)
+        rst = np.zeros(len(data) // S + 2, np.uint32)
+        st = np.array(state, np.int32)
+        nr, ne = C.c_size_t(0), C.c_uint32(0)
+        n = self.lib.orc_unpack(ans, data.ctypes.data, len(data), sample_duration_us,
+                                st.ctypes.data, out.ctypes.data, cap, rst.ctypes.data, len(rst),
+                                C.byref(nr), C.byref(ne))
+        return out[:n], rst[: nr.value], int(ne.value), (int(st[0]), int(st[1]))
+
+    def segment(self, nodes, reset_at, max_count: int = 8192):
+        self._bind_unpack()
+        nodes = np.ascontiguousarray(nodes)
+        reset_at = np.ascontiguousarray(reset_at, np.uint32)
+        out = np.zeros(max(len(nodes), 1), NODE)
+        offs = np.zeros(len(nodes) + 2, np.uint32)
+        ns = self.lib.orc_segment(nodes.ctypes.data, len(nodes), reset_at.ctypes.data,
+                                  len(reset_at), max_count, out.ctypes.data, len(out),
+                                  offs.ctypes.data, len(offs))
+        return out[: offs[ns]], offs[: ns + 1]
+
     def publish_scan(self, nodes: np.ndarray, p: OParams, scan_duration: float = 0.1):
         nodes = np.ascontiguousarray(nodes)
         n = len(nodes)
@@ -134,7 +206,8 @@ def build_oracle():
 def load_oracle() -> Oracle:
     so = ORACLE_DIR / "liboracle.so"
     src_newer = (not so.exists()) or any(
-        (ORACLE_DIR / f).stat().st_mtime > so.stat().st_mtime for f in ("oracle.cpp", "oracle.h"))
+        (ORACLE_DIR / f).stat().st_mtime > so.stat().st_mtime
+        for f in ("oracle.cpp", "oracle_unpack.cpp", "oracle.h"))
     if src_newer:
         build_oracle()
     return Oracle(C.CDLL(str(so)))
@@ -181,6 +254,46 @@ def load_ref():
     if not (a.exists() and b.exists()):
         return None
     return RefLibs(C.CDLL(str(a)), C.CDLL(str(b)))
+
+
+class RefUnpack:
+    """Genuine reference unpackers + ScanDataHolder (oracle/_ref/libunpackref.so)."""
+
+    def __init__(self, lib: C.CDLL):
+        self.lib = lib
+        vp, sz = C.c_void_p, C.c_size_t
+        lib.ref_unpack.argtypes = [C.c_uint8, vp, sz, sz, C.c_uint32, vp, sz, vp, sz,
+                                   C.POINTER(sz), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.ref_unpack.restype = sz
+        lib.ref_segment.argtypes = [vp, sz, vp, sz, sz, vp, sz, vp, sz]
+        lib.ref_segment.restype = sz
+
+    def unpack(self, ans: int, data, sample_duration_us: int = 125, chunk: int = 0):
+        data = np.ascontiguousarray(data, np.uint8)
+        cap = (len(data) // 4 + 1) * 4 + 200  # >= nodes any answer type can publish
+        out = np.zeros(cap, NODE)
+        rst = np.zeros(len(data) // 5 + 2, np.uint32)
+        nr, ne, nenc = C.c_size_t(0), C.c_uint32(0), C.c_uint32(0)
+        n = self.lib.ref_unpack(ans, data.ctypes.data, len(data), chunk, sample_duration_us,
+                                out.ctypes.data, cap, rst.ctypes.data, len(rst), C.byref(nr),
+                                C.byref(ne), C.byref(nenc))
+        assert n <= cap
+        return out[:n], rst[: nr.value], int(ne.value)
+
+    def segment(self, nodes, reset_at, max_count: int = 8192):
+        nodes = np.ascontiguousarray(nodes)
+        reset_at = np.ascontiguousarray(reset_at, np.uint32)
+        out = np.zeros(max(len(nodes), 1), NODE)
+        offs = np.zeros(len(nodes) + 2, np.uint32)
+        ns = self.lib.ref_segment(nodes.ctypes.data, len(nodes), reset_at.ctypes.data,
+                                  len(reset_at), max_count, out.ctypes.data, len(out),
+                                  offs.ctypes.data, len(offs))
+        return out[: offs[ns]], offs[: ns + 1]
+
+
+def load_ref_unpack():
+    so = ORACLE_DIR / "_ref" / "libunpackref.so"
+    return RefUnpack(C.CDLL(str(so))) if so.exists() else None
 
 
 def canon_equal_angle_runs(nodes: np.ndarray) -> np.ndarray:
