@@ -12,6 +12,8 @@
  *   S3  RPlidarNode::publish_scan body, src/rplidar_node.cpp:568-680 (mask, Q14->rad,
  *         Q2mm->m, quality->intensity, sort, Mode A min-binning / Mode B raw mapping)
  *         -> rplgpu_scan_to_laserscan / rplgpu_laserscan_batch_dev
+ *   pre the step before S1 for recorded input: SDK sample-data unpackers + scan assembly
+ *         -> rplgpu_frame_stream / rplgpu_decode_batch_dev / rplgpu_segment_batch_dev
  *   ext polar->Cartesian PointCloud2 (x,y,z,intensity FLOAT32, point_step 16) with
  *         quality/range clip (E1), radius-outlier removal (E5, applied before the voxel
  *         grid) and voxel-grid downsample (E4)
@@ -58,6 +60,19 @@ extern "C" {
 #define RPLGPU_SCAN_CELL_RANGE 0x2u    /* voxel: |cell index| >= 32767 (range/leaf too large) */
 #define RPLGPU_SCAN_TABLE_FULL 0x4u    /* voxel: more occupied cells than the on-chip table holds */
 #define RPLGPU_SCAN_OUT_TRUNCATED 0x8u /* output region (out_stride) too small; count is clamped */
+/* per-stream status bits of the decode stage */
+#define RPLGPU_STREAM_UNFRAMED 0x10u         /* frames given back to back but a frame does not start
+                                                 with its sync pattern: run rplgpu_frame_stream */
+#define RPLGPU_STREAM_FRAMES_TRUNCATED 0x20u /* more frames / sync nodes than one call handles */
+#define RPLGPU_STREAM_RESETS_TRUNCATED 0x40u /* reset list / scan table (caller-sized) too small */
+
+/* measurement answer types (src/sdk/include/sl_lidar_cmd.h:144-151) */
+#define RPLGPU_ANS_MEASUREMENT 0x81
+#define RPLGPU_ANS_CAPSULED 0x82
+#define RPLGPU_ANS_HQ 0x83
+#define RPLGPU_ANS_CAPSULED_ULTRA 0x84
+#define RPLGPU_ANS_DENSE_CAPSULED 0x85
+#define RPLGPU_ANS_ULTRA_DENSE_CAPSULED 0x86
 
 /* One raw sample == sl_lidar_response_measurement_node_hq_t
  * (src/sdk/include/sl_lidar_cmd.h:272-278): packed, 8 bytes, u32 at offset 2. */
@@ -143,6 +158,68 @@ int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
 int32_t rplgpu_pack_clouds_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t out_stride,
                                const uint32_t *d_n_points, uint32_t B, float *d_packed,
                                uint64_t *d_offsets);
+
+/* ---- the step before the path: recorded answer streams -> nodes -> scans -------------
+ * (SURVEY.md §8(f) rows 1-2).  Replaces, for recorded / batched input, the reference SDK's
+ *   sl::internal::LIDARSampleDataUnpacker::onSampleData(ansType, buf, len)
+ *     src/sdk/src/dataunpacker/dataunpacker.h:79, handlers unpacker/handler_*.cpp
+ *   ScanDataHolder::pushScanNodeData / rewindCurrentScanData
+ *     src/sdk/src/sl_lidar_driver.cpp:272-315 (driven from :1645-1653)
+ * Decoding is split like the reference's byte state machines are not: FRAMING (which bytes
+ * form frames; sequential, trivial, done on the host by rplgpu_frame_stream) and DECODING
+ * (checksums, inter-capsule state, per-sample integer arithmetic; on the GPU).  Node
+ * timestamps are not produced (the reference uses the decoding host's wall clock). */
+size_t rplgpu_frame_size(uint8_t ans_type);      /* bytes per frame, 0 = unknown type */
+size_t rplgpu_nodes_per_frame(uint8_t ans_type); /* nodes a frame can publish */
+uint32_t rplgpu_decode_max_frames(uint8_t ans_type); /* frames of one stream per decode call */
+/* Host framing: the position-0/1 rules of every onData loop.  frame_off[k] = byte offset of
+ * frame k; gap[k] = 1 when bytes were rejected between frame k-1 and frame k (that clears the
+ * reference's previous-capsule latch).  Returns the number of frames found (may exceed cap). */
+size_t rplgpu_frame_stream(uint8_t ans_type, const uint8_t *bytes, size_t nbytes,
+                           uint32_t *frame_off, uint8_t *gap, size_t cap);
+/* Decode B streams.  Stream b: bytes at d_bytes + b*stream_stride; d_n_frames[b] frames at byte
+ * offsets d_frame_off[b*max_frames + k] (NULL: back to back, k*frame_size — then every frame
+ * must start with its sync pattern or the stream gets RPLGPU_STREAM_UNFRAMED and no output);
+ * d_gap optional (same shape).  sample_duration_us: SlamtecLidarTimingDesc::sample_duration_uS
+ * (1..1000000; dense / ultra-dense discard threshold).  d_state_in/out (optional, 2 x int32 per
+ * stream): {last sync bit, last dist_q2} carried between calls on the same stream (the
+ * reference keeps them in a function-level static / members).  Outputs per stream: nodes at
+ * d_nodes + b*node_stride, d_n_nodes[b]; d_reset_at[b*reset_stride + i] = number of nodes
+ * published before the i-th scan-reset request, d_n_reset[b]; d_n_errors[b] checksum / CRC
+ * failures; d_status[b]. */
+int32_t rplgpu_decode_batch_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
+                                const uint8_t *d_bytes, uint64_t stream_stride,
+                                const uint32_t *d_frame_off, const uint8_t *d_gap,
+                                const uint32_t *d_n_frames, uint32_t max_frames, uint32_t B,
+                                const int32_t *d_state_in, int32_t *d_state_out,
+                                rplgpu_node_t *d_nodes, uint32_t node_stride, uint32_t *d_n_nodes,
+                                uint32_t *d_reset_at, uint32_t reset_stride, uint32_t *d_n_reset,
+                                uint32_t *d_n_errors, uint32_t *d_status);
+/* Scan assembly: completed scans of stream b back to back at d_out_nodes + b*out_stride, scan s
+ * = [d_scan_off[b*(scan_cap+1)+s], ..+s+1]), d_n_scans[b].  max_count = ScanDataHolder capacity
+ * (8192 in the reference; a longer scan keeps overwriting its last slot). */
+int32_t rplgpu_segment_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
+                                 uint32_t node_stride, const uint32_t *d_n_nodes,
+                                 const uint32_t *d_reset_at, uint32_t reset_stride,
+                                 const uint32_t *d_n_reset, uint32_t B, uint32_t max_count,
+                                 rplgpu_node_t *d_out_nodes, uint32_t out_stride,
+                                 uint32_t *d_scan_off, uint32_t scan_cap, uint32_t *d_n_scans,
+                                 uint32_t *d_status);
+/* Completed scans of all streams -> the fixed-stride scan batch of the *_batch_dev entry points
+ * (scan g at d_batch + g*n_stride, stream-major order).  d_scan_base: B+1 words of scratch, on
+ * return d_scan_base[B] = total number of scans. */
+int32_t rplgpu_scans_to_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_seg_nodes,
+                                  uint32_t seg_stride, const uint32_t *d_scan_off,
+                                  uint32_t scan_cap, const uint32_t *d_n_scans, uint32_t B,
+                                  uint32_t *d_scan_base, rplgpu_node_t *d_batch, uint32_t n_stride,
+                                  uint32_t max_scans, uint32_t *d_n_per_scan);
+/* One stream, HOST buffers: framing + decode (+ state carried in the handle per answer type is
+ * NOT kept: pass state in/out explicitly).  nodes: cap entries; reset_at: reset_cap entries. */
+int32_t rplgpu_decode_stream(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
+                             const uint8_t *bytes, size_t nbytes, int32_t state[2],
+                             rplgpu_node_t *nodes, size_t cap, size_t *n_nodes,
+                             uint32_t *reset_at, size_t reset_cap, size_t *n_reset,
+                             uint32_t *n_errors);
 
 /* LaserScan scalars from a beam count (host arithmetic of :623-627,:635-638,:666-669). */
 void rplgpu_fill_meta(const rplgpu_params_t *p, uint32_t count, double scan_duration,

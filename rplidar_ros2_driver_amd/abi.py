@@ -53,6 +53,14 @@ ABI_SYMBOLS = [
     "rplgpu_cloud_batch_dev",
     "rplgpu_pack_clouds_dev",
     "rplgpu_fill_meta",
+    "rplgpu_frame_size",
+    "rplgpu_nodes_per_frame",
+    "rplgpu_decode_max_frames",
+    "rplgpu_frame_stream",
+    "rplgpu_decode_batch_dev",
+    "rplgpu_segment_batch_dev",
+    "rplgpu_scans_to_batch_dev",
+    "rplgpu_decode_stream",
 ]
 
 
@@ -150,6 +158,22 @@ def load_library() -> C.CDLL:
     lib.rplgpu_pack_clouds_dev.argtypes = [vp, vp, u32, vp, u32, vp, vp]
     lib.rplgpu_fill_meta.argtypes = [C.POINTER(Params), u32, C.c_double, C.POINTER(ScanMeta)]
     lib.rplgpu_fill_meta.restype = None
+    u8, u64 = C.c_uint8, C.c_uint64
+    lib.rplgpu_frame_size.argtypes = [u8]
+    lib.rplgpu_frame_size.restype = sz
+    lib.rplgpu_nodes_per_frame.argtypes = [u8]
+    lib.rplgpu_nodes_per_frame.restype = sz
+    lib.rplgpu_decode_max_frames.argtypes = [u8]
+    lib.rplgpu_decode_max_frames.restype = u32
+    lib.rplgpu_frame_stream.argtypes = [u8, vp, sz, vp, vp, sz]
+    lib.rplgpu_frame_stream.restype = sz
+    lib.rplgpu_decode_batch_dev.argtypes = [vp, u8, u32, vp, u64, vp, vp, vp, u32, u32, vp, vp,
+                                            vp, u32, vp, vp, u32, vp, vp, vp]
+    lib.rplgpu_segment_batch_dev.argtypes = [vp, vp, u32, vp, vp, u32, vp, u32, u32, vp, u32, vp,
+                                             u32, vp, vp]
+    lib.rplgpu_scans_to_batch_dev.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, vp, u32, u32, vp]
+    lib.rplgpu_decode_stream.argtypes = [vp, u8, u32, vp, sz, vp, vp, sz, C.POINTER(sz), vp, sz,
+                                         C.POINTER(sz), C.POINTER(u32)]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default
@@ -266,3 +290,63 @@ class RplGpu:
         meta = ScanMeta()
         self._lib.rplgpu_fill_meta(C.byref(params), count, scan_duration, C.byref(meta))
         return meta
+
+    # -- decode stage: recorded answer streams -> nodes -> scans -----
+    def decode_stream(self, ans_type: int, data: np.ndarray, sample_duration_us: int = 125,
+                      state=(0, 0)):
+        """One stream, host buffers: host framing + GPU decode.  Returns
+        ``(nodes, reset_at, n_errors, state_out)``."""
+        data = np.ascontiguousarray(data, np.uint8)
+        S = self._lib.rplgpu_frame_size(ans_type)
+        npf = self._lib.rplgpu_nodes_per_frame(ans_type)
+        cap = (len(data) // max(S, 1) + 1) * npf
+        nodes = np.zeros(max(cap, 1), NODE_DTYPE)
+        rst = np.zeros(len(data) // max(S, 1) + 2, np.uint32)
+        st = np.array(state, np.int32)
+        n, nr, ne = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0)
+        self._check(self._lib.rplgpu_decode_stream(
+            self._h, ans_type, sample_duration_us, data.ctypes.data, len(data), st.ctypes.data,
+            nodes.ctypes.data, len(nodes), C.byref(n), rst.ctypes.data, len(rst), C.byref(nr),
+            C.byref(ne)))
+        return nodes[: n.value], rst[: nr.value], int(ne.value), (int(st[0]), int(st[1]))
+
+    def decode_batch_dev(self, ans_type: int, sample_duration_us: int, d_bytes: int,
+                         stream_stride: int, d_frame_off: int, d_gap: int, d_n_frames: int,
+                         max_frames: int, B: int, d_state_in: int, d_state_out: int, d_nodes: int,
+                         node_stride: int, d_n_nodes: int, d_reset_at: int = 0,
+                         reset_stride: int = 0, d_n_reset: int = 0, d_n_errors: int = 0,
+                         d_status: int = 0):
+        self._check(self._lib.rplgpu_decode_batch_dev(
+            self._h, ans_type, sample_duration_us, d_bytes, stream_stride, d_frame_off, d_gap,
+            d_n_frames, max_frames, B, d_state_in, d_state_out, d_nodes, node_stride, d_n_nodes,
+            d_reset_at, reset_stride, d_n_reset, d_n_errors, d_status))
+
+    def segment_batch_dev(self, d_nodes: int, node_stride: int, d_n_nodes: int, d_reset_at: int,
+                          reset_stride: int, d_n_reset: int, B: int, max_count: int,
+                          d_out_nodes: int, out_stride: int, d_scan_off: int, scan_cap: int,
+                          d_n_scans: int, d_status: int = 0):
+        self._check(self._lib.rplgpu_segment_batch_dev(
+            self._h, d_nodes, node_stride, d_n_nodes, d_reset_at, reset_stride, d_n_reset, B,
+            max_count, d_out_nodes, out_stride, d_scan_off, scan_cap, d_n_scans, d_status))
+
+    def scans_to_batch_dev(self, d_seg_nodes: int, seg_stride: int, d_scan_off: int,
+                           scan_cap: int, d_n_scans: int, B: int, d_scan_base: int, d_batch: int,
+                           n_stride: int, max_scans: int, d_n_per_scan: int):
+        self._check(self._lib.rplgpu_scans_to_batch_dev(
+            self._h, d_seg_nodes, seg_stride, d_scan_off, scan_cap, d_n_scans, B, d_scan_base,
+            d_batch, n_stride, max_scans, d_n_per_scan))
+
+
+def frame_stream(ans_type: int, data: np.ndarray):
+    """Host framing (``rplgpu_frame_stream``): ``(frame_off, gap)`` of a recorded byte stream."""
+    lib = load_library()
+    data = np.ascontiguousarray(data, np.uint8)
+    S = lib.rplgpu_frame_size(ans_type)
+    if not S:
+        raise ValueError(f"unknown answer type {ans_type:#x}")
+    cap = len(data) // S + 1
+    off = np.zeros(cap, np.uint32)
+    gap = np.zeros(cap, np.uint8)
+    nf = lib.rplgpu_frame_stream(ans_type, data.ctypes.data, len(data), off.ctypes.data,
+                                 gap.ctypes.data, cap)
+    return off[:nf], gap[:nf]

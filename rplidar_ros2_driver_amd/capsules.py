@@ -134,7 +134,7 @@ def corrupt_stream(ans: int, frames: np.ndarray, seed: int, *, p_checksum: float
     f[bad, col[bad]] ^= (1 << rng.integers(0, 8, int(bad.sum()))).astype(np.uint8)
     bsync = rng.random(n) < p_sync
     which = rng.integers(0, 2, n)
-    f[bsync, which[bsync]] ^= 0xF0 if ans != ANS_MEASUREMENT else 0x03
+    f[bsync, which[bsync]] ^= 0xF0 if ans != ANS_MEASUREMENT else 0x01
     pieces = []
     garb = rng.random(n) < p_garbage
     for i in range(n):

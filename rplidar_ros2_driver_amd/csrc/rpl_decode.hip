@@ -1,0 +1,651 @@
+// rpl_decode.hip — the step BEFORE the hot path on gfx950:
+//   k_decode<ANS>   recorded answer streams (already framed) -> measurement_node_hq nodes,
+//                   one workgroup per stream, bit-exact with the reference SDK's unpackers
+//                   (src/sdk/src/dataunpacker/unpacker/handler_capsules.cpp / handler_hqnode.cpp /
+//                   handler_normalnode.cpp; integer arithmetic only);
+//   k_segment       node stream + scan-reset requests -> completed scans
+//                   (ScanDataHolder::pushScanNodeData / rewindCurrentScanData,
+//                   src/sdk/src/sl_lidar_driver.cpp:272-315);
+//   k_scans_to_batch completed scans of all streams -> the fixed-stride scan batch the
+//                   ascend / LaserScan / cloud kernels consume.
+//
+// The reference decodes a stream with a byte-at-a-time state machine that carries three kinds
+// of state.  They are made data-parallel as follows (citations: handler_capsules.cpp):
+//   * the "previous capsule ready" latch (:137-194): capsule k-1 is published while capsule k
+//     is handled iff  valid(k-1) && valid(k) && !gap(k) && !revolution_start(k)
+//     — a pure function of two neighbouring frames (valid = checksum ok; gap = bytes were
+//     rejected between the frames, known from framing);
+//   * the dense / ultra-dense sync-bit filter  s_i = r_i & ~s_{i-1}  (:770-771, :1025-1026):
+//     inside a run of raw sync bits the filtered bits alternate starting with 1, so
+//     s_i = r_i & (distance to the run's start is even); the raw bits go to an LDS bit set and
+//     each node scans back over its run with word operations;
+//   * the ultra-dense distance smoothing  d_i <- (d_i + d'_{i-1}) >> 1  (:997-1003): a genuine
+//     recurrence, but only along runs of scale-0 samples; a sample whose predecessor is not
+//     scale 0, or differs from it by more than 12 quarter-mm, cannot be reached by it (a
+//     smoothed value is within 4 of its raw value, the rule needs <= 8), so those samples are
+//     chain heads, computed locally, and each chain is walked by one thread from LDS.
+// Timestamps are not produced: the reference stamps nodes with the wall clock of the decoding
+// host (dataunpacker.cpp:164-166), not with anything in the stream.
+#include "rpl_device.hpp"
+#include "rpl_launch.hpp"
+
+namespace rpl {
+
+constexpr int kDecBlock = 256;
+constexpr uint32_t kDecMaxFrames = 4096;     // frames of one stream per call (LDS frame table)
+constexpr uint32_t kUdMaxFrames = 512;       // ultra-dense: 64 nodes each -> 32768 LDS slots
+constexpr uint32_t kRawBitWords = 4096;      // u64 words of raw sync bits (262144 nodes)
+
+__device__ __forceinline__ uint32_t ld8(const uint8_t *p) { return p[0]; }
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
+  return p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+__host__ __device__ constexpr uint32_t dec_frame_size(int ans) {
+  return ans == RPLGPU_ANS_MEASUREMENT            ? 5u
+         : ans == RPLGPU_ANS_CAPSULED             ? 84u
+         : ans == RPLGPU_ANS_HQ                   ? 781u
+         : ans == RPLGPU_ANS_CAPSULED_ULTRA       ? 132u
+         : ans == RPLGPU_ANS_DENSE_CAPSULED       ? 84u
+         : ans == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? 170u
+                                                  : 0u;
+}
+__host__ __device__ constexpr uint32_t dec_nodes_per_frame(int ans) {
+  return ans == RPLGPU_ANS_MEASUREMENT            ? 1u
+         : ans == RPLGPU_ANS_CAPSULED             ? 32u
+         : ans == RPLGPU_ANS_HQ                   ? 96u
+         : ans == RPLGPU_ANS_CAPSULED_ULTRA       ? 96u
+         : ans == RPLGPU_ANS_DENSE_CAPSULED       ? 40u
+         : ans == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? 64u
+                                                  : 0u;
+}
+
+// the common tail of every capsule decoder (e.g. :246-257): wrap the Q6 angle once, build the
+// flag byte, convert to Q14 (the u16 store truncates exactly like the reference's assignment)
+__device__ __forceinline__ uint2 make_node(int angle_q6, uint32_t dist_q2, uint32_t quality,
+                                           uint32_t sync) {
+  if (angle_q6 < 0) angle_q6 += (360 << 6);
+  if (angle_q6 >= (360 << 6)) angle_q6 -= (360 << 6);
+  const uint32_t q14 = (uint32_t)((angle_q6 << 8) / 90) & 0xFFFFu;
+  const uint32_t flag = sync | ((sync ^ 1u) << 1);
+  uint2 v;  // packed node: u16 angle | u32 dist (unaligned at byte 2) | u8 quality | u8 flag
+  v.x = q14 | (dist_q2 << 16);
+  v.y = (dist_q2 >> 16) | ((quality & 0xFFu) << 16) | (flag << 24);
+  return v;
+}
+
+// _varbitscale_decode (:422-458)
+__device__ __forceinline__ uint32_t varbitscale(uint32_t scaled, uint32_t &lvl) {
+  if (scaled >= 3328u) { lvl = 4; return (1u << 14) + ((scaled - 3328u) << 4); }
+  if (scaled >= 1792u) { lvl = 3; return (1u << 12) + ((scaled - 1792u) << 3); }
+  if (scaled >= 1280u) { lvl = 2; return (1u << 11) + ((scaled - 1280u) << 2); }
+  if (scaled >= 512u) { lvl = 1; return (1u << 9) + ((scaled - 512u) << 1); }
+  lvl = 0;
+  return scaled;
+}
+
+// CRC of handler_hqnode.cpp:124-126 / sl_crc.cpp:36-101: reflected CRC-32, zero padded by
+// 4 - (len & 3) bytes.  One thread per frame, table in LDS.
+__device__ __forceinline__ uint32_t crc32_padded(const uint8_t *p, uint32_t len,
+                                                 const uint32_t *table) {
+  uint32_t crc = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < len; ++i) crc = (crc >> 8) ^ table[(crc ^ p[i]) & 0xFFu];
+  const uint32_t pad = 4u - (len & 3u);
+  for (uint32_t i = 0; i < pad; ++i) crc = (crc >> 8) ^ table[crc & 0xFFu];
+  return crc ^ 0xFFFFFFFFu;
+}
+
+struct DecodeLds {
+  // per frame: bit31 valid, bit30 emits, bit29 reset request, bits 0..15 start_angle_sync_q6
+  uint32_t frame[kDecMaxFrames];
+  uint32_t emit_frame[kDecMaxFrames];  // compacted list of the frames that publish nodes
+  unsigned long long rawbits[kRawBitWords];  // dense / ultra-dense raw sync bits per node
+  uint32_t tmp[40];
+  uint32_t misc[8];  // 0 status, 1 n_emit, 2 n_reset
+  uint32_t crc_table[256];
+};
+struct UltraDenseLds {
+  uint16_t d[kUdMaxFrames * 64];  // bit15: scale 0; bits 0..13: raw (unsmoothed) dist_q2
+};
+
+__device__ __forceinline__ uint32_t dec_block_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
+  // exclusive scan over kDecBlock = 256 threads (4 waves)
+  uint32_t inc = wave_incl_scan(v);
+  if (lane_id() == 63) tmp[wave_id()] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kDecBlock / 64; ++w) {
+    const uint32_t t = tmp[w];
+    if (w < (int)wave_id()) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+template <int ANS>
+__global__ __launch_bounds__(kDecBlock) void k_decode(
+    const uint8_t *__restrict__ bytes, uint64_t stream_stride, const uint32_t *__restrict__ frame_off,
+    const uint8_t *__restrict__ gap, const uint32_t *__restrict__ n_frames, uint32_t max_frames,
+    uint32_t sample_duration_us, const int32_t *__restrict__ state_in,
+    int32_t *__restrict__ state_out, uint2 *__restrict__ nodes_out, uint32_t node_stride,
+    uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ reset_at, uint32_t reset_stride,
+    uint32_t *__restrict__ n_reset, uint32_t *__restrict__ n_errors, uint32_t *__restrict__ status) {
+  constexpr uint32_t S = dec_frame_size(ANS);
+  constexpr uint32_t NPF = dec_nodes_per_frame(ANS);
+  constexpr bool CAPS = ANS == RPLGPU_ANS_CAPSULED || ANS == RPLGPU_ANS_CAPSULED_ULTRA ||
+                        ANS == RPLGPU_ANS_DENSE_CAPSULED || ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
+  constexpr bool FILTERED = ANS == RPLGPU_ANS_DENSE_CAPSULED || ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
+  constexpr uint32_t SA_OFF = ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? 8u : 2u;
+  __shared__ DecodeLds L;
+  __shared__ UltraDenseLds U;  // only touched by the ultra-dense instantiation
+
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  const uint8_t *base = bytes + (size_t)b * stream_stride;
+  const uint32_t *foff = frame_off ? frame_off + (size_t)b * max_frames : nullptr;
+  const uint8_t *fgap = gap ? gap + (size_t)b * max_frames : nullptr;
+  const uint32_t nf = min(n_frames[b], min(max_frames, ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED
+                                                           ? kUdMaxFrames : kDecMaxFrames));
+  uint2 *out = nodes_out + (size_t)b * node_stride;
+  auto frame_ptr = [&](uint32_t k) -> const uint8_t * {
+    return base + (foff ? (size_t)foff[k] : (size_t)k * S);
+  };
+
+  if (tid < 8) L.misc[tid] = 0u;
+  if (ANS == RPLGPU_ANS_HQ) {
+    uint32_t c = tid;  // kDecBlock == 256 table entries
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+    L.crc_table[tid] = c;
+  }
+  if (n_frames[b] > nf && tid == 0) L.misc[0] = RPLGPU_STREAM_FRAMES_TRUNCATED;
+  __syncthreads();
+
+  // ---- P1: per frame: framing check (unframed input only), checksum, header word ---------
+  uint32_t my_err = 0, unframed = 0;
+  for (uint32_t k = tid; k < nf; k += kDecBlock) {
+    const uint8_t *f = frame_ptr(k);
+    uint32_t rec = 0;
+    if (ANS == RPLGPU_ANS_MEASUREMENT) {  // handler_normalnode.cpp:88-112
+      const uint32_t b0 = ld8(f), b1 = ld8(f + 1);
+      if (!foff && !((((b0 >> 1) ^ b0) & 1u) && (b1 & 1u))) unframed = 1;
+      rec = 0x80000000u;
+    } else if (ANS == RPLGPU_ANS_HQ) {  // handler_hqnode.cpp:99-172
+      if (!foff && ld8(f) != 0xA5u) unframed = 1;
+      const bool ok = crc32_padded(f, S - 4u, L.crc_table) == ld32(f + S - 4u);
+      rec = ok ? 0x80000000u : 0u;
+      my_err += ok ? 0u : 1u;
+    } else {  // the four capsule types: handler_capsules.cpp:107-194 and siblings
+      const uint32_t b0 = ld8(f), b1 = ld8(f + 1);
+      if (!foff && ((b0 >> 4) != 0xAu || (b1 >> 4) != 0x5u)) unframed = 1;
+      uint32_t x = 0;
+      for (uint32_t i = 2; i < S; ++i) x ^= f[i];
+      const bool ok = (((b0 & 0xFu) | (b1 << 4)) & 0xFFu) == x;
+      my_err += ok ? 0u : 1u;
+      rec = (ok ? 0x80000000u : 0u) | ld16(f + SA_OFF);
+    }
+    L.frame[k] = rec;
+  }
+  if (unframed) atomicOr(&L.misc[0], RPLGPU_STREAM_UNFRAMED);
+  __syncthreads();
+  const bool bad_framing = (L.misc[0] & RPLGPU_STREAM_UNFRAMED) != 0u;
+
+  // ---- P2: which frames publish, node offsets, reset requests ------------------------------
+  // (loop over chunks of 256 frames with a running carry)
+  uint32_t carry_nodes = 0, carry_emit = 0, carry_reset = 0;
+  const int thr_q8 = FILTERED ? (int)((360u * 100u * (ANS == RPLGPU_ANS_DENSE_CAPSULED ? 40u : 32u) /
+                                       (1000000u / sample_duration_us)) << 8)
+                              : 0;
+  for (uint32_t k0 = 0; k0 < nf && !bad_framing; k0 += kDecBlock) {
+    const uint32_t k = k0 + tid;
+    uint32_t emits = 0, resets = 0;
+    if (k < nf) {
+      const uint32_t rec = L.frame[k];
+      if (!CAPS) {
+        emits = rec >> 31;
+      } else if (rec >> 31) {
+        resets = (rec >> 15) & 1u;  // revolution start: publishNewScanReset (:160-171)
+        const bool prev_ok = k > 0 && (L.frame[k - 1] >> 31) && !(fgap && fgap[k]);
+        if (prev_ok && !resets) {
+          emits = 1;
+          if (FILTERED) {  // :750-754 / :971-975: too large an angle step -> discard
+            const int cur_q8 = (int)(rec & 0x7FFFu) << 2, prev_q8 = (int)(L.frame[k - 1] & 0x7FFFu) << 2;
+            int diff = cur_q8 - prev_q8;
+            if (prev_q8 > cur_q8) diff += (360 << 8);
+            if (diff > thr_q8) emits = 0;
+          }
+        }
+      }
+    }
+    uint32_t tot_e, tot_r;
+    const uint32_t ex_e = dec_block_scan(emits, L.tmp, &tot_e);
+    const uint32_t ex_r = dec_block_scan(resets, L.tmp, &tot_r);
+    if (emits) L.emit_frame[carry_emit + ex_e] = k;
+    if (resets) {
+      const uint32_t slot = carry_reset + ex_r;
+      if (reset_at && slot < reset_stride)
+        reset_at[(size_t)b * reset_stride + slot] = (carry_emit + ex_e) * NPF;
+    }
+    carry_emit += tot_e;
+    carry_reset += tot_r;
+  }
+  carry_nodes = carry_emit * NPF;
+  __syncthreads();
+  const uint32_t n_emit = carry_emit;
+  const uint32_t n_out = min(carry_nodes, node_stride);
+
+  // ---- P3: the nodes ----------------------------------------------------------------------
+  const int last_sync_in = state_in ? state_in[2 * b] : 0;
+  const int last_dist_in = state_in ? state_in[2 * b + 1] : 0;
+  for (uint32_t i0 = 0; i0 < carry_nodes; i0 += kDecBlock) {
+    const uint32_t i = i0 + tid;
+    const bool live = i < carry_nodes;
+    uint2 node = make_uint2(0u, 0u);
+    uint32_t raw_sync = 0;
+    if (live) {
+      const uint32_t e = i / NPF, pos = i - e * NPF;
+      const uint32_t k = L.emit_frame[e];
+      if (ANS == RPLGPU_ANS_MEASUREMENT) {  // handler_normalnode.cpp:121-130
+        const uint8_t *f = frame_ptr(k);
+        const uint32_t b0 = ld8(f), aq = ld16(f + 1), d = ld16(f + 3);
+        const uint32_t q14 = (((aq >> 1) << 8) / 90u) & 0xFFFFu;
+        node.x = q14 | (d << 16);
+        node.y = (((b0 >> 2) << 2) << 16) | ((b0 & 1u) << 24);
+      } else if (ANS == RPLGPU_ANS_HQ) {  // handler_hqnode.cpp:150-160: verbatim copy
+        const uint8_t *f = frame_ptr(k) + 9u + 8u * pos;
+        node.x = ld32(f);
+        node.y = ld32(f + 4);
+      } else {
+        const uint8_t *prev = frame_ptr(k - 1), *cur = frame_ptr(k);
+        // signed arithmetic throughout, as in the reference: a corrupted-but-checksummed start
+        // angle above 360 deg makes the step (and everything derived from it) negative
+        const int cur_q8 = (int)(L.frame[k] & 0x7FFFu) << 2;
+        const int prev_q8 = (int)(L.frame[k - 1] & 0x7FFFu) << 2;
+        int diff_q8 = cur_q8 - prev_q8;
+        if (prev_q8 > cur_q8) diff_q8 += (360 << 8);
+        if (ANS == RPLGPU_ANS_CAPSULED) {  // :206-260
+          const int inc = diff_q8 << 3;
+          const int ang = (prev_q8 << 8) + (int)pos * inc;
+          const uint8_t *c = prev + 4u + 5u * (pos >> 1);
+          const uint32_t da = ld16(c + 2u * (pos & 1u)), offs = ld8(c + 4);
+          const int dist = (int)(da & 0xFFFCu);
+          const int aoff = (int)(((pos & 1u) ? (offs >> 4) : (offs & 0xFu)) | ((da & 0x3u) << 4));
+          const int angle_q6 = (ang - (aoff << 13)) >> 10;
+          const uint32_t sync = (((ang + inc) % (360 << 16)) < inc) ? 1u : 0u;
+          node = make_node(angle_q6, (uint32_t)dist, dist ? (0x2Fu << 2) : 0u, sync);
+        } else if (ANS == RPLGPU_ANS_CAPSULED_ULTRA) {  // :460-577
+          const int inc = (diff_q8 << 3) / 3;
+          const int ang = (prev_q8 << 8) + (int)pos * inc;
+          const uint32_t cab = pos / 3u, j = pos - cab * 3u;
+          const uint32_t cx = ld32(prev + 4u + 4u * cab);
+          const uint32_t nx = (cab == 31u) ? ld32(cur + 4u) : ld32(prev + 4u + 4u * (cab + 1u));
+          uint32_t lvl1, lvl2;
+          const int major = (int)varbitscale(cx & 0xFFFu, lvl1);
+          const int major2 = (int)varbitscale(nx & 0xFFFu, lvl2);
+          int dist;
+          if (j == 0u) {
+            dist = major << 2;
+          } else {
+            int pred = (j == 1u) ? (((int)(cx << 10)) >> 22) : (((int)cx) >> 22);
+            if ((uint32_t)pred == 0xFFFFFE00u || (uint32_t)pred == 0x1FFu) {
+              dist = 0;
+            } else if (j == 1u) {
+              int base1 = major;
+              uint32_t l1 = lvl1;
+              if (!major && major2) { base1 = major2; l1 = lvl2; }
+              pred = (int)((uint32_t)pred << l1);
+              dist = (int)((uint32_t)(pred + base1) << 2);
+            } else {
+              pred = (int)((uint32_t)pred << lvl2);
+              dist = (int)((uint32_t)(pred + major2) << 2);
+            }
+          }
+          const uint32_t sync = (((ang + inc) % (360 << 16)) < inc) ? 1u : 0u;
+          int off_q16 = (int)(7.5 * 3.1415926535 * (1 << 16) / 180.0);
+          if (dist >= (50 * 4)) {  // triangulation angle correction :547-553
+            const int k1 = 98361;
+            const int k2 = k1 / dist;
+            off_q16 = (int)(8 * 3.1415926535 * (1 << 16) / 180) - (k2 << 6) - (k2 * k2 * k2) / 98304;
+          }
+          const int angle_q6 = (ang - (int)((double)(off_q16 * 180) / 3.14159265)) >> 10;
+          node = make_node(angle_q6, (uint32_t)dist, dist ? (0x2Fu << 2) : 0u, sync);
+        } else if (ANS == RPLGPU_ANS_DENSE_CAPSULED) {  // :756-784
+          const int inc = (diff_q8 << 8) / 40;
+          const int ang = (prev_q8 << 8) + (int)pos * inc;
+          const int dist = (int)ld16(prev + 4u + 2u * pos) << 2;
+          raw_sync = (((ang + inc) % (360 << 16)) < (inc * 2)) ? 1u : 0u;
+          node = make_node(ang >> 10, (uint32_t)dist, dist ? (0x2Fu << 2) : 0u, 0u);
+        } else {  // ultra dense :979-1045
+          const int inc = (diff_q8 << 8) / 64;
+          const int ang = (prev_q8 << 8) + (int)pos * inc;
+          const uint8_t *c = prev + 10u + 5u * (pos >> 1);
+          const uint32_t q4 = ld8(c + 4);
+          const uint32_t qds = ld16(c + 2u * (pos & 1u)) | (((pos & 1u) ? (q4 >> 4) : (q4 & 0xFu)) << 16);
+          const uint32_t scale = qds & 3u;
+          uint32_t quality, dist;
+          if (scale == 0u) { quality = qds >> 12; dist = (qds & 0xFFCu) * 2u; }
+          else if (scale == 1u) { quality = (qds >> 13) << 1; dist = (qds & 0x1FFCu) * 3u + (2046u << 2); }
+          else if (scale == 2u) { quality = (qds >> 14) << 2; dist = (qds & 0x3FFCu) * 4u + (8187u << 2); }
+          else { quality = (qds >> 15) << 3; dist = (qds & 0x7FFCu) * 5u + (24567u << 2); }
+          raw_sync = (((ang + inc) % (360 << 16)) < (inc * 2)) ? 1u : 0u;
+          node = make_node(ang >> 10, dist, quality, 0u);
+          // raw distance for the smoothing pass: scale 0 -> bit 15 + value (<= 8184);
+          // other scales only matter as "last distance" of a scale-0 successor, whose rule
+          // |d - last| <= 8 can hold only if last <= 8192: store min(dist, 0x3FFF)
+          U.d[i] = (uint16_t)(scale == 0u ? (0x8000u | dist) : min(dist, 0x3FFFu));
+        }
+      }
+    }
+    if (FILTERED) {  // raw sync bits of 64 consecutive nodes -> one LDS word
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(live && raw_sync);
+      if (lane_id() == 0 && (i >> 6) < kRawBitWords) L.rawbits[i >> 6] = m;
+    }
+    if (live && i < n_out) out[i] = node;  // dense types: the (rare) sync flags are set in P4
+  }
+
+  // ---- P4 (dense / ultra-dense): the sync-bit filter, s_i = r_i & ~s_{i-1} -------------------
+  int last_sync_out = last_sync_in, last_dist_out = last_dist_in;
+  if (FILTERED) {
+    __syncthreads();
+    const uint32_t nwords = (carry_nodes + 63u) >> 6;
+    for (uint32_t w = tid; w < nwords && w < kRawBitWords; w += kDecBlock) {
+      unsigned long long m = L.rawbits[w];
+      while (m) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t i = (w << 6) + bit;
+        // length of the run of raw sync bits ending just before i (across words, and into the
+        // carried-in state when the run reaches the start of the stream)
+        uint32_t run = 0;
+        int j = (int)i - 1;
+        while (j >= 0 && ((L.rawbits[j >> 6] >> (j & 63)) & 1ull)) { ++run; --j; }
+        if (j < 0 && last_sync_in) {
+          // s_{-1} = 1 acts like one more raw bit in front of the run
+          ++run;
+        }
+        const uint32_t s = (run & 1u) ? 0u : 1u;
+        if (s && i < n_out) {  // flag byte: sync | (!sync << 1) : 2 -> 1
+          uint2 v = out[i];
+          v.y = (v.y & 0x00FFFFFFu) | (1u << 24);
+          out[i] = v;
+        }
+        if (i == carry_nodes - 1u) L.misc[3] = s;  // carried-out state
+      }
+    }
+    if (tid == 0 && carry_nodes) {
+      const uint32_t i = carry_nodes - 1u;
+      if (!((L.rawbits[i >> 6] >> (i & 63)) & 1ull)) L.misc[3] = 0u;
+    }
+    __syncthreads();
+    if (carry_nodes) last_sync_out = (int)L.misc[3];
+  }
+
+  // ---- P5 (ultra-dense): distance smoothing along scale-0 chains (:997-1003, :1020) --------
+  if (ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED && carry_nodes) {
+    __syncthreads();
+    auto rawd = [&](uint32_t i) -> int { return (int)(U.d[i] & 0x3FFFu); };
+    auto is_s0 = [&](uint32_t i) -> bool { return (U.d[i] & 0x8000u) != 0u; };
+    for (uint32_t i = tid; i < carry_nodes; i += kDecBlock) {
+      if (!is_s0(i)) continue;
+      // head of a chain: its predecessor's FINAL value is known without smoothing history
+      int last;
+      bool head;
+      if (i == 0u) { head = true; last = last_dist_in; }
+      else if (!is_s0(i - 1u)) {
+        head = true;
+        last = rawd(i - 1u);
+        // a non-scale-0 predecessor above 0x3FFF was clamped: anything > 8192 + 8 behaves alike
+      } else {
+        const int dd = rawd(i) - rawd(i - 1u);
+        head = (dd > 12 || dd < -12);
+        last = rawd(i - 1u);  // irrelevant when head: |d - final(i-1)| > 8 whatever final is
+        if (head) last = 0;   // "no smoothing" is what happens; 0 disables the rule
+      }
+      if (!head) continue;
+      uint32_t jn = i;
+      while (true) {  // walk the chain
+        int d = rawd(jn);
+        if (last) {
+          int ad = d - last;
+          if (ad < 0) ad = -ad;
+          if (ad <= 8) d = (d + last) >> 1;
+        }
+        if (d != rawd(jn) && jn < n_out) {  // patch dist_mm_q2 (bits 16.. of the packed node)
+          uint2 v = out[jn];
+          v.x = (v.x & 0xFFFFu) | ((uint32_t)d << 16);
+          v.y = (v.y & 0xFFFF0000u) | ((uint32_t)d >> 16);
+          out[jn] = v;
+        }
+        last = d;
+        if (jn == carry_nodes - 1u) L.misc[4] = (uint32_t)d | 0x80000000u;
+        ++jn;
+        if (jn >= carry_nodes || !is_s0(jn)) break;
+        const int dd = rawd(jn) - rawd(jn - 1u);
+        if (dd > 12 || dd < -12) break;  // next node is a head of its own
+      }
+    }
+    __syncthreads();
+    if (L.misc[4] & 0x80000000u) {
+      last_dist_out = (int)(L.misc[4] & 0x7FFFFFFFu);
+    } else {  // last node is not scale 0: _last_dist_q2 = its own distance (:1020)
+      const uint32_t i = carry_nodes - 1u;
+      const uint32_t e = i / NPF, pos = i - e * NPF;
+      const uint8_t *prev = frame_ptr(L.emit_frame[e] - 1u);
+      const uint8_t *c = prev + 10u + 5u * (pos >> 1);
+      const uint32_t q4 = ld8(c + 4);
+      const uint32_t qds = ld16(c + 2u * (pos & 1u)) | (((pos & 1u) ? (q4 >> 4) : (q4 & 0xFu)) << 16);
+      const uint32_t scale = qds & 3u;
+      last_dist_out = scale == 1u ? (int)((qds & 0x1FFCu) * 3u + (2046u << 2))
+                      : scale == 2u ? (int)((qds & 0x3FFCu) * 4u + (8187u << 2))
+                                    : (int)((qds & 0x7FFCu) * 5u + (24567u << 2));
+    }
+  }
+
+  // ---- per-stream results ---------------------------------------------------------------------
+  for (int d = 32; d > 0; d >>= 1) my_err += (uint32_t)__shfl_xor((int)my_err, d, 64);
+  if (lane_id() == 0 && my_err) atomicAdd(&L.misc[5], my_err);
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t st = L.misc[0];
+    if (carry_nodes > node_stride) st |= RPLGPU_SCAN_OUT_TRUNCATED;
+    if (reset_at && carry_reset > reset_stride) st |= RPLGPU_STREAM_RESETS_TRUNCATED;
+    if (FILTERED && carry_nodes > kRawBitWords * 64u) st |= RPLGPU_STREAM_FRAMES_TRUNCATED;
+    n_nodes[b] = bad_framing ? 0u : n_out;
+    if (n_reset) n_reset[b] = bad_framing ? 0u : min(carry_reset, reset_at ? reset_stride : carry_reset);
+    if (n_errors) n_errors[b] = L.misc[5];
+    if (status) status[b] = st;
+    if (state_out) {
+      state_out[2 * b] = bad_framing ? last_sync_in : last_sync_out;
+      state_out[2 * b + 1] = bad_framing ? last_dist_in : last_dist_out;
+    }
+  }
+  (void)n_emit;
+}
+
+// ------------------------------------------------------------------------------------------
+// Scan assembly.  ScanDataHolder rules (src/sdk/src/sl_lidar_driver.cpp:272-315): a node with
+// flag bit 0 closes the scan being built (if it holds anything) and opens the next; nodes before
+// the first sync node are discarded; a rewind (scan-reset request, "before node p") empties the
+// scan being built and everything up to the next sync node is discarded; a scan that reached
+// max_count nodes keeps overwriting its last slot.  Hence scan j = [s_j, s_{j+1}) between two
+// consecutive sync nodes is completed iff no reset position p satisfies s_j < p <= s_{j+1}, and
+// it is nodes s_j .. s_j + max_count - 2 followed by node s_{j+1} - 1 when it is longer than
+// max_count.  One workgroup per stream: compact the sync positions, judge the scans, copy.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kSegMaxSync = 8192;
+
+__global__ __launch_bounds__(kDecBlock) void k_segment(
+    const uint2 *__restrict__ nodes, uint32_t node_stride, const uint32_t *__restrict__ n_nodes,
+    const uint32_t *__restrict__ reset_at, uint32_t reset_stride, const uint32_t *__restrict__ n_reset,
+    uint32_t max_count, uint2 *__restrict__ out_nodes, uint32_t out_stride,
+    uint32_t *__restrict__ scan_off, uint32_t scan_cap, uint32_t *__restrict__ n_scans,
+    uint32_t *__restrict__ status) {
+  __shared__ uint32_t sync_pos[kSegMaxSync + 1];
+  __shared__ uint32_t scan_len[kSegMaxSync];  // 0 = not completed
+  __shared__ uint32_t tmp[40];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  const uint2 *in = nodes + (size_t)b * node_stride;
+  uint2 *out = out_nodes + (size_t)b * out_stride;
+  const uint32_t n = min(n_nodes[b], node_stride);
+  const uint32_t nr = (reset_at && n_reset) ? min(n_reset[b], reset_stride) : 0u;
+  const uint32_t *rs = reset_at ? reset_at + (size_t)b * reset_stride : nullptr;
+  uint32_t st = 0;
+
+  // sync positions, in order
+  uint32_t nsync = 0;
+  for (uint32_t i0 = 0; i0 < n; i0 += kDecBlock) {
+    const uint32_t i = i0 + tid;
+    const uint32_t is = (i < n && ((in[i].y >> 24) & 1u)) ? 1u : 0u;
+    uint32_t tot;
+    const uint32_t ex = dec_block_scan(is, tmp, &tot);
+    if (is && nsync + ex <= kSegMaxSync) sync_pos[nsync + ex] = i;
+    nsync += tot;
+  }
+  if (nsync > kSegMaxSync + 1u) {
+    st |= RPLGPU_STREAM_FRAMES_TRUNCATED;
+    nsync = kSegMaxSync + 1u;
+  }
+  __syncthreads();
+  const uint32_t ncand = nsync ? nsync - 1u : 0u;  // scans closed by a following sync node
+  // which of them are complete, and how long
+  for (uint32_t j = tid; j < ncand; j += kDecBlock) {
+    const uint32_t s0 = sync_pos[j], s1 = sync_pos[j + 1];
+    // number of reset positions <= x (ascending list): lower bound by bisection
+    auto count_le = [&](uint32_t x) -> uint32_t {
+      uint32_t lo = 0, hi = nr;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rs[mid] <= x) lo = mid + 1; else hi = mid;
+      }
+      return lo;
+    };
+    const bool broken = nr && (count_le(s1) != count_le(s0));
+    scan_len[j] = broken ? 0u : min(s1 - s0, max_count);
+  }
+  __syncthreads();
+  // copy pass: the workgroup copies one completed scan after the other (there is one
+  // candidate per revolution, so the serial loop is short) and records the running offsets
+  uint32_t off = 0, stored = 0, completed = 0;
+  for (uint32_t j = 0; j < ncand; ++j) {
+    const uint32_t len = scan_len[j];
+    if (!len) continue;
+    ++completed;
+    if (stored >= scan_cap) continue;
+    const uint32_t s0 = sync_pos[j], s1 = sync_pos[j + 1];
+    for (uint32_t t = tid; t < len; t += kDecBlock) {
+      const uint32_t src = (t == len - 1u && (s1 - s0) > len) ? s1 - 1u : s0 + t;
+      if (off + t < out_stride) out[off + t] = in[src];
+    }
+    if (tid == 0) scan_off[(size_t)b * (scan_cap + 1u) + stored] = off;
+    off += len;
+    ++stored;
+  }
+  const uint32_t total_scans = stored;
+  if (completed > scan_cap) st |= RPLGPU_STREAM_RESETS_TRUNCATED;
+  if (off > out_stride) st |= RPLGPU_SCAN_OUT_TRUNCATED;
+  if (tid == 0) {
+    scan_off[(size_t)b * (scan_cap + 1u) + total_scans] = off;
+    n_scans[b] = total_scans;
+    if (status) status[b] = st;
+  }
+}
+
+// Completed scans of every stream -> the fixed-stride batch (scan g at batch + g*n_stride) that
+// rplgpu_ascend_batch_dev / rplgpu_laserscan_batch_dev / rplgpu_cloud_batch_dev take.  The
+// global scan index is the stream-major running count (d_scan_base from a prefix sum over
+// d_n_scans, computed by k_scan_base).  One workgroup per output scan slot.
+__global__ void k_scan_base(const uint32_t *__restrict__ n_scans, uint32_t B,
+                            uint32_t *__restrict__ scan_base) {
+  // B is small (streams): one thread does the running sum
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t b = 0; b < B; ++b) {
+      scan_base[b] = acc;
+      acc += n_scans[b];
+    }
+    scan_base[B] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kDecBlock) void k_scans_to_batch(
+    const uint2 *__restrict__ seg_nodes, uint32_t seg_stride, const uint32_t *__restrict__ scan_off,
+    uint32_t scan_cap, uint32_t B, const uint32_t *__restrict__ scan_base,
+    uint2 *__restrict__ batch, uint32_t n_stride, uint32_t max_scans,
+    uint32_t *__restrict__ n_per_scan) {
+  const uint32_t g = blockIdx.x;  // global scan index
+  if (g >= min(scan_base[B], max_scans)) return;
+  uint32_t lo = 0, hi = B;  // the stream b with scan_base[b] <= g < scan_base[b+1]
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (scan_base[mid] <= g) lo = mid; else hi = mid;
+  }
+  const uint32_t b = lo, s = g - scan_base[b];
+  const uint32_t *so = scan_off + (size_t)b * (scan_cap + 1u);
+  const uint32_t o0 = so[s], len = min(so[s + 1] - o0, n_stride);
+  const uint2 *src = seg_nodes + (size_t)b * seg_stride + o0;
+  uint2 *dst = batch + (size_t)g * n_stride;
+  for (uint32_t t = threadIdx.x; t < len; t += kDecBlock) dst[t] = src[t];
+  if (threadIdx.x == 0) n_per_scan[g] = len;
+}
+
+// ---- launchers ------------------------------------------------------------------------------
+hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
+                         const uint32_t *frame_off, const uint8_t *gap, const uint32_t *n_frames,
+                         uint32_t max_frames, uint32_t B, uint32_t sample_duration_us,
+                         const int32_t *state_in, int32_t *state_out, void *nodes,
+                         uint32_t node_stride, uint32_t *n_nodes, uint32_t *reset_at,
+                         uint32_t reset_stride, uint32_t *n_reset, uint32_t *n_errors,
+                         uint32_t *status) {
+  if (B == 0) return hipSuccess;
+#define RPL_LAUNCH_DEC(A)                                                                        \
+  hipLaunchKernelGGL((k_decode<A>), dim3(B), dim3(kDecBlock), 0, s, bytes, stream_stride,       \
+                     frame_off, gap, n_frames, max_frames, sample_duration_us, state_in,         \
+                     state_out, (uint2 *)nodes, node_stride, n_nodes, reset_at, reset_stride,    \
+                     n_reset, n_errors, status)
+  switch (ans) {
+    case RPLGPU_ANS_MEASUREMENT: RPL_LAUNCH_DEC(RPLGPU_ANS_MEASUREMENT); break;
+    case RPLGPU_ANS_CAPSULED: RPL_LAUNCH_DEC(RPLGPU_ANS_CAPSULED); break;
+    case RPLGPU_ANS_HQ: RPL_LAUNCH_DEC(RPLGPU_ANS_HQ); break;
+    case RPLGPU_ANS_CAPSULED_ULTRA: RPL_LAUNCH_DEC(RPLGPU_ANS_CAPSULED_ULTRA); break;
+    case RPLGPU_ANS_DENSE_CAPSULED: RPL_LAUNCH_DEC(RPLGPU_ANS_DENSE_CAPSULED); break;
+    case RPLGPU_ANS_ULTRA_DENSE_CAPSULED: RPL_LAUNCH_DEC(RPLGPU_ANS_ULTRA_DENSE_CAPSULED); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef RPL_LAUNCH_DEC
+  return hipGetLastError();
+}
+
+hipError_t launch_segment(hipStream_t s, const void *nodes, uint32_t node_stride,
+                          const uint32_t *n_nodes, const uint32_t *reset_at, uint32_t reset_stride,
+                          const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *out_nodes,
+                          uint32_t out_stride, uint32_t *scan_off, uint32_t scan_cap,
+                          uint32_t *n_scans, uint32_t *status) {
+  if (B == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_segment, dim3(B), dim3(kDecBlock), 0, s, (const uint2 *)nodes, node_stride,
+                     n_nodes, reset_at, reset_stride, n_reset, max_count, (uint2 *)out_nodes,
+                     out_stride, scan_off, scan_cap, n_scans, status);
+  return hipGetLastError();
+}
+
+hipError_t launch_scans_to_batch(hipStream_t s, const void *seg_nodes, uint32_t seg_stride,
+                                 const uint32_t *scan_off, uint32_t scan_cap,
+                                 const uint32_t *n_scans, uint32_t B, uint32_t *scan_base,
+                                 void *batch, uint32_t n_stride, uint32_t max_scans,
+                                 uint32_t *n_per_scan) {
+  if (B == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_scan_base, dim3(1), dim3(64), 0, s, n_scans, B, scan_base);
+  if (max_scans == 0) return hipGetLastError();
+  hipLaunchKernelGGL(k_scans_to_batch, dim3(max_scans), dim3(kDecBlock), 0, s,
+                     (const uint2 *)seg_nodes, seg_stride, scan_off, scan_cap, B, scan_base,
+                     (uint2 *)batch, n_stride, max_scans, n_per_scan);
+  return hipGetLastError();
+}
+
+uint32_t decode_max_frames(int ans) {
+  return ans == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? kUdMaxFrames : kDecMaxFrames;
+}
+
+}  // namespace rpl

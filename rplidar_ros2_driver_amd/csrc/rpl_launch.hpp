@@ -40,4 +40,24 @@ hipError_t launch_validate_div(hipStream_t s, float d, float rd, uint32_t e_lo, 
 hipError_t launch_pack(hipStream_t s, const float *xyzi, uint32_t out_stride,
                        const uint32_t *n_points, uint32_t B, float *packed, uint64_t *offsets);
 
+// decode stage (rpl_decode.hip)
+hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
+                         const uint32_t *frame_off, const uint8_t *gap, const uint32_t *n_frames,
+                         uint32_t max_frames, uint32_t B, uint32_t sample_duration_us,
+                         const int32_t *state_in, int32_t *state_out, void *nodes,
+                         uint32_t node_stride, uint32_t *n_nodes, uint32_t *reset_at,
+                         uint32_t reset_stride, uint32_t *n_reset, uint32_t *n_errors,
+                         uint32_t *status);
+hipError_t launch_segment(hipStream_t s, const void *nodes, uint32_t node_stride,
+                          const uint32_t *n_nodes, const uint32_t *reset_at, uint32_t reset_stride,
+                          const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *out_nodes,
+                          uint32_t out_stride, uint32_t *scan_off, uint32_t scan_cap,
+                          uint32_t *n_scans, uint32_t *status);
+hipError_t launch_scans_to_batch(hipStream_t s, const void *seg_nodes, uint32_t seg_stride,
+                                 const uint32_t *scan_off, uint32_t scan_cap,
+                                 const uint32_t *n_scans, uint32_t B, uint32_t *scan_base,
+                                 void *batch, uint32_t n_stride, uint32_t max_scans,
+                                 uint32_t *n_per_scan);
+uint32_t decode_max_frames(int ans);
+
 }  // namespace rpl

@@ -552,4 +552,207 @@ int32_t rplgpu_scan_to_cloud(rplgpu_handle_t h, const rplgpu_node_t *nodes, size
                                                                           : RPLGPU_OK;
 }
 
+// ---- decode stage ------------------------------------------
+
+size_t rplgpu_frame_size(uint8_t ans_type) {
+  switch (ans_type) {  // packed wire structs, src/sdk/include/sl_lidar_cmd.h:189-286
+    case RPLGPU_ANS_MEASUREMENT: return 5;
+    case RPLGPU_ANS_CAPSULED: return 84;
+    case RPLGPU_ANS_HQ: return 781;
+    case RPLGPU_ANS_CAPSULED_ULTRA: return 132;
+    case RPLGPU_ANS_DENSE_CAPSULED: return 84;
+    case RPLGPU_ANS_ULTRA_DENSE_CAPSULED: return 170;
+    default: return 0;
+  }
+}
+
+size_t rplgpu_nodes_per_frame(uint8_t ans_type) {
+  switch (ans_type) {
+    case RPLGPU_ANS_MEASUREMENT: return 1;
+    case RPLGPU_ANS_CAPSULED: return 32;
+    case RPLGPU_ANS_HQ: return 96;
+    case RPLGPU_ANS_CAPSULED_ULTRA: return 96;
+    case RPLGPU_ANS_DENSE_CAPSULED: return 40;
+    case RPLGPU_ANS_ULTRA_DENSE_CAPSULED: return 64;
+    default: return 0;
+  }
+}
+
+uint32_t rplgpu_decode_max_frames(uint8_t ans_type) {
+  return rplgpu_frame_size(ans_type) ? rpl::decode_max_frames(ans_type) : 0u;
+}
+
+// Framing = what the first two switch cases of every onData loop decide
+// (handler_capsules.cpp:107-135 and siblings, handler_hqnode.cpp:99-113,
+// handler_normalnode.cpp:88-112): a frame starts at a byte accepted in position 0 whose
+// successor is accepted in position 1; rejected bytes are dropped one at a time (a byte
+// rejected in position 1 is dropped together with the pending position-0 byte's claim, it is
+// not reconsidered as a start).  Sequential by nature, a few ns per byte, so it runs on the
+// host; the GPU gets (offset, gap) per frame.
+size_t rplgpu_frame_stream(uint8_t ans_type, const uint8_t *bytes, size_t nbytes,
+                           uint32_t *frame_off, uint8_t *gap, size_t cap) {
+  const size_t S = rplgpu_frame_size(ans_type);
+  if (!S || (!bytes && nbytes)) return 0;
+  const bool hq = ans_type == RPLGPU_ANS_HQ, legacy = ans_type == RPLGPU_ANS_MEASUREMENT;
+  size_t found = 0, i = 0;
+  uint8_t dirty = 0;
+  while (i < nbytes) {
+    const uint8_t b0 = bytes[i];
+    const bool start_ok = hq ? (b0 == 0xA5u) : legacy ? ((((b0 >> 1) ^ b0) & 1u) != 0u)
+                                                      : ((b0 >> 4) == 0xAu);
+    if (!start_ok) {
+      dirty = 1;
+      ++i;
+      continue;
+    }
+    if (!hq) {
+      if (i + 1 >= nbytes) break;  // the second byte has not arrived yet
+      const uint8_t b1 = bytes[i + 1];
+      const bool second_ok = legacy ? ((b1 & 1u) != 0u) : ((b1 >> 4) == 0x5u);
+      if (!second_ok) {
+        dirty = 1;
+        i += 2;  // both bytes are consumed
+        continue;
+      }
+    }
+    if (i + S > nbytes) break;  // incomplete trailing frame stays in the reference's cache
+    if (found < cap) {
+      if (frame_off) frame_off[found] = (uint32_t)i;
+      if (gap) gap[found] = dirty;
+    }
+    ++found;
+    dirty = 0;
+    i += S;
+  }
+  return found;
+}
+
+int32_t rplgpu_decode_batch_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
+                                const uint8_t *d_bytes, uint64_t stream_stride,
+                                const uint32_t *d_frame_off, const uint8_t *d_gap,
+                                const uint32_t *d_n_frames, uint32_t max_frames, uint32_t B,
+                                const int32_t *d_state_in, int32_t *d_state_out,
+                                rplgpu_node_t *d_nodes, uint32_t node_stride, uint32_t *d_n_nodes,
+                                uint32_t *d_reset_at, uint32_t reset_stride, uint32_t *d_n_reset,
+                                uint32_t *d_n_errors, uint32_t *d_status) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  if (!rplgpu_frame_size(ans_type)) return RPLGPU_ERR_INVALID_ARG;
+  // the dense / ultra-dense discard threshold divides by 1000000 / sample_duration_us
+  // (handler_capsules.cpp:750, :971): zero or > 1 s would divide by zero in the reference too
+  if (sample_duration_us == 0 || sample_duration_us > 1000000u) return RPLGPU_ERR_INVALID_ARG;
+  if (B && (!d_bytes || !d_n_frames || !d_nodes || !d_n_nodes)) return RPLGPU_ERR_INVALID_ARG;
+  if (d_gap && !d_frame_off) return RPLGPU_ERR_INVALID_ARG;
+  if (max_frames > rpl::decode_max_frames(ans_type)) return RPLGPU_ERR_CAPACITY;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_decode(h->stream, ans_type, d_bytes, stream_stride, d_frame_off, d_gap,
+                                d_n_frames, max_frames, B, sample_duration_us, d_state_in,
+                                d_state_out, d_nodes, node_stride, d_n_nodes, d_reset_at,
+                                reset_stride, d_n_reset, d_n_errors, d_status));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_segment_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
+                                 uint32_t node_stride, const uint32_t *d_n_nodes,
+                                 const uint32_t *d_reset_at, uint32_t reset_stride,
+                                 const uint32_t *d_n_reset, uint32_t B, uint32_t max_count,
+                                 rplgpu_node_t *d_out_nodes, uint32_t out_stride,
+                                 uint32_t *d_scan_off, uint32_t scan_cap, uint32_t *d_n_scans,
+                                 uint32_t *d_status) {
+  if (!h || max_count == 0) return RPLGPU_ERR_INVALID_ARG;
+  if (B && (!d_nodes || !d_n_nodes || !d_out_nodes || !d_scan_off || !d_n_scans))
+    return RPLGPU_ERR_INVALID_ARG;
+  if ((d_reset_at == nullptr) != (d_n_reset == nullptr)) return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_segment(h->stream, d_nodes, node_stride, d_n_nodes, d_reset_at,
+                                 reset_stride, d_n_reset, B, max_count, d_out_nodes, out_stride,
+                                 d_scan_off, scan_cap, d_n_scans, d_status));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_scans_to_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_seg_nodes,
+                                  uint32_t seg_stride, const uint32_t *d_scan_off,
+                                  uint32_t scan_cap, const uint32_t *d_n_scans, uint32_t B,
+                                  uint32_t *d_scan_base, rplgpu_node_t *d_batch, uint32_t n_stride,
+                                  uint32_t max_scans, uint32_t *d_n_per_scan) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  if (B && (!d_seg_nodes || !d_scan_off || !d_n_scans || !d_scan_base || !d_batch || !d_n_per_scan))
+    return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_scans_to_batch(h->stream, d_seg_nodes, seg_stride, d_scan_off, scan_cap,
+                                        d_n_scans, B, d_scan_base, d_batch, n_stride, max_scans,
+                                        d_n_per_scan));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_decode_stream(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
+                             const uint8_t *bytes, size_t nbytes, int32_t state[2],
+                             rplgpu_node_t *nodes, size_t cap, size_t *n_nodes,
+                             uint32_t *reset_at, size_t reset_cap, size_t *n_reset,
+                             uint32_t *n_errors) {
+  if (!h || !n_nodes || (nbytes && !bytes) || (cap && !nodes)) return RPLGPU_ERR_INVALID_ARG;
+  const size_t S = rplgpu_frame_size(ans_type), npf = rplgpu_nodes_per_frame(ans_type);
+  if (!S) return RPLGPU_ERR_INVALID_ARG;
+  *n_nodes = 0;
+  if (n_reset) *n_reset = 0;
+  if (n_errors) *n_errors = 0;
+  if (nbytes >= 0xFFFFFFFFull) return RPLGPU_ERR_CAPACITY;
+  const size_t max_f = nbytes / S;
+  std::vector<uint32_t> off(max_f ? max_f : 1);
+  std::vector<uint8_t> gap(max_f ? max_f : 1);
+  const size_t nf = rplgpu_frame_stream(ans_type, bytes, nbytes, off.data(), gap.data(), max_f);
+  if (nf == 0) return RPLGPU_OK;
+  if (nf > rpl::decode_max_frames(ans_type)) return RPLGPU_ERR_CAPACITY;
+  RPL_HIP(h, hipSetDevice(h->device));
+  // one-off device staging (this entry point is the convenience path; batches use *_batch_dev)
+  const size_t node_cap = nf * npf, rcap = nf + 1;
+  const size_t sz_bytes = (nbytes + 15) & ~size_t(15), sz_off = nf * 4, sz_gap = (nf + 15) & ~size_t(15);
+  const size_t sz_nodes = node_cap * 8, sz_rst = rcap * 4, sz_small = 64;
+  unsigned char *d = nullptr;
+  RPL_HIP(h, hipMalloc(&d, sz_bytes + sz_off + sz_gap + sz_nodes + sz_rst + sz_small));
+  unsigned char *d_b = d, *d_off = d_b + sz_bytes, *d_gap = d_off + sz_off;
+  unsigned char *d_nodes = d_gap + sz_gap, *d_rst = d_nodes + sz_nodes, *d_small = d_rst + sz_rst;
+  // d_small: [0] n_frames [1] n_nodes [2] n_reset [3] n_err [4] status [5,6] state in [7,8] state out
+  uint32_t small[16] = {0};
+  small[0] = (uint32_t)nf;
+  small[5] = state ? (uint32_t)state[0] : 0u;
+  small[6] = state ? (uint32_t)state[1] : 0u;
+  int32_t rc = RPLGPU_OK;
+  auto fail = [&](hipError_t e, const char *what) {
+    h->err = std::string(what) + ": " + hipGetErrorString(e);
+    rc = RPLGPU_ERR_HIP;
+  };
+  hipError_t e;
+  if ((e = hipMemcpyAsync(d_b, bytes, nbytes, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy bytes");
+  if (!rc && (e = hipMemcpyAsync(d_off, off.data(), sz_off, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy offsets");
+  if (!rc && (e = hipMemcpyAsync(d_gap, gap.data(), nf, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy gaps");
+  if (!rc && (e = hipMemcpyAsync(d_small, small, sz_small, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy small");
+  if (!rc) {
+    uint32_t *ds = reinterpret_cast<uint32_t *>(d_small);
+    rc = rplgpu_decode_batch_dev(h, ans_type, sample_duration_us, d_b, 0,
+                                 reinterpret_cast<uint32_t *>(d_off), d_gap, ds, (uint32_t)nf, 1,
+                                 reinterpret_cast<int32_t *>(ds + 5), reinterpret_cast<int32_t *>(ds + 7),
+                                 reinterpret_cast<rplgpu_node_t *>(d_nodes), (uint32_t)node_cap, ds + 1,
+                                 reinterpret_cast<uint32_t *>(d_rst), (uint32_t)rcap, ds + 2, ds + 3, ds + 4);
+  }
+  if (!rc && (e = hipMemcpyAsync(small, d_small, sz_small, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) fail(e, "copy back");
+  if (!rc && (e = hipStreamSynchronize(h->stream)) != hipSuccess) fail(e, "sync");
+  if (!rc) {
+    const size_t got = small[1], nr = small[2];
+    *n_nodes = got;
+    if (n_reset) *n_reset = nr;
+    if (n_errors) *n_errors = small[3];
+    if (state) {
+      state[0] = (int32_t)small[7];
+      state[1] = (int32_t)small[8];
+    }
+    const size_t ncopy = got < cap ? got : cap, rcopy = nr < reset_cap ? nr : reset_cap;
+    if (ncopy && (e = hipMemcpy(nodes, d_nodes, ncopy * 8, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy nodes");
+    if (!rc && rcopy && reset_at &&
+        (e = hipMemcpy(reset_at, d_rst, rcopy * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+      fail(e, "copy resets");
+  }
+  (void)hipFree(d);
+  return rc;
+}
+
 }  // extern "C"

@@ -1,0 +1,281 @@
+"""GPU parity tests of the decode stage: recorded answer streams ->
+nodes (k_decode) -> completed scans (k_segment) -> scan batch, through the C ABI, against the
+CPU oracle (oracle/oracle_unpack.cpp, itself pinned against the genuine SDK) and against the
+golden vectors produced by the genuine SDK unpackers.  Integer work: bit-exact everywhere."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from rplidar_ros2_driver_amd import NODE_DTYPE, Params, abi
+from rplidar_ros2_driver_amd import capsules as cp
+from tests import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+GOLD = Path(__file__).resolve().parent / "golden" / "unpack_golden.npz"
+ALL_ANS = (0x81, 0x82, 0x83, 0x84, 0x85, 0x86)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _check_stream(gpu, oracle, ans, data, dur, state=(0, 0)):
+    nodes, rst, err, st = gpu.decode_stream(ans, data, dur, state)
+    w_nodes, w_rst, w_err, w_st = oracle.unpack(ans, data, dur, state=state)
+    assert len(nodes) == len(w_nodes)
+    if nodes.tobytes() != w_nodes.tobytes():
+        d = np.nonzero(nodes != w_nodes)[0]
+        raise AssertionError(f"ans {ans:#x}: {len(d)} nodes differ, first at {d[:4]}: "
+                             f"{nodes[d[:2]]} != {w_nodes[d[:2]]}")
+    assert list(rst) == list(w_rst)
+    assert err == w_err
+    assert st == w_st
+    return nodes, rst, st
+
+
+def test_decode_matches_genuine_golden(gpu):
+    """The kernels against what the GENUINE SDK unpackers published (tests/golden)."""
+    g = np.load(GOLD)
+    tags = sorted({k.split("__")[0] for k in g.files})
+    for t in tags:
+        ans, nf, seed, corrupt, dur, dense_last = (int(v) for v in g[t + "__meta"])
+        nodes, rst, err, _ = gpu.decode_stream(ans, g[t + "__bytes"], dur, (dense_last, 0))
+        assert nodes.tobytes() == g[t + "__nodes"].tobytes(), t
+        assert list(rst) == list(g[t + "__reset_at"]), t
+        assert err == int(g[t + "__n_err"]), t
+
+
+@pytest.mark.parametrize("ans", ALL_ANS)
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_decode_stream_matches_oracle(gpu, oracle, ans, corrupt):
+    for seed in range(6):
+        fpr = [12.3, 3.1, 40.0, 7.7, 300.0, 1.5][seed]
+        dur = [125, 125, 32, 20, 2, 1000000][seed]
+        payload = "random" if seed % 2 else "ring"
+        nf = 300 if ans != 0x81 else 3000
+        data = cp.make_stream(ans, nf, 40 + seed, corrupt=corrupt, payload=payload,
+                              frames_per_rev=fpr)
+        _check_stream(gpu, oracle, ans, data, dur, state=(seed & 1, 0))
+
+
+@pytest.mark.parametrize("ans", [0x85, 0x86])
+def test_decode_sync_filter_runs(gpu, oracle, ans):
+    """Long runs of raw sync bits (tiny angle steps around 0 deg, start angles above 360 deg)
+    and the carried-in sync bit: s_i = r_i & ~s_{i-1}."""
+    S = cp.FRAME_SIZE[ans]
+    o = 2 if ans == 0x85 else 8
+    for start_q6, step_q6 in ((0, 0), (0, 1), (23039, 1), (23030, 3), (32000, 5), (23040, 0)):
+        f = cp.make_frames(ans, 40, 9, payload="random", first_sync=False)
+        sa = ((start_q6 + step_q6 * np.arange(40)) % 32768).astype(np.uint16)
+        f[:, o] = sa & 0xFF
+        f[:, o + 1] = sa >> 8
+        cp._seal_capsules(f)
+        for init in (0, 1):
+            nodes, _, _ = _check_stream(gpu, oracle, ans, f.reshape(-1), 125, state=(init, 0))
+            assert len(nodes) == 39 * cp.NODES_PER_FRAME[ans]
+    assert S in (84, 170)
+
+
+def test_ultra_dense_smoothing_chains(gpu, oracle):
+    """Scale-0 distances built to smooth over long chains, break chains at every distance,
+    hit zero, and cross capsule boundaries (handler_capsules.cpp:997-1003)."""
+    rng = np.random.default_rng(5)
+    nfr = 60
+    f = cp.make_frames(0x86, nfr, 3, payload="random", first_sync=False)
+    walk = np.cumsum(rng.integers(-1, 2, nfr * 64)) + 500  # dist_q2 = 8 * walk: steps of 0 / 8
+    walk[rng.random(nfr * 64) < 0.05] += 40          # chain breaks
+    walk[rng.random(nfr * 64) < 0.03] = 0            # zeros
+    walk = np.clip(walk, 0, 0xFFC // 4).astype(np.uint32)
+    scale = np.where(rng.random(nfr * 64) < 0.1, rng.integers(1, 4, nfr * 64), 0).astype(np.uint32)
+    w = ((walk << 2) & 0xFFC) | scale | (rng.integers(0, 256, nfr * 64).astype(np.uint32) << 12)
+    w = w.reshape(nfr, 64)
+    e, o_ = w[:, 0::2], w[:, 1::2]
+    f[:, 10::5] = e & 0xFF
+    f[:, 11::5] = (e >> 8) & 0xFF
+    f[:, 12::5] = o_ & 0xFF
+    f[:, 13::5] = (o_ >> 8) & 0xFF
+    f[:, 14::5] = ((e >> 16) & 0xF) | (((o_ >> 16) & 0xF) << 4)
+    cp._seal_capsules(f)
+    for last in (0, 5, 8000, 8190):
+        _check_stream(gpu, oracle, 0x86, f.reshape(-1), 125, state=(0, last))
+
+
+def test_decode_state_carries_between_calls(gpu, oracle):
+    """Two calls on the halves of one dense / ultra-dense stream == the oracle run the same way
+    (the latch restarts at a call boundary; the sync / smoothing state is carried)."""
+    for ans in (0x85, 0x86):
+        S = cp.FRAME_SIZE[ans]
+        data = cp.make_stream(ans, 120, 77, payload="ring", frames_per_rev=9.7)
+        a, b_ = data[: 60 * S], data[60 * S:]
+        _, _, st = _check_stream(gpu, oracle, ans, a, 125, state=(0, 0))
+        _check_stream(gpu, oracle, ans, b_, 125, state=st)
+
+
+def test_decode_batch_dev_unframed_and_status(gpu, oracle):
+    """Device-resident batch: frames back to back (no offsets); a stream whose frames do not all
+    start with the sync pattern is flagged RPLGPU_STREAM_UNFRAMED and yields nothing."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    for ans in (0x82, 0x84, 0x85, 0x86, 0x83, 0x81):
+        S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
+        B, nf = 7, 90
+        streams = [cp.make_stream(ans, nf - 3 * b, 200 + b, payload="ring" if b % 2 else "random",
+                                  frames_per_rev=11.0 + b) for b in range(B)]
+        streams[4] = streams[4].copy()
+        streams[4][5 * S] ^= 0xF0 if ans != 0x81 else 0x01  # broken sync pattern in frame 5
+        stride = nf * S
+        buf = np.zeros((B, stride), np.uint8)
+        for b, s in enumerate(streams):
+            buf[b, : len(s)] = s
+        nfs = np.array([len(s) // S for s in streams], np.int32)
+        d_bytes = torch.from_numpy(buf).to(dev)
+        d_nf = torch.from_numpy(nfs).to(dev)
+        node_stride = nf * npf
+        d_nodes = torch.zeros(B, node_stride * 8, dtype=torch.uint8, device=dev)
+        d_nn = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_rst = torch.zeros(B, 16, dtype=torch.int32, device=dev)
+        d_nr = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_ne = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_state = torch.zeros(B, 2, dtype=torch.int32, device=dev)
+        gpu.decode_batch_dev(ans, 125, d_bytes.data_ptr(), stride, 0, 0, d_nf.data_ptr(), nf, B,
+                             0, d_state.data_ptr(), d_nodes.data_ptr(), node_stride,
+                             d_nn.data_ptr(), d_rst.data_ptr(), 16, d_nr.data_ptr(),
+                             d_ne.data_ptr(), d_st.data_ptr())
+        gpu.synchronize()
+        nn, st = d_nn.cpu().numpy(), d_st.cpu().numpy()
+        nodes = d_nodes.cpu().numpy().view(NODE_DTYPE).reshape(B, node_stride)
+        rst, nr = d_rst.cpu().numpy(), d_nr.cpu().numpy()
+        state = d_state.cpu().numpy()
+        for b in range(B):
+            if b == 4:
+                assert st[b] & abi_status("UNFRAMED") and nn[b] == 0
+                continue
+            want, w_rst, w_err, w_st = oracle.unpack(ans, streams[b], 125)
+            assert st[b] == 0 and nn[b] == len(want), (hex(ans), b)
+            assert nodes[b, : nn[b]].tobytes() == want.tobytes(), (hex(ans), b)
+            assert list(rst[b, : nr[b]]) == list(w_rst)
+            assert tuple(state[b]) == w_st
+
+
+def abi_status(name):
+    return {"UNFRAMED": 0x10, "FRAMES_TRUNCATED": 0x20, "RESETS_TRUNCATED": 0x40}[name]
+
+
+def test_segment_matches_oracle_and_golden(gpu, oracle):
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    g = np.load(GOLD)
+    tags = sorted({k.split("__")[0] for k in g.files})
+    cases = [(g[t + "__nodes"], g[t + "__reset_at"]) for t in tags]
+    # plus long synthetic node streams with many revolutions and resets
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        n = 20000
+        nd = np.zeros(n, NODE_DTYPE)
+        nd["dist_mm_q2"] = rng.integers(0, 1 << 20, n)
+        nd["angle_z_q14"] = rng.integers(0, 65536, n)
+        sync = rng.random(n) < 0.004
+        nd["flag"] = np.where(sync, 1, 2)
+        rs = np.unique(rng.integers(0, n + 1, 12)).astype(np.uint32)
+        cases.append((nd, rs))
+    B = len(cases)
+    node_stride = max(len(c[0]) for c in cases) + 8
+    rcap = max(len(c[1]) for c in cases) + 1
+    for max_count in (8192, 37, 1):
+        buf = np.zeros((B, node_stride), NODE_DTYPE)
+        rbuf = np.zeros((B, rcap), np.uint32)
+        nn = np.zeros(B, np.int32)
+        nr = np.zeros(B, np.int32)
+        for b, (nd, rs) in enumerate(cases):
+            buf[b, : len(nd)] = nd
+            rbuf[b, : len(rs)] = rs
+            nn[b], nr[b] = len(nd), len(rs)
+        scan_cap = 4096
+        d_nodes = torch.from_numpy(buf.view(np.uint8).reshape(B, -1)).to(dev)
+        d_out = torch.zeros_like(d_nodes)
+        d_nn, d_nr = torch.from_numpy(nn).to(dev), torch.from_numpy(nr).to(dev)
+        d_rst = torch.from_numpy(rbuf.view(np.int32)).to(dev)
+        d_off = torch.zeros(B, scan_cap + 1, dtype=torch.int32, device=dev)
+        d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+        gpu.segment_batch_dev(d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(),
+                              rcap, d_nr.data_ptr(), B, max_count, d_out.data_ptr(), node_stride,
+                              d_off.data_ptr(), scan_cap, d_ns.data_ptr(), d_st.data_ptr())
+        gpu.synchronize()
+        out = d_out.cpu().numpy().view(NODE_DTYPE).reshape(B, node_stride)
+        offs, ns = d_off.cpu().numpy(), d_ns.cpu().numpy()
+        assert np.all(d_st.cpu().numpy() == 0)
+        for b, (nd, rs) in enumerate(cases):
+            want, w_off = oracle.segment(nd, rs, max_count)
+            assert ns[b] == len(w_off) - 1, (b, max_count)
+            assert list(offs[b, : ns[b] + 1]) == list(w_off), (b, max_count)
+            assert out[b, : w_off[-1]].tobytes() == want.tobytes(), (b, max_count)
+
+
+def test_recorded_stream_to_laserscan_pipeline(gpu, oracle):
+    """Config-2-like end to end on the device: DenseBoost capsule streams -> decode -> scan
+    assembly -> scan batch -> ascendScanData -> publish_scan, equal to the oracle chain."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    ans, S, npf = 0x85, 84, 40
+    B, nf = 5, 400
+    streams = [cp.make_stream(ans, nf, 900 + b, payload="ring", frames_per_rev=20.0 + 3 * b)
+               for b in range(B)]
+    buf = np.stack(streams)
+    d_bytes = torch.from_numpy(buf).to(dev)
+    d_nf = torch.full((B,), nf, dtype=torch.int32, device=dev)
+    node_stride = nf * npf
+    d_nodes = torch.zeros(B, node_stride * 8, dtype=torch.uint8, device=dev)
+    d_seg = torch.zeros_like(d_nodes)
+    d_nn = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_rst = torch.zeros(B, 8, dtype=torch.int32, device=dev)
+    d_nr = torch.zeros(B, dtype=torch.int32, device=dev)
+    scan_cap, n_stride, max_scans = 64, 2048, 256
+    d_off = torch.zeros(B, scan_cap + 1, dtype=torch.int32, device=dev)
+    d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_base = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    d_batch = torch.zeros(max_scans, n_stride * 8, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(max_scans, dtype=torch.int32, device=dev)
+    gpu.decode_batch_dev(ans, 125, d_bytes.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0,
+                         d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8,
+                         d_nr.data_ptr())
+    gpu.segment_batch_dev(d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8,
+                          d_nr.data_ptr(), B, 8192, d_seg.data_ptr(), node_stride,
+                          d_off.data_ptr(), scan_cap, d_ns.data_ptr())
+    gpu.scans_to_batch_dev(d_seg.data_ptr(), node_stride, d_off.data_ptr(), scan_cap,
+                           d_ns.data_ptr(), B, d_base.data_ptr(), d_batch.data_ptr(), n_stride,
+                           max_scans, d_len.data_ptr())
+    gpu.synchronize()
+    total = int(d_base.cpu().numpy()[B])
+    assert 0 < total <= max_scans
+    d_status = torch.zeros(max_scans, dtype=torch.int32, device=dev)
+    gpu.ascend_batch_dev(d_batch.data_ptr(), n_stride, d_len.data_ptr(), total, d_status.data_ptr())
+    p = Params.defaults(range_max=40.0)
+    d_r = torch.zeros(total, n_stride, dtype=torch.float32, device=dev)
+    d_i = torch.zeros(total, n_stride, dtype=torch.float32, device=dev)
+    d_cnt = torch.zeros(total, dtype=torch.int32, device=dev)
+    gpu.laserscan_batch_dev(d_batch.data_ptr(), n_stride, d_len.data_ptr(), total, p,
+                            d_r.data_ptr(), d_i.data_ptr(), d_cnt.data_ptr())
+    gpu.synchronize()
+    lens = d_len.cpu().numpy()
+    r, i, cnt = d_r.cpu().numpy(), d_i.cpu().numpy(), d_cnt.cpu().numpy()
+    gidx = 0
+    for b in range(B):
+        nodes, rst, _, _ = oracle.unpack(ans, streams[b], 125)
+        scans, offs = oracle.segment(nodes, rst, 8192)
+        for s in range(len(offs) - 1):
+            scan = scans[offs[s]: offs[s + 1]]
+            assert lens[gidx] == len(scan)
+            asc, res = oracle.ascend(scan)
+            assert res == 0
+            wr, wi, wm = oracle.publish_scan(asc, oracle_lib.copy_params(p), 0.1)
+            assert cnt[gidx] == wm.count
+            assert r[gidx, : wm.count].tobytes() == wr.tobytes()
+            # equal (angle, dist) ties may carry either quality (documented tie rule)
+            assert np.count_nonzero(i[gidx, : wm.count] != wi) <= wm.count // 50
+            gidx += 1
+    assert gidx == total
