@@ -32,9 +32,26 @@
 namespace rpl {
 
 constexpr int kDecBlock = 256;
-constexpr uint32_t kDecMaxFrames = 4096;     // frames of one stream per call (LDS frame table)
+constexpr uint32_t kDecMaxFrames = 2048;     // frames of one stream per call (LDS frame table)
 constexpr uint32_t kUdMaxFrames = 512;       // ultra-dense: 64 nodes each -> 32768 LDS slots
-constexpr uint32_t kRawBitWords = 4096;      // u64 words of raw sync bits (262144 nodes)
+// LDS is sized per answer type so that several streams share a CU (a 32 000-sample DenseBoost
+// scan is 800 frames): dense 26 KiB, express / ultra / legacy 16 KiB, HQ 20 KiB, ultra-dense 72 KiB
+template <int ANS>
+struct DecCfg {
+  static constexpr bool kFiltered =
+      ANS == RPLGPU_ANS_DENSE_CAPSULED || ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
+  // legacy 5-byte nodes carry no inter-frame state and always publish: no frame table at all
+  static constexpr bool kTable = ANS != RPLGPU_ANS_MEASUREMENT;
+  static constexpr uint32_t kMaxFrames = !kTable ? 0x7FFFFFFFu
+                                         : ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? kUdMaxFrames
+                                                                                  : kDecMaxFrames;
+  static constexpr uint32_t kTableSlots = kTable ? kMaxFrames : 1u;
+  // u64 words of raw sync bits: one bit per node the stream can publish in one call
+  static constexpr uint32_t kRawBitWords =
+      !kFiltered ? 1u : ANS == RPLGPU_ANS_DENSE_CAPSULED ? kDecMaxFrames * 40u / 64u : kUdMaxFrames;
+  static constexpr uint32_t kSmoothSlots = ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? kUdMaxFrames * 64u : 1u;
+  static constexpr uint32_t kCrcWords = ANS == RPLGPU_ANS_HQ ? 1024u : 1u;
+};
 
 __device__ __forceinline__ uint32_t ld8(const uint8_t *p) { return p[0]; }
 __device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8); }
@@ -85,28 +102,37 @@ __device__ __forceinline__ uint32_t varbitscale(uint32_t scaled, uint32_t &lvl) 
   return scaled;
 }
 
-// CRC of handler_hqnode.cpp:124-126 / sl_crc.cpp:36-101: reflected CRC-32, zero padded by
-// 4 - (len & 3) bytes.  One thread per frame, table in LDS.
+// CRC of handler_hqnode.cpp:124-126 / sl_crc.cpp:36-101: reflected CRC-32, the data zero padded
+// by 4 - (len & 3) bytes -- so the padded length is always a multiple of four and the CRC can
+// be advanced a 32-bit word at a time (slicing-by-4: four independent table look-ups per word
+// instead of four dependent ones).  One thread per frame, tables (4 x 256 words) in LDS.
 __device__ __forceinline__ uint32_t crc32_padded(const uint8_t *p, uint32_t len,
-                                                 const uint32_t *table) {
+                                                 const uint32_t *t) {
   uint32_t crc = 0xFFFFFFFFu;
-  for (uint32_t i = 0; i < len; ++i) crc = (crc >> 8) ^ table[(crc ^ p[i]) & 0xFFu];
-  const uint32_t pad = 4u - (len & 3u);
-  for (uint32_t i = 0; i < pad; ++i) crc = (crc >> 8) ^ table[crc & 0xFFu];
+  const uint32_t full = len & ~3u;
+  for (uint32_t i = 0; i < full; i += 4u) {
+    crc ^= ld32(p + i);
+    crc = t[768u + (crc & 0xFFu)] ^ t[512u + ((crc >> 8) & 0xFFu)] ^ t[256u + ((crc >> 16) & 0xFFu)] ^
+          t[crc >> 24];
+  }
+  uint32_t tail = 0;  // the last 0..3 data bytes followed by the zero padding
+  for (uint32_t i = full; i < len; ++i) tail |= (uint32_t)p[i] << (8u * (i - full));
+  crc ^= tail;
+  crc = t[768u + (crc & 0xFFu)] ^ t[512u + ((crc >> 8) & 0xFFu)] ^ t[256u + ((crc >> 16) & 0xFFu)] ^
+        t[crc >> 24];
   return crc ^ 0xFFFFFFFFu;
 }
 
+template <int ANS>
 struct DecodeLds {
-  // per frame: bit31 valid, bit30 emits, bit29 reset request, bits 0..15 start_angle_sync_q6
-  uint32_t frame[kDecMaxFrames];
-  uint32_t emit_frame[kDecMaxFrames];  // compacted list of the frames that publish nodes
-  unsigned long long rawbits[kRawBitWords];  // dense / ultra-dense raw sync bits per node
+  // per frame: bit31 valid, bits 0..15 start_angle_sync_q6
+  uint32_t frame[DecCfg<ANS>::kTableSlots];
+  uint32_t emit_frame[DecCfg<ANS>::kTableSlots];  // compacted list of the frames that publish nodes
+  unsigned long long rawbits[DecCfg<ANS>::kRawBitWords];  // dense types: raw sync bit per node
+  uint16_t smooth[DecCfg<ANS>::kSmoothSlots];  // ultra-dense: bit15 scale 0, bits 0..13 raw dist_q2
+  uint32_t crc_table[DecCfg<ANS>::kCrcWords];  // HQ: slicing-by-4 tables
   uint32_t tmp[40];
-  uint32_t misc[8];  // 0 status, 1 n_emit, 2 n_reset
-  uint32_t crc_table[256];
-};
-struct UltraDenseLds {
-  uint16_t d[kUdMaxFrames * 64];  // bit15: scale 0; bits 0..13: raw (unsmoothed) dist_q2
+  uint32_t misc[8];  // 0 status, 3 last sync out, 4 last dist out, 5 error count
 };
 
 __device__ __forceinline__ uint32_t dec_block_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
@@ -140,15 +166,14 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
                         ANS == RPLGPU_ANS_DENSE_CAPSULED || ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
   constexpr bool FILTERED = ANS == RPLGPU_ANS_DENSE_CAPSULED || ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
   constexpr uint32_t SA_OFF = ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? 8u : 2u;
-  __shared__ DecodeLds L;
-  __shared__ UltraDenseLds U;  // only touched by the ultra-dense instantiation
+  __shared__ DecodeLds<ANS> L;
+  constexpr uint32_t kRawBitWords = DecCfg<ANS>::kRawBitWords;
 
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   const uint8_t *base = bytes + (size_t)b * stream_stride;
   const uint32_t *foff = frame_off ? frame_off + (size_t)b * max_frames : nullptr;
   const uint8_t *fgap = gap ? gap + (size_t)b * max_frames : nullptr;
-  const uint32_t nf = min(n_frames[b], min(max_frames, ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED
-                                                           ? kUdMaxFrames : kDecMaxFrames));
+  const uint32_t nf = min(n_frames[b], min(max_frames, DecCfg<ANS>::kMaxFrames));
   uint2 *out = nodes_out + (size_t)b * node_stride;
   auto frame_ptr = [&](uint32_t k) -> const uint8_t * {
     return base + (foff ? (size_t)foff[k] : (size_t)k * S);
@@ -160,19 +185,25 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
 #pragma unroll
     for (int j = 0; j < 8; ++j) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
     L.crc_table[tid] = c;
+    __syncthreads();
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {  // T_k[i] = T_{k-1}[i] advanced by one zero byte
+      c = (c >> 8) ^ L.crc_table[c & 0xFFu];
+      L.crc_table[256 * k + tid] = c;
+    }
   }
   if (n_frames[b] > nf && tid == 0) L.misc[0] = RPLGPU_STREAM_FRAMES_TRUNCATED;
   __syncthreads();
 
   // ---- P1: per frame: framing check (unframed input only), checksum, header word ---------
   uint32_t my_err = 0, unframed = 0;
-  for (uint32_t k = tid; k < nf; k += kDecBlock) {
+  for (uint32_t k = tid; k < nf && (DecCfg<ANS>::kTable || !foff); k += kDecBlock) {
     const uint8_t *f = frame_ptr(k);
     uint32_t rec = 0;
     if (ANS == RPLGPU_ANS_MEASUREMENT) {  // handler_normalnode.cpp:88-112
       const uint32_t b0 = ld8(f), b1 = ld8(f + 1);
       if (!foff && !((((b0 >> 1) ^ b0) & 1u) && (b1 & 1u))) unframed = 1;
-      rec = 0x80000000u;
+      continue;  // nothing to tabulate
     } else if (ANS == RPLGPU_ANS_HQ) {  // handler_hqnode.cpp:99-172
       if (!foff && ld8(f) != 0xA5u) unframed = 1;
       const bool ok = crc32_padded(f, S - 4u, L.crc_table) == ld32(f + S - 4u);
@@ -199,7 +230,8 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   const int thr_q8 = FILTERED ? (int)((360u * 100u * (ANS == RPLGPU_ANS_DENSE_CAPSULED ? 40u : 32u) /
                                        (1000000u / sample_duration_us)) << 8)
                               : 0;
-  for (uint32_t k0 = 0; k0 < nf && !bad_framing; k0 += kDecBlock) {
+  if (!DecCfg<ANS>::kTable && !bad_framing) carry_emit = nf;  // every legacy node publishes
+  for (uint32_t k0 = 0; k0 < nf && !bad_framing && DecCfg<ANS>::kTable; k0 += kDecBlock) {
     const uint32_t k = k0 + tid;
     uint32_t emits = 0, resets = 0;
     if (k < nf) {
@@ -247,7 +279,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     uint32_t raw_sync = 0;
     if (live) {
       const uint32_t e = i / NPF, pos = i - e * NPF;
-      const uint32_t k = L.emit_frame[e];
+      const uint32_t k = DecCfg<ANS>::kTable ? L.emit_frame[e] : e;
       if (ANS == RPLGPU_ANS_MEASUREMENT) {  // handler_normalnode.cpp:121-130
         const uint8_t *f = frame_ptr(k);
         const uint32_t b0 = ld8(f), aq = ld16(f + 1), d = ld16(f + 3);
@@ -335,7 +367,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
           // raw distance for the smoothing pass: scale 0 -> bit 15 + value (<= 8184);
           // other scales only matter as "last distance" of a scale-0 successor, whose rule
           // |d - last| <= 8 can hold only if last <= 8192: store min(dist, 0x3FFF)
-          U.d[i] = (uint16_t)(scale == 0u ? (0x8000u | dist) : min(dist, 0x3FFFu));
+          L.smooth[i] = (uint16_t)(scale == 0u ? (0x8000u | dist) : min(dist, 0x3FFFu));
         }
       }
     }
@@ -383,49 +415,95 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     if (carry_nodes) last_sync_out = (int)L.misc[3];
   }
 
-  // ---- P5 (ultra-dense): distance smoothing along scale-0 chains (:997-1003, :1020) --------
+  // ---- P5 (ultra-dense): distance smoothing (:997-1003, :1020) -------------------------------
+  // out_i = smooth(d_i, out_{i-1}) is a recurrence, but a smoothed value stays within +-4 of its
+  // raw value, so "out_{i-1} - d_{i-1} + 4" is one of 9 states and every node is a map from
+  // the 9 states of its predecessor to its own 9 states (36 bits).  Maps compose associatively:
+  // each thread folds a contiguous segment of the stream into one map (tracking all 9 inputs),
+  // a block scan composes the segment maps, and a second walk with the now known entry state
+  // writes the smoothed distances.  Exact for any input, O(n / 256) steps per thread.
   if (ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED && carry_nodes) {
     __syncthreads();
-    auto rawd = [&](uint32_t i) -> int { return (int)(U.d[i] & 0x3FFFu); };
-    auto is_s0 = [&](uint32_t i) -> bool { return (U.d[i] & 0x8000u) != 0u; };
-    for (uint32_t i = tid; i < carry_nodes; i += kDecBlock) {
-      if (!is_s0(i)) continue;
-      // head of a chain: its predecessor's FINAL value is known without smoothing history
-      int last;
-      bool head;
-      if (i == 0u) { head = true; last = last_dist_in; }
-      else if (!is_s0(i - 1u)) {
-        head = true;
-        last = rawd(i - 1u);
-        // a non-scale-0 predecessor above 0x3FFF was clamped: anything > 8192 + 8 behaves alike
-      } else {
-        const int dd = rawd(i) - rawd(i - 1u);
-        head = (dd > 12 || dd < -12);
-        last = rawd(i - 1u);  // irrelevant when head: |d - final(i-1)| > 8 whatever final is
-        if (head) last = 0;   // "no smoothing" is what happens; 0 disables the rule
+    auto rawd = [&](uint32_t i) -> int { return (int)(L.smooth[i] & 0x3FFFu); };
+    auto is_s0 = [&](uint32_t i) -> bool { return (L.smooth[i] & 0x8000u) != 0u; };
+    // state of node i given the value `last` its predecessor left behind
+    auto step = [&](uint32_t i, int last) -> int {
+      if (!is_s0(i)) return 4;
+      const int d = rawd(i);
+      int ad = d - last;
+      if (ad < 0) ad = -ad;
+      if (last != 0 && ad <= 8) return ((d + last) >> 1) - d + 4;
+      return 4;
+    };
+    constexpr unsigned long long kIdent = 0x876543210ull;
+    auto compose = [](unsigned long long first, unsigned long long then) -> unsigned long long {
+      unsigned long long r = 0;
+#pragma unroll
+      for (int sidx = 0; sidx < 9; ++sidx) {
+        const uint32_t mid = (uint32_t)(first >> (4 * sidx)) & 15u;
+        r |= ((then >> (4u * mid)) & 15ull) << (4 * sidx);
       }
-      if (!head) continue;
-      uint32_t jn = i;
-      while (true) {  // walk the chain
-        int d = rawd(jn);
-        if (last) {
-          int ad = d - last;
-          if (ad < 0) ad = -ad;
-          if (ad <= 8) d = (d + last) >> 1;
+      return r;
+    };
+    const uint32_t N = carry_nodes;
+    const uint32_t seg = (N + kDecBlock - 1u) / kDecBlock;
+    const uint32_t i_lo = min(tid * seg, N), i_hi = min(i_lo + seg, N);
+    // pass A: the segment as one map (all 9 entry states at once; they usually collapse fast)
+    unsigned long long M = kIdent;
+    if (i_lo < i_hi) {
+      int cur[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) cur[c] = c;
+      for (uint32_t i = i_lo; i < i_hi; ++i) {
+        if (i == 0u) {
+          const int st0 = step(0u, last_dist_in);
+#pragma unroll
+          for (int c = 0; c < 9; ++c) cur[c] = st0;
+        } else {
+          const int pd = rawd(i - 1u);
+#pragma unroll
+          for (int c = 0; c < 9; ++c) cur[c] = step(i, pd + cur[c] - 4);
         }
-        if (d != rawd(jn) && jn < n_out) {  // patch dist_mm_q2 (bits 16.. of the packed node)
-          uint2 v = out[jn];
-          v.x = (v.x & 0xFFFFu) | ((uint32_t)d << 16);
-          v.y = (v.y & 0xFFFF0000u) | ((uint32_t)d >> 16);
-          out[jn] = v;
-        }
-        last = d;
-        if (jn == carry_nodes - 1u) L.misc[4] = (uint32_t)d | 0x80000000u;
-        ++jn;
-        if (jn >= carry_nodes || !is_s0(jn)) break;
-        const int dd = rawd(jn) - rawd(jn - 1u);
-        if (dd > 12 || dd < -12) break;  // next node is a head of its own
       }
+      M = 0;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) M |= (unsigned long long)(uint32_t)cur[c] << (4 * c);
+    }
+    // pass B: exclusive scan of the maps over the block (composition, earlier segment first)
+    unsigned long long inc = M;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d, 64);
+      const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d, 64);
+      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+      if ((int)lane_id() >= d) inc = compose(other, inc);
+    }
+    if (lane_id() == 63) L.rawbits[wave_id()] = inc;  // (the sync bits are no longer needed)
+    __syncthreads();
+    unsigned long long before = kIdent;  // everything in front of this wave
+    for (uint32_t w = 0; w < wave_id(); ++w) before = compose(before, L.rawbits[w]);
+    unsigned long long excl;
+    {
+      const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, 1, 64);
+      const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), 1, 64);
+      excl = lane_id() == 0 ? kIdent : (((unsigned long long)hi << 32) | lo);
+    }
+    excl = compose(before, excl);
+    // every map in front of a non-empty segment starts with node 0's constant map, so any
+    // entry state (take 4) gives the state its predecessor node really has
+    int sp = (int)((excl >> (4 * 4)) & 15ull);
+    // pass C: the walk with the true entry state
+    for (uint32_t i = i_lo; i < i_hi; ++i) {
+      const int last = (i == 0u) ? last_dist_in : rawd(i - 1u) + sp - 4;
+      sp = step(i, last);
+      if (sp != 4 && i < n_out) {  // patch dist_mm_q2 (bits 16.. of the packed node)
+        const uint32_t d = (uint32_t)(rawd(i) + sp - 4);
+        uint2 v = out[i];
+        v.x = (v.x & 0xFFFFu) | (d << 16);
+        v.y = (v.y & 0xFFFF0000u) | (d >> 16);
+        out[i] = v;
+      }
+      if (i == N - 1u && is_s0(i)) L.misc[4] = (uint32_t)(rawd(i) + sp - 4) | 0x80000000u;
     }
     __syncthreads();
     if (L.misc[4] & 0x80000000u) {
@@ -645,7 +723,9 @@ hipError_t launch_scans_to_batch(hipStream_t s, const void *seg_nodes, uint32_t 
 }
 
 uint32_t decode_max_frames(int ans) {
-  return ans == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? kUdMaxFrames : kDecMaxFrames;
+  return ans == RPLGPU_ANS_MEASUREMENT            ? 0x7FFFFFFFu
+         : ans == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? kUdMaxFrames
+                                                  : kDecMaxFrames;
 }
 
 }  // namespace rpl

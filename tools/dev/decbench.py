@@ -1,0 +1,48 @@
+"""Developer aid: throughput of the decode stage (k_decode / k_segment / k_scans_to_batch)."""
+import sys, time
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from rplidar_ros2_driver_amd import RplGpu, capsules as cp
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+dev = torch.device("cuda:0")
+gpu = RplGpu(0, 32768, 16)
+st = torch.cuda.Stream(); torch.cuda.set_stream(st); gpu.set_stream(st.cuda_stream)
+for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334), (0x81, 4000)):
+    S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
+    uniq = 16
+    base = np.stack([cp.make_stream(ans, nf, 10 + s, payload="ring", frames_per_rev=nf / 1.0 - 0.7) for s in range(uniq)])
+    buf = torch.from_numpy(base).to(dev).repeat((B + uniq - 1) // uniq, 1)[:B].contiguous()
+    d_nf = torch.full((B,), nf, dtype=torch.int32, device=dev)
+    node_stride = nf * npf
+    d_nodes = torch.empty(B, node_stride * 8, dtype=torch.uint8, device=dev)
+    d_nn = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_rst = torch.zeros(B, 8, dtype=torch.int32, device=dev)
+    d_nr = torch.zeros(B, dtype=torch.int32, device=dev)
+    def run():
+        gpu.decode_batch_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0,
+                             d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8, d_nr.data_ptr())
+    run(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st); run(); b.record(st); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    nodes = int(d_nn.sum().item())
+    t = min(ts)
+    print(f"ans {ans:#x}: {nodes/1e6:.1f} Mnodes in {t:.3f} ms -> {nodes/t/1e6:.1f} Gnodes/s, "
+          f"in {B*nf*S/1e6:.0f} MB out {nodes*8/1e6:.0f} MB -> {(B*nf*S+nodes*8)/t/1e6:.0f} GB/s")
+    if ans == 0x85:
+        d_seg = torch.empty_like(d_nodes)
+        scan_cap = 8
+        d_off = torch.zeros(B, scan_cap + 1, dtype=torch.int32, device=dev)
+        d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
+        def seg():
+            gpu.segment_batch_dev(d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8,
+                                  d_nr.data_ptr(), B, 32768, d_seg.data_ptr(), node_stride, d_off.data_ptr(), scan_cap, d_ns.data_ptr())
+        seg(); torch.cuda.synchronize(); ts = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st); seg(); b.record(st); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+        print(f"  segment: {min(ts):.3f} ms, scans {int(d_ns.sum().item())}")
+    del buf, d_nodes
