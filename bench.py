@@ -60,6 +60,8 @@ def parse_args():
                     help="target wall time of the CPU baseline sample (0 disables)")
     ap.add_argument("--no-laserscan", action="store_true",
                     help="skip the secondary ascend+LaserScan measurement")
+    ap.add_argument("--no-decode", action="store_true",
+                    help="skip the secondary decode-stage measurement (capsules -> nodes -> scans)")
     return ap.parse_args()
 
 
@@ -122,6 +124,77 @@ def cpu_baseline(batch_np, lens_np, params, target_s):
         "reference_path_ascend_mpts": round(nscans * n / t_asc / 1e6, 1),
         "reference_path_laserscan_mpts": round(nscans * n / t_ls / 1e6, 1),
     }
+
+
+def decode_stage(gpu, dev, stream, cpu_seconds):
+    """Secondary measurement (not `value`): the step before the path, SURVEY.md §8(f) rows 1-2.
+    4096 recorded DenseBoost capsule streams (801 frames = 32 000 samples each, resident in HBM)
+    -> k_decode -> k_segment, plus the CPU oracle restatement of the SDK unpacker on one core."""
+    import torch
+
+    from rplidar_ros2_driver_amd import capsules as cp
+
+    ans, nf, B = cp.ANS_DENSE_CAPSULED, 801, 4096
+    S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
+    uniq = 32  # distinct streams (host generation time); the batch repeats them
+    # two revolutions per stream so that scan assembly has one complete scan to cut out
+    base = np.stack([cp.make_stream(ans, nf, 10 + s, payload="ring", frames_per_rev=nf / 2.0 + 0.3)
+                     for s in range(uniq)])
+    buf = torch.from_numpy(base).to(dev).repeat(B // uniq, 1).contiguous()
+    d_nf = torch.full((B,), nf, dtype=torch.int32, device=dev)
+    node_stride = nf * npf
+    d_nodes = torch.empty(B, node_stride * 8, dtype=torch.uint8, device=dev)
+    d_seg = torch.empty_like(d_nodes)
+    d_nn = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_rst = torch.zeros(B, 8, dtype=torch.int32, device=dev)
+    d_nr = torch.zeros(B, dtype=torch.int32, device=dev)
+    scan_cap = 8
+    d_off = torch.zeros(B, scan_cap + 1, dtype=torch.int32, device=dev)
+    d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def dec():
+        gpu.decode_batch_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0,
+                             d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8,
+                             d_nr.data_ptr())
+
+    def seg():
+        gpu.segment_batch_dev(d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(),
+                              8, d_nr.data_ptr(), B, 32768, d_seg.data_ptr(), node_stride,
+                              d_off.data_ptr(), scan_cap, d_ns.data_ptr())
+
+    res = {}
+    for name, fn in (("decode", dec), ("segment", seg)):
+        fn()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            fn()
+            b.record(stream)
+            torch.cuda.synchronize(dev)
+            ts.append(a.elapsed_time(b))
+        res[name] = min(ts)
+    nodes = int(d_nn.sum().item())
+    out = {
+        "decode_dense_ms": round(res["decode"], 4),
+        "decode_dense_mnodes": round(nodes / res["decode"] / 1e3, 1),
+        "decode_dense_gbs": round((B * nf * S + 8 * nodes) / res["decode"] / 1e6, 1),
+        "segment_ms": round(res["segment"], 4),
+        "segment_scans": int(d_ns.sum().item()),
+    }
+    if cpu_seconds > 0:  # the oracle restatement of the SDK unpacker, one core, one stream
+        from tests import oracle_lib
+
+        orc = oracle_lib.load_oracle()
+        orc.unpack(ans, base[0], 125)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < min(cpu_seconds, 2.0):
+            orc.unpack(ans, base[reps % uniq], 125)
+            reps += 1
+        out["decode_dense_cpu1_mnodes"] = round(reps * (nf - 1) * npf / (time.perf_counter() - t0) / 1e6, 1)
+    return out
 
 
 def main():
@@ -271,6 +344,9 @@ def main():
             "laserscan_mpts": round(B * n / res["laserscan"] / 1e3, 1),
         }
         del d_nodes2, d_r, d_i
+
+    if not args.no_decode and rank == 0:
+        extra.update(decode_stage(gpu, dev, stream, args.cpu_seconds))
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
