@@ -6,6 +6,7 @@ Only what the hot path needs lives here:
 * ``lib/``       the built ``librplgpu.so`` (git-ignored, built by ``__graft_entry__.build()``)
 * ``abi.py``     thin ctypes binding over that ABI (no torch types cross it)
 * ``synth.py``   deterministic synthetic raw-scan generators (bench / tests input)
+* ``capsules.py`` deterministic synthetic recorded answer streams (encoder for the decode stage)
 * ``sharding.py`` scan-index sharding + all-gather of the filtered clouds (RCCL / gloo)
 * ``host/``      C++ mirror of the reference call sites (publish_scan / grab_scan_data)
 
