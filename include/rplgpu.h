@@ -181,9 +181,12 @@ size_t rplgpu_frame_stream(uint8_t ans_type, const uint8_t *bytes, size_t nbytes
  * offsets d_frame_off[b*max_frames + k] (NULL: back to back, k*frame_size — then every frame
  * must start with its sync pattern or the stream gets RPLGPU_STREAM_UNFRAMED and no output);
  * d_gap optional (same shape).  sample_duration_us: SlamtecLidarTimingDesc::sample_duration_uS
- * (1..1000000; dense / ultra-dense discard threshold).  d_state_in/out (optional, 2 x int32 per
- * stream): {last sync bit, last dist_q2} carried between calls on the same stream (the
- * reference keeps them in a function-level static / members).  Outputs per stream: nodes at
+ * (1..1000000; dense / ultra-dense discard threshold).  d_state_in/out (optional, 4 x int32 per
+ * stream): {last sync bit, last dist_q2, flags, reserved} carried between calls on the same
+ * stream (the reference keeps the first two in a function-level static / members).  flags bit 0
+ * (input only): frame 0 of this call is the previous call's last frame, passed again only as
+ * the predecessor of frame 1 — this is how a recording longer than rplgpu_decode_max_frames is
+ * cut without losing the capsule at the cut.  Outputs per stream: nodes at
  * d_nodes + b*node_stride, d_n_nodes[b]; d_reset_at[b*reset_stride + i] = number of nodes
  * published before the i-th scan-reset request, d_n_reset[b]; d_n_errors[b] checksum / CRC
  * failures; d_status[b]. */
@@ -213,10 +216,12 @@ int32_t rplgpu_scans_to_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_seg_
                                   uint32_t scan_cap, const uint32_t *d_n_scans, uint32_t B,
                                   uint32_t *d_scan_base, rplgpu_node_t *d_batch, uint32_t n_stride,
                                   uint32_t max_scans, uint32_t *d_n_per_scan);
-/* One stream, HOST buffers: framing + decode (+ state carried in the handle per answer type is
- * NOT kept: pass state in/out explicitly).  nodes: cap entries; reset_at: reset_cap entries. */
+/* One stream of any length, HOST buffers: framing on the host, decode on the GPU in pieces of
+ * rplgpu_decode_max_frames frames (overlapping by one frame, see flags bit 0).  No state is kept
+ * in the handle: pass state in/out explicitly ({0,0,0,0} for a fresh unpacker).  nodes: cap
+ * entries; reset_at: reset_cap entries (node positions in the whole output). */
 int32_t rplgpu_decode_stream(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
-                             const uint8_t *bytes, size_t nbytes, int32_t state[2],
+                             const uint8_t *bytes, size_t nbytes, int32_t state[4],
                              rplgpu_node_t *nodes, size_t cap, size_t *n_nodes,
                              uint32_t *reset_at, size_t reset_cap, size_t *n_reset,
                              uint32_t *n_errors);

@@ -302,7 +302,8 @@ class RplGpu:
         cap = (len(data) // max(S, 1) + 1) * npf
         nodes = np.zeros(max(cap, 1), NODE_DTYPE)
         rst = np.zeros(len(data) // max(S, 1) + 2, np.uint32)
-        st = np.array(state, np.int32)
+        st = np.zeros(4, np.int32)
+        st[: len(state)] = state
         n, nr, ne = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0)
         self._check(self._lib.rplgpu_decode_stream(
             self._h, ans_type, sample_duration_us, data.ctypes.data, len(data), st.ctypes.data,

@@ -179,6 +179,9 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     return base + (foff ? (size_t)foff[k] : (size_t)k * S);
   };
 
+  // state word 2, bit 0: frame 0 is the previous call's last frame, handed over again only as
+  // the predecessor of frame 1 (its errors / reset request / nodes were accounted for then)
+  const bool carry0 = CAPS && state_in && (state_in[4 * b + 2] & 1);
   if (tid < 8) L.misc[tid] = 0u;
   if (ANS == RPLGPU_ANS_HQ) {
     uint32_t c = tid;  // kDecBlock == 256 table entries
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       uint32_t x = 0;
       for (uint32_t i = 2; i < S; ++i) x ^= f[i];
       const bool ok = (((b0 & 0xFu) | (b1 << 4)) & 0xFFu) == x;
-      my_err += ok ? 0u : 1u;
+      my_err += (ok || (carry0 && k == 0u)) ? 0u : 1u;
       rec = (ok ? 0x80000000u : 0u) | ld16(f + SA_OFF);
     }
     L.frame[k] = rec;
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
         emits = rec >> 31;
       } else if (rec >> 31) {
         resets = (rec >> 15) & 1u;  // revolution start: publishNewScanReset (:160-171)
+        if (carry0 && k == 0u) resets = 0u;
         const bool prev_ok = k > 0 && (L.frame[k - 1] >> 31) && !(fgap && fgap[k]);
         if (prev_ok && !resets) {
           emits = 1;
@@ -270,8 +274,8 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   const uint32_t n_out = min(carry_nodes, node_stride);
 
   // ---- P3: the nodes ----------------------------------------------------------------------
-  const int last_sync_in = state_in ? state_in[2 * b] : 0;
-  const int last_dist_in = state_in ? state_in[2 * b + 1] : 0;
+  const int last_sync_in = state_in ? state_in[4 * b] : 0;
+  const int last_dist_in = state_in ? state_in[4 * b + 1] : 0;
   for (uint32_t i0 = 0; i0 < carry_nodes; i0 += kDecBlock) {
     const uint32_t i = i0 + tid;
     const bool live = i < carry_nodes;
@@ -536,8 +540,10 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     if (n_errors) n_errors[b] = L.misc[5];
     if (status) status[b] = st;
     if (state_out) {
-      state_out[2 * b] = bad_framing ? last_sync_in : last_sync_out;
-      state_out[2 * b + 1] = bad_framing ? last_dist_in : last_dist_out;
+      state_out[4 * b] = bad_framing ? last_sync_in : last_sync_out;
+      state_out[4 * b + 1] = bad_framing ? last_dist_in : last_dist_out;
+      state_out[4 * b + 2] = 0;
+      state_out[4 * b + 3] = 0;
     }
   }
   (void)n_emit;

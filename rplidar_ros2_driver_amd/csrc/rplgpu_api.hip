@@ -6,6 +6,7 @@
 // fallback: if no gfx950 device is usable, rplgpu_create fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -685,7 +686,7 @@ int32_t rplgpu_scans_to_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_seg_
 }
 
 int32_t rplgpu_decode_stream(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
-                             const uint8_t *bytes, size_t nbytes, int32_t state[2],
+                             const uint8_t *bytes, size_t nbytes, int32_t state[4],
                              rplgpu_node_t *nodes, size_t cap, size_t *n_nodes,
                              uint32_t *reset_at, size_t reset_cap, size_t *n_reset,
                              uint32_t *n_errors) {
@@ -701,21 +702,19 @@ int32_t rplgpu_decode_stream(rplgpu_handle_t h, uint8_t ans_type, uint32_t sampl
   std::vector<uint8_t> gap(max_f ? max_f : 1);
   const size_t nf = rplgpu_frame_stream(ans_type, bytes, nbytes, off.data(), gap.data(), max_f);
   if (nf == 0) return RPLGPU_OK;
-  if (nf > rpl::decode_max_frames(ans_type)) return RPLGPU_ERR_CAPACITY;
   RPL_HIP(h, hipSetDevice(h->device));
+  const bool caps = ans_type != RPLGPU_ANS_MEASUREMENT && ans_type != RPLGPU_ANS_HQ;
+  const size_t piece = std::min<size_t>(nf, rpl::decode_max_frames(ans_type));
   // one-off device staging (this entry point is the convenience path; batches use *_batch_dev)
-  const size_t node_cap = nf * npf, rcap = nf + 1;
-  const size_t sz_bytes = (nbytes + 15) & ~size_t(15), sz_off = nf * 4, sz_gap = (nf + 15) & ~size_t(15);
-  const size_t sz_nodes = node_cap * 8, sz_rst = rcap * 4, sz_small = 64;
+  const size_t node_cap = piece * npf, rcap = piece + 1;
+  const size_t sz_bytes = (nbytes + 15) & ~size_t(15), sz_off = piece * 4, sz_gap = (piece + 15) & ~size_t(15);
+  const size_t sz_nodes = node_cap * 8, sz_rst = rcap * 4, sz_small = 128;
   unsigned char *d = nullptr;
   RPL_HIP(h, hipMalloc(&d, sz_bytes + sz_off + sz_gap + sz_nodes + sz_rst + sz_small));
   unsigned char *d_b = d, *d_off = d_b + sz_bytes, *d_gap = d_off + sz_off;
   unsigned char *d_nodes = d_gap + sz_gap, *d_rst = d_nodes + sz_nodes, *d_small = d_rst + sz_rst;
-  // d_small: [0] n_frames [1] n_nodes [2] n_reset [3] n_err [4] status [5,6] state in [7,8] state out
-  uint32_t small[16] = {0};
-  small[0] = (uint32_t)nf;
-  small[5] = state ? (uint32_t)state[0] : 0u;
-  small[6] = state ? (uint32_t)state[1] : 0u;
+  // d_small (u32): [0] n_frames [1] n_nodes [2] n_reset [3] n_err [4] status
+  //                [8..11] state in, [12..15] state out
   int32_t rc = RPLGPU_OK;
   auto fail = [&](hipError_t e, const char *what) {
     h->err = std::string(what) + ": " + hipGetErrorString(e);
@@ -723,36 +722,63 @@ int32_t rplgpu_decode_stream(rplgpu_handle_t h, uint8_t ans_type, uint32_t sampl
   };
   hipError_t e;
   if ((e = hipMemcpyAsync(d_b, bytes, nbytes, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy bytes");
-  if (!rc && (e = hipMemcpyAsync(d_off, off.data(), sz_off, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy offsets");
-  if (!rc && (e = hipMemcpyAsync(d_gap, gap.data(), nf, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy gaps");
-  if (!rc && (e = hipMemcpyAsync(d_small, small, sz_small, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy small");
-  if (!rc) {
+  int32_t st[4] = {state ? state[0] : 0, state ? state[1] : 0, 0, 0};
+  size_t done_nodes = 0, done_resets = 0, errs = 0;
+  std::vector<uint32_t> rst_host(rcap);
+  // pieces of at most `piece` frames; a capsule piece after the first starts one frame early
+  // (flags bit 0: that frame only serves as the predecessor of the next one)
+  for (size_t first = 0; first < nf && !rc;) {
+    const bool overlap = caps && first > 0;
+    const size_t lo = overlap ? first - 1 : first;
+    const size_t cnt = std::min(piece, nf - lo);
+    uint32_t small[32] = {0};
+    small[0] = (uint32_t)cnt;
+    small[8] = (uint32_t)st[0];
+    small[9] = (uint32_t)st[1];
+    small[10] = overlap ? 1u : 0u;
+    if ((e = hipMemcpyAsync(d_off, off.data() + lo, cnt * 4, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy offsets");
+    if (!rc && (e = hipMemcpyAsync(d_gap, gap.data() + lo, cnt, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy gaps");
+    if (!rc && (e = hipMemcpyAsync(d_small, small, sz_small, hipMemcpyHostToDevice, h->stream)) != hipSuccess) fail(e, "copy small");
+    if (rc) break;
     uint32_t *ds = reinterpret_cast<uint32_t *>(d_small);
     rc = rplgpu_decode_batch_dev(h, ans_type, sample_duration_us, d_b, 0,
-                                 reinterpret_cast<uint32_t *>(d_off), d_gap, ds, (uint32_t)nf, 1,
-                                 reinterpret_cast<int32_t *>(ds + 5), reinterpret_cast<int32_t *>(ds + 7),
+                                 reinterpret_cast<uint32_t *>(d_off), d_gap, ds, (uint32_t)cnt, 1,
+                                 reinterpret_cast<int32_t *>(ds + 8), reinterpret_cast<int32_t *>(ds + 12),
                                  reinterpret_cast<rplgpu_node_t *>(d_nodes), (uint32_t)node_cap, ds + 1,
                                  reinterpret_cast<uint32_t *>(d_rst), (uint32_t)rcap, ds + 2, ds + 3, ds + 4);
-  }
-  if (!rc && (e = hipMemcpyAsync(small, d_small, sz_small, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) fail(e, "copy back");
-  if (!rc && (e = hipStreamSynchronize(h->stream)) != hipSuccess) fail(e, "sync");
-  if (!rc) {
+    if (rc) break;
+    if ((e = hipMemcpyAsync(small, d_small, sz_small, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) { fail(e, "copy back"); break; }
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) { fail(e, "sync"); break; }
     const size_t got = small[1], nr = small[2];
-    *n_nodes = got;
-    if (n_reset) *n_reset = nr;
-    if (n_errors) *n_errors = small[3];
-    if (state) {
-      state[0] = (int32_t)small[7];
-      state[1] = (int32_t)small[8];
+    errs += small[3];
+    st[0] = (int32_t)small[12];
+    st[1] = (int32_t)small[13];
+    if (got && done_nodes < cap) {
+      const size_t ncopy = std::min(got, cap - done_nodes);
+      if ((e = hipMemcpy(nodes + done_nodes, d_nodes, ncopy * 8, hipMemcpyDeviceToHost)) != hipSuccess) { fail(e, "copy nodes"); break; }
     }
-    const size_t ncopy = got < cap ? got : cap, rcopy = nr < reset_cap ? nr : reset_cap;
-    if (ncopy && (e = hipMemcpy(nodes, d_nodes, ncopy * 8, hipMemcpyDeviceToHost)) != hipSuccess) fail(e, "copy nodes");
-    if (!rc && rcopy && reset_at &&
-        (e = hipMemcpy(reset_at, d_rst, rcopy * 4, hipMemcpyDeviceToHost)) != hipSuccess)
-      fail(e, "copy resets");
+    if (nr) {
+      if ((e = hipMemcpy(rst_host.data(), d_rst, nr * 4, hipMemcpyDeviceToHost)) != hipSuccess) { fail(e, "copy resets"); break; }
+      for (size_t i = 0; i < nr; ++i) {
+        if (reset_at && done_resets < reset_cap) reset_at[done_resets] = (uint32_t)(rst_host[i] + done_nodes);
+        ++done_resets;
+      }
+    }
+    done_nodes += got;
+    first = lo + cnt;
   }
   (void)hipFree(d);
-  return rc;
+  if (rc) return rc;
+  *n_nodes = done_nodes;
+  if (n_reset) *n_reset = done_resets;
+  if (n_errors) *n_errors = (uint32_t)errs;
+  if (state) {
+    state[0] = st[0];
+    state[1] = st[1];
+    state[2] = 0;
+    state[3] = 0;
+  }
+  return RPLGPU_OK;
 }
 
 }  // extern "C"
