@@ -6,10 +6,14 @@
 //   host_selftest <nodes.bin> <out.bin> <is_new> <inverted> <scan_processing> <ascend 0|1> <cloud 0|1|2>
 //   out.bin: u32 published, 7 x f32 meta, u32 count, ranges[count], intensities[count],
 //            u32 sl_result, u32 n_points, xyzi[4*n_points]
+//   host_selftest replay <ans_type> <sample_duration_us> <stream.bin> <out.bin>
+//   out.bin: u32 n_nodes, u32 n_reset_calls, u32 n_err, u32 n_scans, nodes[n_nodes],
+//            reset positions, then per scan: u32 len, nodes[len]   (replay_recording + ScanAssembler)
 //   no arguments: config-1 smoke run (3 Dummy scans through the whole path).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <type_traits>
 #include <vector>
 
@@ -42,6 +46,57 @@ int main(int argc, char **argv) {
   if (!path.configure(0, 32768)) {
     std::fprintf(stderr, "configure failed: %s\n", path.last_error().c_str());
     return 2;
+  }
+  if (argc == 6 && std::string(argv[1]) == "replay") {
+    struct Recorder {  // what SlamtecLidarDriver's listener would see, plus the scan assembly
+      std::vector<rplgpu_node_t> nodes;
+      std::vector<uint32_t> resets;
+      std::vector<std::vector<rplgpu_node_t>> scans;
+    } rec;
+    auto on_scan = [&](std::vector<rplgpu_node_t> &s) { rec.scans.push_back(s); };
+    rplgpu_host::ScanAssembler<decltype(on_scan)> assembler(on_scan, 8192);
+    struct Tee {
+      Recorder &r;
+      rplgpu_host::ScanAssembler<decltype(on_scan)> &a;
+      void onHQNodeScanResetReq() {
+        r.resets.push_back(static_cast<uint32_t>(r.nodes.size()));
+        a.onHQNodeScanResetReq();
+      }
+      void onHQNodeDecoded(unsigned long long ts, const rplgpu_node_t *n) {
+        r.nodes.push_back(*n);
+        a.onHQNodeDecoded(ts, n);
+      }
+    } tee{rec, assembler};
+    std::FILE *f = std::fopen(argv[4], "rb");
+    if (!f) return 4;
+    std::fseek(f, 0, SEEK_END);
+    const long nb = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> bytes(static_cast<size_t>(nb));
+    if (nb && std::fread(bytes.data(), 1, bytes.size(), f) != bytes.size()) return 4;
+    std::fclose(f);
+    int32_t state[4] = {0, 0, 0, 0};
+    uint32_t n_err = 0;
+    if (!path.replay_recording(static_cast<uint8_t>(std::strtoul(argv[2], nullptr, 0)),
+                               static_cast<uint32_t>(std::atoi(argv[3])), bytes.data(), bytes.size(),
+                               tee, state, &n_err)) {
+      std::fprintf(stderr, "replay failed: %s\n", path.last_error().c_str());
+      return 5;
+    }
+    std::FILE *o = std::fopen(argv[5], "wb");
+    if (!o) return 6;
+    const uint32_t hdr[4] = {static_cast<uint32_t>(rec.nodes.size()), static_cast<uint32_t>(rec.resets.size()),
+                             n_err, static_cast<uint32_t>(rec.scans.size())};
+    std::fwrite(hdr, 4, 4, o);
+    std::fwrite(rec.nodes.data(), 8, rec.nodes.size(), o);
+    std::fwrite(rec.resets.data(), 4, rec.resets.size(), o);
+    for (auto &s : rec.scans) {
+      const uint32_t len = static_cast<uint32_t>(s.size());
+      std::fwrite(&len, 4, 1, o);
+      std::fwrite(s.data(), 8, s.size(), o);
+    }
+    std::fclose(o);
+    return 0;
   }
   if (argc < 8) {
     float phase = 0.0f;

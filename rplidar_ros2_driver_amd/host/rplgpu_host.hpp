@@ -9,6 +9,11 @@
 //            but not including, scan_pub_->publish(scan_msg) at :682)
 //   ext PointCloud2 (x, y, z, intensity FLOAT32; point_step 16) with clip / radius-outlier /
 //         voxel grid -> rplgpu_host::ScanPath::fill_point_cloud2(nodes, ..., cloud_msg)
+//   pre LIDARSampleDataUnpacker::onSampleData -> LIDARSampleDataListener callbacks
+//         (src/sdk/src/dataunpacker/dataunpacker.h:48-88) and ScanDataHolder
+//         (src/sdk/src/sl_lidar_driver.cpp:272-315), for RECORDED answer streams
+//         -> rplgpu_host::ScanPath::replay_recording(ans, bytes, n, listener) /
+//            rplgpu_host::ScanAssembler
 //
 // Header only, no ROS dependency: the message types are template parameters, so the same
 // code compiles against sensor_msgs::msg::LaserScan / PointCloud2 in the node and against
@@ -153,6 +158,44 @@ class ScanPath {
     return true;
   }
 
+  // == feeding a whole recording of answer type `ans_type` to a fresh
+  // sl::internal::LIDARSampleDataUnpacker (onSampleData, dataunpacker.h:79): `listener` gets the
+  // calls the SDK's listener would get, in the same order — onHQNodeScanResetReq() and
+  // onHQNodeDecoded(timestamp_uS, const node*) (dataunpacker.h:52-56; SlamtecLidarDriver's own
+  // implementation is src/sdk/src/sl_lidar_driver.cpp:1645-1653).  Timestamps are 0: the SDK
+  // stamps nodes with the decoding host's wall clock, which a recording does not contain.
+  // `state` = {last sync bit, last dist_q2, 0, 0} carried between recordings of one sensor
+  // (all zero for a fresh unpacker).  `sample_duration_us` = SlamtecLidarTimingDesc::
+  // sample_duration_uS.  n_checksum_errors counts ERR_EVENT_ON_EXP_CHECKSUM_ERR events.
+  template <class ListenerT>
+  bool replay_recording(uint8_t ans_type, uint32_t sample_duration_us, const uint8_t *bytes,
+                        size_t nbytes, ListenerT &listener, int32_t state[4],
+                        uint32_t *n_checksum_errors = nullptr) {
+    if (!h_) return fail("rplgpu handle not configured");
+    const size_t S = rplgpu_frame_size(ans_type), npf = rplgpu_nodes_per_frame(ans_type);
+    if (!S) return fail("unknown answer type");
+    const size_t max_frames = nbytes / S;
+    dec_nodes_.resize(max_frames * npf + 1);
+    dec_resets_.resize(max_frames + 2);
+    size_t n_nodes = 0, n_reset = 0;
+    uint32_t n_err = 0;
+    int32_t zero[4] = {0, 0, 0, 0};
+    if (rplgpu_decode_stream(h_, ans_type, sample_duration_us, bytes, nbytes, state ? state : zero,
+                             dec_nodes_.data(), dec_nodes_.size(), &n_nodes, dec_resets_.data(),
+                             dec_resets_.size(), &n_reset, &n_err) != RPLGPU_OK)
+      return note_error();
+    if (n_checksum_errors) *n_checksum_errors = n_err;
+    size_t r = 0;
+    for (size_t i = 0; i <= n_nodes; ++i) {
+      while (r < n_reset && dec_resets_[r] == i) {
+        listener.onHQNodeScanResetReq();
+        ++r;
+      }
+      if (i < n_nodes) listener.onHQNodeDecoded(0ull, &dec_nodes_[i]);
+    }
+    return true;
+  }
+
   // ext: fills a sensor_msgs/PointCloud2-shaped message (fields x, y, z, intensity FLOAT32 at
   // offsets 0/4/8/12, point_step 16, height 1, is_dense, little endian).  `PointFieldT` is
   // sensor_msgs::msg::PointField (datatype 7 == FLOAT32).
@@ -200,7 +243,41 @@ class ScanPath {
   rplgpu_handle_t h_ = nullptr;
   uint32_t max_n_ = 0;
   std::vector<float> ranges_, intens_, xyzi_;
+  std::vector<rplgpu_node_t> dec_nodes_;
+  std::vector<uint32_t> dec_resets_;
   std::string last_error_;
+};
+
+// == ScanDataHolder<T> as SlamtecLidarDriver drives it (src/sdk/src/sl_lidar_driver.cpp:236-360,
+// :1645-1653): a listener for replay_recording that assembles scans.  A node with flag bit 0
+// closes the scan being built and opens the next one; nodes before the first sync node, or after
+// a rewind until the next sync node, are discarded; a scan that reached max_count nodes keeps
+// overwriting its last slot.  `on_scan(std::vector<rplgpu_node_t>&)` receives every completed
+// scan (the SDK instead parks it for grabScanDataHq).  Host-side bookkeeping, no arithmetic: for
+// batches the same rules run on the device (rplgpu_segment_batch_dev).
+template <class OnScan>
+class ScanAssembler {
+ public:
+  explicit ScanAssembler(OnScan on_scan, size_t max_count = 8192)
+      : on_scan_(on_scan), max_count_(max_count ? max_count : 1) {}
+  void onHQNodeScanResetReq() { cur_.clear(); }
+  void onHQNodeDecoded(unsigned long long, const rplgpu_node_t *node) {
+    if (node->flag & 1u) {
+      if (!cur_.empty()) {
+        on_scan_(cur_);
+        cur_.clear();
+      }
+    } else if (cur_.empty()) {
+      return;
+    }
+    if (cur_.size() >= max_count_) cur_.back() = *node;
+    else cur_.push_back(*node);
+  }
+
+ private:
+  OnScan on_scan_;
+  size_t max_count_;
+  std::vector<rplgpu_node_t> cur_;
 };
 
 // == DummyLidarDriver::grab_scan_data's synthetic ring (src/lidar_driver_wrapper.cpp:441-471),
