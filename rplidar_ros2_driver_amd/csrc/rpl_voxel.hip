@@ -37,6 +37,9 @@
 // A scan whose records do not fit (or that spans > 2048 rows) is processed in key
 // bands: the key range is bisected until a band fits, each band re-streaming the scan
 // (from L2 / Infinity Cache).
+#include <algorithm>
+#include <cstdlib>
+
 #include "rpl_device.hpp"
 #include "rpl_launch.hpp"
 
@@ -420,10 +423,13 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
     float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
-    uint32_t *__restrict__ status) {
+    uint32_t *__restrict__ status, uint32_t B) {
   __shared__ VoxelLds L;
 
-  const uint32_t b = blockIdx.x;
+  // persistent workgroups: one per CU (a workgroup needs the whole LDS of a CU, so launching
+  // one per scan only adds 4096 dispatches); the first scan is blockIdx.x, the next ones come
+  // from a shared counter, so a workgroup that drew cheap scans simply takes more of them
+  for (uint32_t b = blockIdx.x; b < B;) {
   const uint32_t n = min(n_per_scan[b], kMaxN);
   const uint2 *scan = nodes + (size_t)b * n_stride;
   float4 *out = xyzi + (size_t)b * out_stride;
@@ -568,6 +574,19 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     n_points[b] = min(total, out_stride);
     if (status) status[b] = L.misc[1] | ((total > out_stride) ? RPLGPU_SCAN_OUT_TRUNCATED : 0u);
   }
+  if (threadIdx.x == 0) L.tmp[31] = gridDim.x + atomicAdd(&T.work_ctr[0], 1u);
+  __syncthreads();  // LDS is reused by the next scan
+  b = L.tmp[31];
+  __syncthreads();
+  }
+  // the last workgroup to leave rearms the queue for the next launch on this stream
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&T.work_ctr[1], 1u) == gridDim.x - 1u) {
+      T.work_ctr[0] = 0u;
+      T.work_ctr[1] = 0u;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------
@@ -610,10 +629,20 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               float *xyzi, uint32_t out_stride, uint32_t *n_points,
                               uint32_t *status) {
   if (B == 0) return hipSuccess;
+  static int n_cu = 0;  // one persistent workgroup per CU
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  uint32_t grid = std::min<uint32_t>(B, (uint32_t)n_cu);
+  if (const char *e = std::getenv("RPLGPU_VOXEL_GRID")) grid = std::min<uint32_t>(B, (uint32_t)std::atoi(e));
 #define RPL_LAUNCH_VOXEL(FD, SF)                                                              \
-  hipLaunchKernelGGL((k_cloud_voxel<FD, SF>), dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, \
+  hipLaunchKernelGGL((k_cloud_voxel<FD, SF>), dim3(grid), dim3(kBlock), 0, s, (const uint2 *)nodes, \
                      n_stride, n_per_scan, p, T, keepmask, mask_stride, (float4 *)xyzi, out_stride, \
-                     n_points, status)
+                     n_points, status, B)
   if (p.fast_div) {
     if (p.cell_range_safe) RPL_LAUNCH_VOXEL(true, true); else RPL_LAUNCH_VOXEL(true, false);
   } else {

@@ -133,6 +133,7 @@ rpl::Tables tables_of(const rplgpu_ctx *c) {
   t.cs = c->d_cs;
   t.cs_inv = c->d_cs_inv;
   t.rcp = c->d_rcp;
+  t.work_ctr = c->d_small + 16;  // [16] next scan, [17] finished workgroups (self-resetting)
   return t;
 }
 
@@ -344,8 +345,12 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   if (hipHostMalloc((void **)&c->h_pin, n * 8 + n * 16 + 64, hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void **)&c->d_nodes, n * 8) != hipSuccess ||
       hipMalloc((void **)&c->d_out, n * 16) != hipSuccess ||
-      hipMalloc((void **)&c->d_small, 64) != hipSuccess) {
+      hipMalloc((void **)&c->d_small, 128) != hipSuccess) {
     c->err = "staging allocation failed";
+    return fail(RPLGPU_ERR_HIP);
+  }
+  if (hipMemset(c->d_small, 0, 128) != hipSuccess) {  // incl. the voxel kernel's scan queue
+    c->err = "staging clear failed";
     return fail(RPLGPU_ERR_HIP);
   }
   // dist_mm_q2 / 4000.0f: operands are the integer-valued floats 1 .. 2^32
