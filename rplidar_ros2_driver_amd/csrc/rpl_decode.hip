@@ -20,10 +20,10 @@
 //     s_i = r_i & (distance to the run's start is even); the raw bits go to an LDS bit set and
 //     each node scans back over its run with word operations;
 //   * the ultra-dense distance smoothing  d_i <- (d_i + d'_{i-1}) >> 1  (:997-1003): a genuine
-//     recurrence, but only along runs of scale-0 samples; a sample whose predecessor is not
-//     scale 0, or differs from it by more than 12 quarter-mm, cannot be reached by it (a
-//     smoothed value is within 4 of its raw value, the rule needs <= 8), so those samples are
-//     chain heads, computed locally, and each chain is walked by one thread from LDS.
+//     recurrence, but a smoothed value stays within +-4 of its raw value, so the carried value
+//     is one of 9 states relative to its node and every node is a 9 -> 9 map; maps compose
+//     associatively, so a block scan over per-thread segment maps resolves the recurrence
+//     exactly (phase P5).
 // Timestamps are not produced: the reference stamps nodes with the wall clock of the decoding
 // host (dataunpacker.cpp:164-166), not with anything in the stream.
 #include "rpl_device.hpp"
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
 // it is nodes s_j .. s_j + max_count - 2 followed by node s_{j+1} - 1 when it is longer than
 // max_count.  One workgroup per stream: compact the sync positions, judge the scans, copy.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kSegMaxSync = 8192;
+constexpr uint32_t kSegMaxSync = 2047;  // sync nodes of one stream per call (16 KiB of LDS)
 
 __global__ __launch_bounds__(kDecBlock) void k_segment(
     const uint2 *__restrict__ nodes, uint32_t node_stride, const uint32_t *__restrict__ n_nodes,
@@ -578,19 +578,31 @@ __global__ __launch_bounds__(kDecBlock) void k_segment(
   const uint32_t *rs = reset_at ? reset_at + (size_t)b * reset_stride : nullptr;
   uint32_t st = 0;
 
-  // sync positions, in order
-  uint32_t nsync = 0;
+  // sync positions: sync nodes are rare (one per revolution), so the pass over the stream is
+  // barrier-free — a ballot per wave, the few hits appended through an LDS counter — and the
+  // short list is put in order afterwards by counting
+  __shared__ uint32_t unsorted[kSegMaxSync + 1];
+  if (tid == 0) tmp[32] = 0u;
+  __syncthreads();
   for (uint32_t i0 = 0; i0 < n; i0 += kDecBlock) {
     const uint32_t i = i0 + tid;
-    const uint32_t is = (i < n && ((in[i].y >> 24) & 1u)) ? 1u : 0u;
-    uint32_t tot;
-    const uint32_t ex = dec_block_scan(is, tmp, &tot);
-    if (is && nsync + ex <= kSegMaxSync) sync_pos[nsync + ex] = i;
-    nsync += tot;
+    const bool is = i < n && ((in[i].y >> 24) & 1u);
+    if (__builtin_amdgcn_ballot_w64(is) != 0ull && is) {
+      const uint32_t slot = atomicAdd(&tmp[32], 1u);
+      if (slot <= kSegMaxSync) unsorted[slot] = i;
+    }
   }
+  __syncthreads();
+  uint32_t nsync = tmp[32];
   if (nsync > kSegMaxSync + 1u) {
-    st |= RPLGPU_STREAM_FRAMES_TRUNCATED;
+    st |= RPLGPU_STREAM_FRAMES_TRUNCATED;  // (which of the sync nodes were kept is arbitrary)
     nsync = kSegMaxSync + 1u;
+  }
+  for (uint32_t j = tid; j < nsync; j += kDecBlock) {
+    const uint32_t v = unsorted[j];
+    uint32_t rank = 0;
+    for (uint32_t q = 0; q < nsync; ++q) rank += unsorted[q] < v ? 1u : 0u;
+    sync_pos[rank] = v;
   }
   __syncthreads();
   const uint32_t ncand = nsync ? nsync - 1u : 0u;  // scans closed by a following sync node
