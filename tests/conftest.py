@@ -46,7 +46,15 @@ def reflibs():
 
 @pytest.fixture(scope="session")
 def gpu():
+    import torch
+
     from rplidar_ros2_driver_amd import RplGpu
     h = RplGpu(device=0, max_samples_per_scan=32768, max_batch=4096)
+    # one real stream shared by torch and the library: tensor fills / copies issued by a test
+    # and the library's kernels are then ordered (the handle's own stream would race torch's)
+    stream = torch.cuda.Stream(device=0)
+    torch.cuda.set_stream(stream)
+    h.set_stream(stream.cuda_stream)
     yield h
+    torch.cuda.synchronize()
     h.close()

@@ -290,3 +290,68 @@ def test_recorded_stream_to_laserscan_pipeline(gpu, oracle):
             assert np.count_nonzero(i[gidx, : wm.count] != wi) <= wm.count // 50
             gidx += 1
     assert gidx == total
+
+
+def test_decode_full_size_properties(gpu):
+    """BASELINE config-3 shape for the decode stage (4096 DenseBoost streams x 801 capsules =
+    131 M nodes), checked through size-independent properties computed on the device:
+    every capsule but the last publishes 40 nodes; the decoded distances are the capsule words
+    shifted by two (a sum of sums over the whole batch); quality is 0x2F << 2 exactly where the
+    distance is non-zero; every flag byte is 1 or 2 and there is exactly one sync node per
+    revolution; after scan assembly the completed scan of a stream is the node range between
+    its two sync nodes."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    ans, nf, B = 0x85, 801, 4096
+    S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
+    uniq = 16
+    base = np.stack([cp.make_stream(ans, nf, 500 + s, payload="ring", frames_per_rev=nf / 2.0 + 0.3)
+                     for s in range(uniq)])
+    buf = torch.from_numpy(base).to(dev).repeat(B // uniq, 1).contiguous()
+    d_nf = torch.full((B,), nf, dtype=torch.int32, device=dev)
+    node_stride = nf * npf
+    d_nodes = torch.zeros(B, node_stride * 8, dtype=torch.uint8, device=dev)
+    d_nn = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_rst = torch.zeros(B, 8, dtype=torch.int32, device=dev)
+    d_nr = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    gpu.decode_batch_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0,
+                         d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8,
+                         d_nr.data_ptr(), 0, d_st.data_ptr())
+    gpu.synchronize()
+    assert int(d_st.max()) == 0
+    assert bool((d_nn == (nf - 1) * npf).all())
+    assert bool((d_nr == 1).all()) and bool((d_rst[:, 0] == 0).all())  # first capsule: reset at node 0
+    n = (nf - 1) * npf
+    raw = d_nodes.view(B, node_stride, 8)[:, :n]
+    dist = (raw[..., 2].to(torch.int64) | (raw[..., 3].to(torch.int64) << 8)
+            | (raw[..., 4].to(torch.int64) << 16) | (raw[..., 5].to(torch.int64) << 24))
+    cab = buf.view(B, nf, S)[:, : nf - 1, 4:].reshape(B, n, 2).to(torch.int64)
+    want = (cab[..., 0] | (cab[..., 1] << 8)) << 2
+    assert int(dist.sum()) == int(want.sum()) and bool((dist == want).all())
+    q = raw[..., 6]
+    assert bool(((q == (0x2F << 2)) == (dist != 0)).all()) and bool(((q == 0) == (dist == 0)).all())
+    flag = raw[..., 7]
+    assert bool(((flag == 1) | (flag == 2)).all())
+    nsync = (flag == 1).sum(1)
+    assert bool(((nsync >= 1) & (nsync <= 2)).all())  # two revolutions per stream, +- the start phase
+    # scan assembly: one completed scan per stream with two sync nodes
+    d_seg = torch.zeros_like(d_nodes)
+    scan_cap = 4
+    d_off = torch.zeros(B, scan_cap + 1, dtype=torch.int32, device=dev)
+    d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()  # the handle runs on its own stream: torch's fills must have landed
+    gpu.segment_batch_dev(d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8,
+                          d_nr.data_ptr(), B, 32768, d_seg.data_ptr(), node_stride,
+                          d_off.data_ptr(), scan_cap, d_ns.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    assert int(d_st.max()) == 0
+    assert bool((d_ns == nsync - 1).all())
+    for b in (0, 1, 17, B - 1):
+        f = flag[b].cpu().numpy()
+        pos = np.nonzero(f == 1)[0]
+        if len(pos) == 2:
+            ln = int(d_off[b, 1])
+            assert ln == pos[1] - pos[0]
+            assert bool((d_seg.view(B, node_stride, 8)[b, :ln] == raw[b, pos[0]: pos[1]]).all())
