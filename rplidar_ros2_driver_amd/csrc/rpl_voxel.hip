@@ -39,6 +39,7 @@
 // (from L2 / Infinity Cache).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "rpl_device.hpp"
 #include "rpl_launch.hpp"
@@ -127,49 +128,44 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
                                              uint32_t ibfe_w, uint32_t klo, uint32_t khi,
                                              uint32_t &key, uint32_t &qx, uint32_t &qy,
                                              uint32_t &ci, uint32_t &flags) {
+  // Straight-line: a dropped sample runs the same arithmetic on harmless operands (dist 0 or an
+  // out-of-range distance give finite values) and is masked at the end.  A wave issues in
+  // order, so the exec-mask regions and branches of an `if (kept)` cost it more than the few
+  // instructions they skip on the ~10 % of dropped samples (profiles/r01).
   const uint32_t d = __builtin_amdgcn_alignbit(hi, lo, 16);  // unaligned u32 at byte 2
-  key = kEmptyKey;
-  qx = 0u;
-  qy = 0u;
-  ci = 0u;
   bool kept = (d - p.d_lo) <= p.d_span;                      // E1 (and :584)
-  if (HASQ) kept = kept && ((hi & 0x00FF0000u) >= q_min16);
-  bool taken = false;
-  if (kept) {
-    const float df = __uint2float_rn(d);
-    const float dm = FAST_DIV ? div_by(df, 4000.0f, 0.00025f) : df / 4000.0f;  // :590
-    const f2 cv = {c.x, c.y};
-    const f2 xy = cv * dm;                                                       // E2
-    f2 t;
-    if (FAST_DIV) {
-      t = div_by2(xy, p.voxel_leaf, p.inv_leaf);                                 // E4 cell
-    } else {
-      t.x = xy.x / p.voxel_leaf;
-      t.y = xy.y / p.voxel_leaf;
-    }
-    const f2 f = {__builtin_floorf(t.x), __builtin_floorf(t.y)};
-    bool ok = true;
-    if (!SAFE) {
-      ok = (fabsf(f.x) < 32767.0f) && (fabsf(f.y) < 32767.0f);
-      if (!ok) flags |= RPLGPU_SCAN_CELL_RANGE;
-    }
-    // iy + 32768 | ix + 32768 from the mantissas of f + (2^23 + 32768)
-    const uint32_t kx = __float_as_uint(f.x + kKeyMagic);
-    const uint32_t ky = __float_as_uint(f.y + kKeyMagic);
-    const uint32_t k = __builtin_amdgcn_perm(ky, kx, 0x05040100u);
-    if (BAND) ok = ok && (k >= klo) && (k <= khi);
-    if (ok) {
-      taken = true;
-      const f2 lf = {p.voxel_leaf, p.voxel_leaf};
-      const f2 r = __builtin_elementwise_fma(-f, lf, xy);  // x - ix*leaf, exact
-      const f2 o = r * p.vox_scale_f;
-      key = k;
-      qx = (uint32_t)((int)o.x + p.vox_bias);
-      qy = (uint32_t)((int)o.y + p.vox_bias);
-      ci = (1u << 16) | ((hi >> ibfe_off) & ibfe_w);  // count | intensity (:591-592)
-    }
+  if (HASQ) kept = kept & ((hi & 0x00FF0000u) >= q_min16);
+  const float df = __uint2float_rn(d);
+  const float dm = FAST_DIV ? div_by(df, 4000.0f, 0.00025f) : df / 4000.0f;  // :590
+  const f2 cv = {c.x, c.y};
+  const f2 xy = cv * dm;                                                       // E2
+  f2 t;
+  if (FAST_DIV) {
+    t = div_by2(xy, p.voxel_leaf, p.inv_leaf);                                 // E4 cell
+  } else {
+    t.x = xy.x / p.voxel_leaf;
+    t.y = xy.y / p.voxel_leaf;
   }
-  return taken;
+  const f2 f = {__builtin_floorf(t.x), __builtin_floorf(t.y)};
+  if (!SAFE) {
+    const bool inr = (fabsf(f.x) < 32767.0f) && (fabsf(f.y) < 32767.0f);
+    if (kept && !inr) flags |= RPLGPU_SCAN_CELL_RANGE;
+    kept = kept & inr;
+  }
+  // iy + 32768 | ix + 32768 from the mantissas of f + (2^23 + 32768)
+  const uint32_t kx = __float_as_uint(f.x + kKeyMagic);
+  const uint32_t ky = __float_as_uint(f.y + kKeyMagic);
+  const uint32_t k = __builtin_amdgcn_perm(ky, kx, 0x05040100u);
+  if (BAND) kept = kept & ((k - klo) <= (khi - klo));
+  const f2 lf = {p.voxel_leaf, p.voxel_leaf};
+  const f2 r = __builtin_elementwise_fma(-f, lf, xy);  // x - ix*leaf, exact
+  const f2 o = r * p.vox_scale_f;
+  const uint32_t m = kept ? 0xFFFFFFFFu : 0u;
+  key = kept ? k : kEmptyKey;
+  qx = (uint32_t)((int)o.x + p.vox_bias) & m;
+  qy = (uint32_t)((int)o.y + p.vox_bias) & m;
+  ci = ((1u << 16) | ((hi >> ibfe_off) & ibfe_w)) & m;  // count | intensity (:591-592)
+  return kept;
 }
 
 // Cross-lane part of one wave-pass over 128 samples: lane l holds samples A = 2l, B = 2l+1
@@ -486,7 +482,11 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     __syncthreads();
 
     // ---- phase S: raw pairs two rounds ahead, table entries one round ahead -------------
-    {
+    // (one loop instance per uniform condition, so that none of them is tested per pass)
+    auto stream = [&](auto band_tag, auto hasq_tag, auto mask_tag) {
+      constexpr bool BAND = decltype(band_tag)::value;
+      constexpr bool HASQ = decltype(hasq_tag)::value;
+      constexpr bool HASMASK = decltype(mask_tag)::value;
       uint4 w1 = load_pair(threadIdx.x);
       uint4 w2 = load_pair(kBlock + threadIdx.x);
       float2 cA1 = cs[w1.x & 0xFFFFu], cB1 = cs[w1.z & 0xFFFFu];
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
         cB1 = cs[w1.z & 0xFFFFu];
         w2 = load_pair(base + 2u * kBlock + threadIdx.x);
         uint4 w = w0;
-        if (keepmask) {  // E5 mask (one bit per sample): a dropped sample gets dist 0
+        if (HASMASK) {  // E5 mask (one bit per sample): a dropped sample gets dist 0
           const uint32_t pi = base + threadIdx.x;  // pair index -> bits 2*pi, 2*pi + 1
           const uint32_t word = pi >> 4;
           const uint32_t bits = (word < mask_stride) ? ror_bits[word] : 0u;
@@ -509,23 +509,28 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
           if (!(two & 2u)) { w.z &= 0x0000FFFFu; w.w &= 0xFFFF0000u; }
         }
         uint32_t keyA, xA, yA, ciA, keyB, xB, yB, ciB;
-        bool okA, okB;
-#define RPL_SAMPLES(BAND, HASQ)                                                                   \
-  okA = voxel_sample<FAST_DIV, BAND, SAFE, HASQ>(w.x, w.y, cA, p, q_min16, ibfe_off, ibfe_w, klo, \
-                                                 khi, keyA, xA, yA, ciA, flags);                  \
-  okB = voxel_sample<FAST_DIV, BAND, SAFE, HASQ>(w.z, w.w, cB, p, q_min16, ibfe_off, ibfe_w, klo, \
-                                                 khi, keyB, xB, yB, ciB, flags);
-        if (first_band) {
-          if (q_min16) { RPL_SAMPLES(false, true) } else { RPL_SAMPLES(false, false) }
-        } else {
-          RPL_SAMPLES(true, true)
-        }
-#undef RPL_SAMPLES
+        const bool okA = voxel_sample<FAST_DIV, BAND, SAFE, HASQ>(
+            w.x, w.y, cA, p, q_min16, ibfe_off, ibfe_w, klo, khi, keyA, xA, yA, ciA, flags);
+        const bool okB = voxel_sample<FAST_DIV, BAND, SAFE, HASQ>(
+            w.z, w.w, cB, p, q_min16, ibfe_off, ibfe_w, klo, khi, keyB, xB, yB, ciB, flags);
         // tag: (round, wave) — two neighbouring queue reservations never share it
         const uint32_t tag = (((round & 15u) << 4) | wave_id()) << 24;
         fits = voxel_pair_pass(L, tag, okA, keyA, xA, yA, ciA, okB, keyB, xB, yB, ciB);
       }
       if (!fits && lane_id() == 0) L.misc[2] = 1u;  // band does not fit
+    };
+    {
+      using T_ = std::true_type;
+      using F_ = std::false_type;
+      if (first_band) {
+        if (keepmask) stream(F_{}, T_{}, T_{});
+        else if (q_min16) stream(F_{}, T_{}, F_{});
+        else stream(F_{}, F_{}, F_{});
+      } else if (keepmask) {
+        stream(T_{}, T_{}, T_{});
+      } else {
+        stream(T_{}, T_{}, F_{});
+      }
     }
     first_band = false;
     __syncthreads();
