@@ -91,7 +91,7 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
   return (1ull << lane_id()) - 1ull;
 }
 
-// Inclusive wave scan (64 lanes) with shuffles.
+// Inclusive wave scan (64 lanes) with shuffles (ds_bpermute: ~24 issue cycles a step).
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -100,16 +100,30 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   }
   return v;
 }
+// The same scan with DPP row shifts / row broadcasts: six VALU instructions, no LDS crossbar.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_fast(uint32_t v) {
+  v = dpp_add_u32<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_add_u32<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_add_u32<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_add_u32<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_add_u32<0x142, 0xA>(v);  // row_bcast:15 -> rows 1,3
+  v = dpp_add_u32<0x143, 0xC>(v);  // row_bcast:31 -> rows 2,3
+  return v;
+}
 
 // Exclusive block scan of one value per thread (1024 threads). `tmp` = 17 u32 in LDS.
 // Returns the exclusive prefix; *total receives the block sum. Contains barriers.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
-  uint32_t inc = wave_incl_scan(v);
+  uint32_t inc = wave_incl_scan_fast(v);
   if (lane_id() == 63) tmp[wave_id()] = inc;
   __syncthreads();
   if (threadIdx.x < 64) {
     uint32_t w = (threadIdx.x < kWaves) ? tmp[threadIdx.x] : 0u;
-    uint32_t ws = wave_incl_scan(w);
+    uint32_t ws = wave_incl_scan_fast(w);
     if (threadIdx.x < kWaves) tmp[threadIdx.x] = ws - w;  // exclusive wave base
     if (threadIdx.x == kWaves - 1) tmp[kWaves] = ws;
   }
