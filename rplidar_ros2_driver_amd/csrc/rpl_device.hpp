@@ -115,6 +115,35 @@ __device__ __forceinline__ uint32_t wave_incl_scan_fast(uint32_t v) {
   return v;
 }
 
+// Wave-wide min / max with the same DPP pattern (lanes without a source keep their own value);
+// the result is valid in lane 63.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
+  return min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xF, false));
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp_max_u32(uint32_t v) {
+  return max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWMASK, 0xF, false));
+}
+__device__ __forceinline__ uint32_t wave_min_lane63(uint32_t v) {
+  v = dpp_min_u32<0x111, 0xF>(v);
+  v = dpp_min_u32<0x112, 0xF>(v);
+  v = dpp_min_u32<0x114, 0xF>(v);
+  v = dpp_min_u32<0x118, 0xF>(v);
+  v = dpp_min_u32<0x142, 0xA>(v);
+  v = dpp_min_u32<0x143, 0xC>(v);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_lane63(uint32_t v) {
+  v = dpp_max_u32<0x111, 0xF>(v);
+  v = dpp_max_u32<0x112, 0xF>(v);
+  v = dpp_max_u32<0x114, 0xF>(v);
+  v = dpp_max_u32<0x118, 0xF>(v);
+  v = dpp_max_u32<0x142, 0xA>(v);
+  v = dpp_max_u32<0x143, 0xC>(v);
+  return v;
+}
+
 // Exclusive block scan of one value per thread (1024 threads). `tmp` = 17 u32 in LDS.
 // Returns the exclusive prefix; *total receives the block sum. Contains barriers.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {

@@ -269,12 +269,9 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
     }
     mine[k] = m;
   }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    rmin = min(rmin, (uint32_t)__shfl_xor((int)rmin, d, 64));
-    rmax = max(rmax, (uint32_t)__shfl_xor((int)rmax, d, 64));
-  }
-  if (lane_id() == 0 && rmin != 0xFFFFFFFFu) {
+  rmin = wave_min_lane63(rmin);  // DPP reductions: the totals land in lane 63
+  rmax = wave_max_lane63(rmax);
+  if (lane_id() == 63 && rmin != 0xFFFFFFFFu) {
     atomicMin(&L.misc[4], rmin);
     atomicMax(&L.misc[5], rmax);
   }
