@@ -98,6 +98,7 @@ struct VoxelLds {
   uint32_t band_lo[34], band_hi[34];
   uint32_t misc[16];  // 0 queue tail, 1 status, 2 overflow, 3 sp, 4 rowmin, 5 rowmax, 7 out_base
   uint32_t tmp[32];
+  double rcp[256];  // RN(1/count) for count < 256 (copied once per workgroup from the host table)
 };
 
 // a / d without v_div_scale / v_rcp / v_div_fmas / v_div_fixup: `rd` = RN(1/d), one
@@ -389,9 +390,11 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
       const uint32_t cnt = cw >> 16, isum = cw & 0xFFFFu;
       const double ix = (double)((int)(key & 0xFFFFu) - 32768);
       const double iy = (double)((int)(key >> 16) - 32768);
-      // RN(1/count): the IEEE fp64 divide is correctly rounded, i.e. exactly the entry of the
-      // host-built reciprocal table; a dependent table gather (L2 latency) per cell costs more
-      const double dc = (double)cnt, rc = 1.0 / dc;
+      // RN(1/count): from the LDS copy of the host-built table for small counts, else the IEEE
+      // fp64 divide (correctly rounded, i.e. the same value; ~25 instructions); a dependent
+      // gather from the table in global memory (L2 latency) per cell costs more than either
+      const double dc = (double)cnt;
+      const double rc = cnt < 256u ? L.rcp[cnt] : 1.0 / dc;
       const double Sx = fma(dc, ix * dL - dbias, sx);  // coordinate sums in units of 2^-K m
       const double Sy = fma(dc, iy * dL - dbias, sy);
       const double si = (double)isum;
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     uint32_t *__restrict__ status, uint32_t B) {
   __shared__ VoxelLds L;
 
+  if (threadIdx.x < 256) L.rcp[threadIdx.x] = T.rcp[threadIdx.x];  // (first barrier below publishes it)
   // persistent workgroups: one per CU (a workgroup needs the whole LDS of a CU, so launching
   // one per scan only adds 4096 dispatches); the first scan is blockIdx.x, the next ones come
   // from a shared counter, so a workgroup that drew cheap scans simply takes more of them
