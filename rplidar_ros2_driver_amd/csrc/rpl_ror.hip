@@ -1,16 +1,23 @@
 // rpl_ror.hip — k_ror_mask: radius-outlier-removal keep mask (extension E5 of SURVEY.md §8
 // a-ext): a kept point survives iff at least `k` OTHER kept points of the same scan lie
 // within `r` (fp32: dx*dx + dy*dy <= r*r, products then sum, no FMA — the oracle's
-// orc_ror_mask expression, oracle/oracle.cpp).  One 1024-thread workgroup owns one scan and
-// keeps it in registers (same geometry as rpl_kernels.hip).
+// orc_ror_mask expression, oracle/oracle.cpp).  One 1024-thread workgroup owns one scan.
 //
-// The oracle is O(n^2).  Here the kept samples are binned by y into rows of height
-// h >= 1.001 r (h grows with the scan's y extent so that 2048 rows always suffice), a
-// counting sort groups their sample indices by row in LDS, and a point only visits the
-// candidates of its own row and the two neighbouring rows — one contiguous slice of the index
-// list — stopping as soon as k neighbours are found.  Candidate coordinates are recomputed
-// from the raw node and the (cos, sin) table, exactly as the cloud kernels compute them, so
-// the distance test sees bit-identical operands and the mask is bit-exact.
+// The oracle is O(n^2).  A point only has to be shown to have k neighbours, or to have fewer
+// after every candidate was seen, so the kernel works in two stages:
+//   1. index neighbours.  A lidar scan is ordered by angle: the nearest points of sample i are
+//      almost always samples i+-1, i+-2, ...  Every kept sample tests its 8 index neighbours
+//      (coalesced loads of the shifted scan) and is settled as soon as k of them lie within r.
+//   2. the few samples that stay unsettled (isolated returns, borders of drop-outs, real
+//      outliers) are searched exhaustively but cooperatively: the kept samples are binned by y
+//      into rows of height h >= 1.001 r (h grows with the scan's y extent so that 2048 rows
+//      always suffice) with a counting sort in LDS, and ONE WAVE per unsettled sample sweeps
+//      the candidates of its own row and the two rows next to it, 64 at a time (ballot +
+//      popcount), stopping at k.
+// Candidate coordinates are always recomputed from the raw node and the (cos, sin) table,
+// exactly as the cloud kernels compute them, so the distance test sees bit-identical operands
+// and the mask is bit-exact.  (The first version gave every thread its 32 samples and walked the
+// three-row slice alone, two dependent gathers per candidate: 9 ms per scan.)
 //
 // Output: one bit per input sample (bit i of word i/32), 1 = the sample passed E1 AND E5.
 #include "rpl_device.hpp"
@@ -19,13 +26,17 @@
 namespace rpl {
 
 constexpr uint32_t kRorRows = 2048;
+constexpr uint32_t kRorTodo = 8192;  // unsettled samples stage 2 can take (else: next round)
+constexpr int kRorNear = 4;          // stage 1 looks at samples i-4 .. i+4
 
 struct RorLds {
   uint16_t idx[kMaxN];          // sample indices grouped by row
   uint32_t rowstart[kRorRows];  // first slot of a row
   uint32_t rowfill[kRorRows];   // one past its last slot (after the scatter)
-  uint32_t misc[8];             // 0/1 ymin/ymax (order-preserving uint encoding)
+  uint32_t misc[8];             // 0/1 ymin/ymax (order-preserving uint encoding), 2 #unsettled
   uint32_t tmp[32];
+  uint16_t todo[kRorTodo];      // unsettled samples of stage 1
+  uint32_t late[kMaxN / 32];    // keep bits found by stage 2 (bit i of word i/32)
 };
 
 // order-preserving float <-> uint map (for LDS atomicMin / atomicMax on floats)
@@ -60,27 +71,54 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   if (threadIdx.x == 0) {
     L.misc[0] = 0xFFFFFFFFu;
     L.misc[1] = 0u;
+    L.misc[2] = 0u;
   }
   for (uint32_t t = threadIdx.x; t < kRorRows; t += kBlock) L.rowstart[t] = 0u;
+  for (uint32_t t = threadIdx.x; t < kMaxN / 32u; t += kBlock) L.late[t] = 0u;
   __syncthreads();
 
-  // ---- E1 keep bits and the y extent of the kept points --------------------------------
-  uint32_t kept = 0;
+  const float r2 = p.ror_r2;
+  const uint32_t need = p.ror_k;
+  // ---- stage 1: E1 keep bits, y extent, and the index-neighbour test ----------------------
+  uint32_t kept = 0, keep = 0;
   float ymin = __uint_as_float(0x7F800000u), ymax = __uint_as_float(0xFF800000u);
   for (int j = 0; j < kIters; ++j) {
     const uint32_t i = ((uint32_t)(j * kWaves) + wave) * 64u + lane;
-    if (i < n) {
-      const uint2 nd = scan[i];
-      if (nd_keep(nd_dist(nd), nd_quality(nd), p)) {
-        kept |= 1u << j;
-        const float y = node_xy(nd, cs).y;
-        ymin = fminf(ymin, y);
-        ymax = fmaxf(ymax, y);
+    if (i >= n) continue;
+    const uint2 nd = scan[i];
+    if (!nd_keep(nd_dist(nd), nd_quality(nd), p)) continue;
+    kept |= 1u << j;
+    const float2 me = node_xy(nd, cs);
+    ymin = fminf(ymin, me.y);
+    ymax = fmaxf(ymax, me.y);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int o = 1; o <= kRorNear; ++o) {
+#pragma unroll
+      for (int sgn = 0; sgn < 2; ++sgn) {
+        const uint32_t q = sgn ? i - (uint32_t)o : i + (uint32_t)o;  // i - o wraps below 0: fails q < n
+        if (cnt < need && q < n) {
+          const uint2 c = scan[q];
+          if (nd_keep(nd_dist(c), nd_quality(c), p)) {
+            const float2 pc = node_xy(c, cs);
+            const float dx = me.x - pc.x, dy = me.y - pc.y;
+            const float d2 = dx * dx + dy * dy;  // products then sum (-ffp-contract=off)
+            cnt += (d2 <= r2) ? 1u : 0u;
+          }
+        }
       }
     }
+    if (cnt >= need) {
+      keep |= 1u << j;
+    } else {  // unsettled: stage 2
+      const uint32_t slot = atomicAdd(&L.misc[2], 1u);
+      if (slot < kRorTodo) L.todo[slot] = (uint16_t)i;
+    }
   }
+  ymin = fminf(ymin, __shfl_xor(ymin, 32, 64));  // (six steps of a butterfly)
+  ymax = fmaxf(ymax, __shfl_xor(ymax, 32, 64));
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
+  for (int d = 16; d > 0; d >>= 1) {
     ymin = fminf(ymin, __shfl_xor(ymin, d, 64));
     ymax = fmaxf(ymax, __shfl_xor(ymax, d, 64));
   }
@@ -89,9 +127,8 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
     atomicMax(&L.misc[1], f2ord(ymax));
   }
   __syncthreads();
-  const bool any = L.misc[0] != 0xFFFFFFFFu;  // block-uniform
-  uint32_t keep = 0;
-  if (any) {
+  const uint32_t n_todo_all = L.misc[2];  // block-uniform
+  if (n_todo_all != 0u) {
     const float y0 = ord2f(L.misc[0]), y1 = ord2f(L.misc[1]);
     const float r = sqrtf(p.ror_r2);
     // rows at least 1.001 r high (points within r in y are at most one row apart) and few
@@ -128,35 +165,62 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
       }
     }
     __syncthreads();
-    // ---- neighbour count: own row and the two rows next to it --------------------------
-    const float r2 = p.ror_r2;
-    const uint32_t need = p.ror_k;
-    for (int j = 0; j < kIters; ++j) {
-      if ((kept >> j) & 1u) {
-        const uint32_t i = ((uint32_t)(j * kWaves) + wave) * 64u + lane;
-        const float2 me = node_xy(scan[i], cs);
-        const uint32_t row = row_of(me.y);
-        const uint32_t a = L.rowstart[row > 0u ? row - 1u : 0u];
-        const uint32_t e = L.rowfill[min(row + 1u, kRorRows - 1u)];
-        uint32_t cnt = 0;
-        for (uint32_t q = a; q < e && cnt < need; q += 2u) {
-          const uint32_t j0 = L.idx[q], j1 = (q + 1u < e) ? L.idx[q + 1u] : i;
-          const float2 p0 = node_xy(scan[j0], cs), p1 = node_xy(scan[j1], cs);
-          const float dx0 = me.x - p0.x, dy0 = me.y - p0.y;
-          const float dx1 = me.x - p1.x, dy1 = me.y - p1.y;
-          const float d0 = dx0 * dx0 + dy0 * dy0;  // products then sum (-ffp-contract=off)
-          const float d1 = dx1 * dx1 + dy1 * dy1;
-          cnt += (j0 != i && d0 <= r2) ? 1u : 0u;
-          cnt += (j1 != i && d1 <= r2) ? 1u : 0u;
+    // ---- stage 2: one wave per unsettled sample, 64 candidates at a time ---------------------
+    const uint32_t n_todo = min(n_todo_all, kRorTodo);
+    for (uint32_t t = wave; t < n_todo; t += kWaves) {
+      const uint32_t i = L.todo[t];
+      const float2 me = node_xy(scan[i], cs);  // wave-uniform address
+      const uint32_t row = row_of(me.y);
+      const uint32_t a = L.rowstart[row > 0u ? row - 1u : 0u];
+      const uint32_t e = L.rowfill[min(row + 1u, kRorRows - 1u)];
+      uint32_t cnt = 0;
+      for (uint32_t q0 = a; q0 < e && cnt < need; q0 += 64u) {
+        const uint32_t q = q0 + lane;
+        bool hit = false;
+        if (q < e) {
+          const uint32_t jc = L.idx[q];
+          const float2 pc = node_xy(scan[jc], cs);
+          const float dx = me.x - pc.x, dy = me.y - pc.y;
+          const float d2 = dx * dx + dy * dy;
+          hit = (jc != i) && (d2 <= r2);
         }
-        if (cnt >= need) keep |= 1u << j;
+        cnt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit));
+      }
+      if (lane == 0 && cnt >= need) atomicOr(&L.late[i >> 5], 1u << (i & 31u));
+    }
+    // more unsettled samples than the list holds (an adversarial scan): the rest is done the
+    // slow way, one thread per sample over the same three-row slice
+    if (n_todo_all > kRorTodo) {
+      __syncthreads();
+      // which samples are in the list is arbitrary, so every unsettled sample not yet kept is
+      // simply re-examined (idempotent)
+      for (int j = 0; j < kIters; ++j) {
+        if (((kept & ~keep) >> j) & 1u) {
+          const uint32_t i = ((uint32_t)(j * kWaves) + wave) * 64u + lane;
+          if ((L.late[i >> 5] >> (i & 31u)) & 1u) continue;
+          const float2 me = node_xy(scan[i], cs);
+          const uint32_t row = row_of(me.y);
+          const uint32_t a = L.rowstart[row > 0u ? row - 1u : 0u];
+          const uint32_t e = L.rowfill[min(row + 1u, kRorRows - 1u)];
+          uint32_t cnt = 0;
+          for (uint32_t q = a; q < e && cnt < need; ++q) {
+            const uint32_t jc = L.idx[q];
+            const float2 pc = node_xy(scan[jc], cs);
+            const float dx = me.x - pc.x, dy = me.y - pc.y;
+            const float d2 = dx * dx + dy * dy;
+            cnt += (jc != i && d2 <= r2) ? 1u : 0u;
+          }
+          if (cnt >= need) keep |= 1u << j;
+        }
       }
     }
   }
+  __syncthreads();
   // ---- one bit per sample: chunk c = j*16 + wave covers samples [64c, 64c+64) -------------
   for (int j = 0; j < kIters; ++j) {
-    const uint64_t m = __ballot((keep >> j) & 1u);
     const uint32_t c = (uint32_t)(j * kWaves) + wave;
+    const uint64_t m = __ballot((keep >> j) & 1u) |
+                       ((uint64_t)L.late[2u * c] | ((uint64_t)L.late[2u * c + 1u] << 32));
     if (lane == 0 && 2u * c < mask_stride) mask[2u * c] = (uint32_t)m;
     if (lane == 1 && 2u * c + 1u < mask_stride) mask[2u * c + 1u] = (uint32_t)(m >> 32);
   }

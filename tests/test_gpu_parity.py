@@ -227,6 +227,22 @@ def test_ror_full_scan_32000(gpu, oracle):
     assert status == 0 and got.tobytes() == want.tobytes()
 
 
+def test_ror_many_unsettled_samples(gpu, oracle):
+    """Random ranges: almost no sample has its neighbours next to it in angle order, so nearly all
+    of them go to the exhaustive stage — more than its work list holds (8192), which exercises
+    the list, the overflow path and scans where most points ARE outliers."""
+    for n, r, k in ((12000, 0.10, 2), (12000, 0.6, 1), (9000, 1.5, 3)):
+        nodes = synth.make_scan(91, n, n, kind="uniform")
+        p = Params.defaults(clip_enable=1, range_max=40.0, ror_enable=1, ror_radius=r,
+                            ror_min_neighbors=k)
+        want = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(p))
+        base = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(
+            Params.defaults(clip_enable=1, range_max=40.0)))
+        got, status = gpu.scan_to_cloud(nodes, p)
+        assert status == 0 and got.tobytes() == want.tobytes()
+        assert len(want) < len(base)
+
+
 def _cells_of(xyzi, leaf):
     leaf = np.float32(leaf)
     ix = np.floor(xyzi[:, 0] / leaf).astype(np.int32)
