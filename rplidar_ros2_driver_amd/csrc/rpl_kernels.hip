@@ -79,23 +79,86 @@ __device__ __forceinline__ bool keys_unsorted(const uint32_t *s_keys, uint32_t c
 // Sort the keys (unique, so the order is the stable (value, input index) order), then turn
 // the array into the inverse map s_keys[sample index] = sorted position.  `count` <= 32768.
 // Only called for unsorted input: already ascending scans (the usual case) never get here.
-__device__ __forceinline__ void sort_keys_to_positions(uint32_t *s_keys, uint32_t count) {
-  const uint32_t N = next_pow2(count);
-  for (uint32_t t = count + threadIdx.x; t < N; t += kBlock) s_keys[t] = 0xFFFFFFFFu;
-  block_bitonic_sort(s_keys, N);  // starts and ends with a barrier
-  // inverse map through registers (the array is read completely before it is rewritten)
+//
+// Angles of a scan are spread over the circle, so a counting sort on the top 11 bits of the
+// angle word (2048 buckets, ~16 keys each for a full scan) followed by ranking every key inside
+// its bucket by counting does the job in a few LDS passes; the keys wait in registers while
+// `s_keys` is reused as the bucket-grouped array.  A scan that piles more than kBucketMax keys
+// into one bucket (many equal angles) takes the bitonic network instead (120 stages).
+constexpr uint32_t kSortBuckets = 2048;
+constexpr uint32_t kBucketMax = 512;
+
+struct SortLds {
+  uint32_t start[kSortBuckets];
+  uint32_t fill[kSortBuckets];
+  uint32_t tmp[32];
+};
+
+__device__ __forceinline__ void sort_keys_to_positions(uint32_t *s_keys, uint32_t count,
+                                                       SortLds &S) {
   uint32_t mine[kIters];
 #pragma unroll
   for (int k = 0; k < kIters; ++k) {
-    uint32_t r = threadIdx.x + (uint32_t)k * kBlock;
+    const uint32_t r = threadIdx.x + (uint32_t)k * kBlock;
     mine[k] = (r < count) ? s_keys[r] : 0xFFFFFFFFu;
   }
+  for (uint32_t t = threadIdx.x; t < kSortBuckets; t += kBlock) S.start[t] = 0u;
+  if (threadIdx.x == 0) S.tmp[31] = 0u;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kIters; ++k) {
-    uint32_t r = threadIdx.x + (uint32_t)k * kBlock;
-    if (r < count) s_keys[mine[k] & 0xFFFFu] = r;
+  for (int k = 0; k < kIters; ++k)
+    if (mine[k] != 0xFFFFFFFFu) atomicAdd(&S.start[mine[k] >> 21], 1u);
+  __syncthreads();
+  {
+    const uint32_t c0 = S.start[2 * threadIdx.x], c1 = S.start[2 * threadIdx.x + 1];
+    if (max(c0, c1) > kBucketMax) S.tmp[31] = 1u;  // benign race: every writer stores 1
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(c0 + c1, S.tmp, &tot);
+    S.start[2 * threadIdx.x] = ex;
+    S.start[2 * threadIdx.x + 1] = ex + c0;
+    S.fill[2 * threadIdx.x] = ex;
+    S.fill[2 * threadIdx.x + 1] = ex + c0;
   }
+  __syncthreads();
+  if (S.tmp[31]) {  // block-uniform: degenerate distribution, s_keys is still untouched
+    const uint32_t N = next_pow2(count);
+    for (uint32_t t = count + threadIdx.x; t < N; t += kBlock) s_keys[t] = 0xFFFFFFFFu;
+    block_bitonic_sort(s_keys, N);  // starts and ends with a barrier
+#pragma unroll
+    for (int k = 0; k < kIters; ++k) {
+      const uint32_t r = threadIdx.x + (uint32_t)k * kBlock;
+      mine[k] = (r < count) ? s_keys[r] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kIters; ++k) {
+      const uint32_t r = threadIdx.x + (uint32_t)k * kBlock;
+      if (r < count) s_keys[mine[k] & 0xFFFFu] = r;
+    }
+    __syncthreads();
+    return;
+  }
+  // group by bucket (order inside a bucket is arbitrary, the ranks below fix it)
+#pragma unroll
+  for (int k = 0; k < kIters; ++k)
+    if (mine[k] != 0xFFFFFFFFu) s_keys[atomicAdd(&S.fill[mine[k] >> 21], 1u)] = mine[k];
+  __syncthreads();
+  // rank inside the bucket; the key is then replaced by (sample index << 16 | position), so no
+  // second register array is needed
+#pragma unroll
+  for (int k = 0; k < kIters; ++k) {
+    if (mine[k] != 0xFFFFFFFFu) {
+      const uint32_t bkt = mine[k] >> 21;
+      const uint32_t s0 = S.start[bkt], s1 = S.fill[bkt];
+      uint32_t rank = s0;
+      for (uint32_t q = s0; q < s1; ++q) rank += s_keys[q] < mine[k] ? 1u : 0u;
+      mine[k] = (mine[k] << 16) | rank;  // rank < 32768: never collides with the empty marker
+    }
+  }
+  __syncthreads();  // every bucket was read before the array is rewritten
+#pragma unroll
+  for (int k = 0; k < kIters; ++k)
+    if (mine[k] != 0xFFFFFFFFu) s_keys[mine[k] >> 16] = mine[k] & 0xFFFFu;
   __syncthreads();
 }
 
@@ -109,12 +172,21 @@ __device__ __forceinline__ uint32_t deg_to_q14(float v) {  // setAngle, :107-110
   return ((uint32_t)(v * 16384.f / 90.f)) & 0xFFFFu;
 }
 
+// Two instantiations, two kernels: SORT = false handles the usual case (the scan comes out
+// ascending once the invalid samples got their angles) and only flags a scan that needs
+// sorting; SORT = true runs after it, returns at once for unflagged scans and does the whole
+// job including the sort for the others.  Keeping the sort (32 keys per thread in registers)
+// out of the first kernel keeps its register allocation spill-free.
+template <bool SORT>
 __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, uint32_t n_stride,
                                                    const uint32_t *__restrict__ n_per_scan,
-                                                   uint32_t *__restrict__ status) {
+                                                   uint32_t *__restrict__ status,
+                                                   uint32_t *__restrict__ need_sort) {
   __shared__ uint32_t s_keys[kMaxN];
   __shared__ uint32_t s_misc[8];
+  __shared__ SortLds s_sort;
   const uint32_t b = blockIdx.x;
+  if (SORT && need_sort[b] == 0u) return;
   const uint32_t n = min(n_per_scan[b], kMaxN);
   uint2 *scan = nodes + (size_t)b * n_stride;
 
@@ -137,6 +209,7 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
   first = s_misc[0];
   if (first == 0xFFFFFFFFu) {  // :151 all invalid -> SL_RESULT_OPERATION_FAIL, buffer untouched
     if (threadIdx.x == 0 && status) status[b] = RPLGPU_SCAN_ALL_INVALID;
+    if (threadIdx.x == 0 && !SORT) need_sort[b] = 0u;
     return;
   }
   if (threadIdx.x == 0 && status) status[b] = 0u;
@@ -159,41 +232,55 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
   const uint32_t front_q = s_misc[1];
   const float front = q14_to_deg(front_q);  // :171
 
+  // the fill pass (:171-178) for the 32 samples of this thread: new angle words in v, keys out
   uint32_t changed = 0;
+  auto fill_angles = [&](bool write_keys) {
+    changed = 0;
 #pragma unroll
-  for (int j = 0; j < kIters; ++j) {
-    uint32_t i = sample_index(j);
-    if (i < n) {
-      uint32_t q = nd_q14(v[j]);
-      uint32_t nq = q;
-      if (nd_dist(v[j]) == 0u) {
-        if (i == 0) {
-          nq = front_q;
-        } else {  // :172-178
-          float e = front + (float)i * inc;
-          if (e > 360.0f) e -= 360.0f;
-          nq = deg_to_q14(e);
+    for (int j = 0; j < kIters; ++j) {
+      uint32_t i = sample_index(j);
+      if (i < n) {
+        uint32_t q = nd_q14(v[j]);
+        uint32_t nq = q;
+        if (nd_dist(v[j]) == 0u) {
+          if (i == 0) {
+            nq = front_q;
+          } else {  // :172-178
+            float e = front + (float)i * inc;
+            if (e > 360.0f) e -= 360.0f;
+            nq = deg_to_q14(e);
+          }
         }
+        if (nq != q) {
+          changed |= 1u << j;
+          v[j].x = (v[j].x & 0xFFFF0000u) | nq;
+        }
+        if (write_keys) s_keys[i] = (nq << 16) | i;  // unique key: (angle, input index)
       }
-      if (nq != q) {
-        changed |= 1u << j;
-        v[j].x = (v[j].x & 0xFFFF0000u) | nq;
-      }
-      s_keys[i] = (nq << 16) | i;  // unique key: (angle, input index)
     }
-  }
+  };
+  fill_angles(true);
   __syncthreads();
 
   // std::sort by float angle (:181) == sort by q14 (getAngle is exact and monotone).
   // Equal angles: the reference order is whatever introsort leaves; ours is input order.
-  if (!keys_unsorted(s_keys, n, &s_misc[2])) {  // already ascending: only the filled angles move
+  if (!SORT) {
+    const bool unsorted = keys_unsorted(s_keys, n, &s_misc[2]);
+    if (threadIdx.x == 0) need_sort[b] = unsorted ? 1u : 0u;
+    if (!unsorted) {  // already ascending: only the filled angles move
 #pragma unroll
-    for (int j = 0; j < kIters; ++j)
-      if ((changed >> j) & 1u) scan[sample_index(j)] = v[j];
-    return;
+      for (int j = 0; j < kIters; ++j)
+        if ((changed >> j) & 1u) scan[sample_index(j)] = v[j];
+    }
+    return;  // unsorted: nothing written, the second kernel redoes this scan
   }
-  sort_keys_to_positions(s_keys, n);
-
+  // the sort keeps 32 keys per thread in registers: the scan is dropped and fetched again (L2)
+  // rather than spilled around it — this path is the rare one.  Every thread has its samples
+  // back in registers before anybody overwrites the buffer.
+  sort_keys_to_positions(s_keys, n, s_sort);
+  load_scan(scan, n, v);
+  fill_angles(false);
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
     uint32_t i = sample_index(j);
@@ -216,6 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_raw(
   __shared__ uint64_t s_mask[kChunks];
   __shared__ uint32_t s_cbase[kChunks];
   __shared__ uint32_t s_tmp[32];
+  __shared__ SortLds s_sort;
 
   const uint32_t b = blockIdx.x;
   const uint32_t n = min(n_per_scan[b], kMaxN);
@@ -246,7 +334,12 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_raw(
   }
   __syncthreads();
   const bool unsorted = keys_unsorted(s_keys, count, &s_tmp[20]);
-  if (unsorted) sort_keys_to_positions(s_keys, count);
+  if (unsorted) {
+    // the sort keeps 32 keys per thread in registers: the scan is dropped and fetched again
+    // (L2) rather than spilled around it — this path is the rare one
+    sort_keys_to_positions(s_keys, count, s_sort);
+    load_scan(scan, n, v);
+  }
 #pragma unroll
   for (int j = 0; j < kIters; ++j) {
     if ((kept >> j) & 1u) {
@@ -351,10 +444,12 @@ __global__ __launch_bounds__(256) void k_pack(const float4 *__restrict__ xyzi, u
 // host-side launchers (declared in rpl_launch.hpp)
 // ------------------------------------------------------------------------------
 hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
-                         uint32_t B, uint32_t *status) {
+                         uint32_t B, uint32_t *status, uint32_t *need_sort) {
   if (B == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_ascend, dim3(B), dim3(kBlock), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
-                     status);
+  hipLaunchKernelGGL(k_ascend<false>, dim3(B), dim3(kBlock), 0, s, (uint2 *)nodes, n_stride,
+                     n_per_scan, status, need_sort);
+  hipLaunchKernelGGL(k_ascend<true>, dim3(B), dim3(kBlock), 0, s, (uint2 *)nodes, n_stride,
+                     n_per_scan, status, need_sort);
   return hipGetLastError();
 }
 

@@ -31,6 +31,8 @@ struct rplgpu_ctx {
   unsigned char *h_pin = nullptr;  // pinned: nodes | out (16 B / sample) | 2 x u32
   unsigned char *d_nodes = nullptr, *d_out = nullptr;
   uint32_t *d_rormask = nullptr;  // E5 keep bits, max_b scans x kMaskStride words
+  uint32_t *d_need_sort = nullptr;  // ascend: scans the sorting kernel must redo (B words)
+  uint32_t need_sort_cap = 0;
   uint32_t *d_small = nullptr;  // [0]=n, [1]=count, [2]=status, [8]=divide-validation mismatches
   // fast-divide validation cache (see k_validate_div)
   bool div4000_ok = false;
@@ -192,6 +194,7 @@ void free_ctx(rplgpu_ctx *c) {
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->d_rormask) (void)hipFree(c->d_rormask);
+  if (c->d_need_sort) (void)hipFree(c->d_need_sort);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -405,7 +408,15 @@ int32_t rplgpu_ascend_batch_dev(rplgpu_handle_t h, rplgpu_node_t *d_nodes, uint3
   int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
   if (rc) return rc;
   RPL_HIP(h, hipSetDevice(h->device));
-  RPL_HIP(h, rpl::launch_ascend(h->stream, d_nodes, n_stride, d_n_per_scan, B, d_status));
+  if (h->need_sort_cap < B) {
+    if (h->d_need_sort) (void)hipFree(h->d_need_sort);
+    h->d_need_sort = nullptr;
+    h->need_sort_cap = 0;
+    RPL_HIP(h, hipMalloc((void **)&h->d_need_sort, (size_t)B * 4u));
+    h->need_sort_cap = B;
+  }
+  RPL_HIP(h, rpl::launch_ascend(h->stream, d_nodes, n_stride, d_n_per_scan, B, d_status,
+                                h->d_need_sort));
   return RPLGPU_OK;
 }
 
@@ -487,7 +498,8 @@ int32_t rplgpu_ascend(rplgpu_handle_t h, rplgpu_node_t *nodes, size_t n, uint32_
   h_small[0] = (uint32_t)n;
   RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
   RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
-  RPL_HIP(h, rpl::launch_ascend(h->stream, h->d_nodes, (uint32_t)n, h->d_small, 1, h->d_small + 2));
+  RPL_HIP(h, rpl::launch_ascend(h->stream, h->d_nodes, (uint32_t)n, h->d_small, 1, h->d_small + 2,
+                                h->d_small + 20));
   RPL_HIP(h, hipMemcpyAsync(h->h_pin, h->d_nodes, n * 8, hipMemcpyDeviceToHost, h->stream));
   RPL_HIP(h, hipMemcpyAsync(h_small + 2, h->d_small + 2, 4, hipMemcpyDeviceToHost, h->stream));
   RPL_HIP(h, hipStreamSynchronize(h->stream));
