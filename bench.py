@@ -4,7 +4,8 @@
 A "step" is one pass of the hot path over one batch of synthetic raw scans that is
 already resident in HBM: BASELINE config 3 — 4096 scans x 32 000 samples (131 072 000
 input samples, 1 048 576 000 B of packed 8-byte nodes) -> E1 quality/range clip -> polar->XYZ
--> 5 cm voxel grid (kernel ``k_cloud_voxel``), then packed into one contiguous cloud.
+-> 5 cm voxel grid (kernel ``k_cloud_voxel``), the clouds of all scans written to one
+contiguous arena (every scan reserves exactly its cells; no packing pass).
 With --gpus N > 1 (config 4) the SAME batch is sharded by scan index (strong scaling), each
 rank processes its block and the packed clouds are all-gathered with RCCL over xGMI inside
 the timed region.
@@ -231,11 +232,14 @@ def main():
     h_nodes = torch.from_numpy(batch_np.view(np.uint8).reshape(B, n * 8))
     d_nodes = h_nodes.to(dev)
     d_len = torch.from_numpy(lens_np).to(dev)
-    d_xyzi = torch.empty(B, out_stride, 4, dtype=torch.float32, device=dev)
     d_np = torch.zeros(B, dtype=torch.int32, device=dev)
     d_st = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
-    d_packed = torch.empty(B * out_stride, 4, dtype=torch.float32, device=dev)
+    # the voxelised clouds of the whole batch go to one contiguous arena (every scan reserves
+    # exactly its cells): no packing pass, and the all-gather payload for N > 1 as it is
+    arena_cap = B * out_stride
+    d_arena = torch.empty(arena_cap, 4, dtype=torch.float32, device=dev)
+    d_cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_start = torch.zeros(B, dtype=torch.int64, device=dev)
 
     params = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0,
                              voxel_enable=1, voxel_leaf=0.05)
@@ -247,13 +251,12 @@ def main():
     gpu.set_stream(stream.cuda_stream)
 
     def step():
-        gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
-                            d_xyzi.data_ptr(), out_stride, d_np.data_ptr(), d_st.data_ptr())
-        gpu.pack_clouds_dev(d_xyzi.data_ptr(), out_stride, d_np.data_ptr(), B,
-                            d_packed.data_ptr(), d_off.data_ptr())
+        gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
+                            d_arena.data_ptr(), arena_cap, d_cursor.data_ptr(),
+                            d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
         if world > 1:
-            total = int(d_off[B].item())
-            return allgather_clouds(d_packed, total, d_np)
+            total = int(d_cursor.item())
+            return allgather_clouds(d_arena, total, d_np, scan_starts=d_start)
         return None
 
     def fence():
@@ -275,7 +278,7 @@ def main():
         elapsed = float(t.item())
 
     status = int(d_st.max().item())
-    cells_local = int(d_off[B].item())
+    cells_local = int(d_cursor.item())
 
     # PCIe-inclusive rate (NOT `value`): the same batch handed over as a pinned host buffer
     h2d_ms = None
@@ -300,9 +303,10 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(reps)]
     for a, b in ev:
-        a.record(stream)
-        gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
-                            d_xyzi.data_ptr(), out_stride, d_np.data_ptr(), d_st.data_ptr())
+        a.record(stream)  # the same launch as in the step (k_cloud_voxel + an 8-byte memset)
+        gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
+                            d_arena.data_ptr(), arena_cap, d_cursor.data_ptr(),
+                            d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
         b.record(stream)
     torch.cuda.synchronize(dev)
     k_ms = sorted(a.elapsed_time(b) for a, b in ev)
@@ -371,7 +375,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"config3: {B_total} scans x {n} samples (ring, 10% invalid runs), "
-                            f"clip [0.15,40] m + polar->XYZ + 5 cm voxel grid + pack"
+                            f"clip [0.15,40] m + polar->XYZ + 5 cm voxel grid into one contiguous cloud"
                             + ("" if world == 1 else f", sharded by scan over {world} GPUs + "
                                "RCCL all-gather of voxelised clouds"),
                 "scans": B_total, "samples_per_scan": n, "voxel_leaf_m": 0.05,

@@ -153,6 +153,15 @@ int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
                                const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
                                float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,
                                uint32_t *d_status);
+/* Voxelised clouds of a whole batch in ONE contiguous cloud ("arena"), no packing pass: every
+ * scan reserves exactly its cells once their number is known, so the scans lie in the arena in
+ * completion order; scan b is d_arena[d_scan_start[b] .. + d_n_points[b]).  *d_cursor (a device
+ * word, reset by this call) ends up as the total number of points; points beyond
+ * arena_capacity are dropped and flagged RPLGPU_SCAN_OUT_TRUNCATED.  Requires voxel_enable. */
+int32_t rplgpu_cloud_arena_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
+                               const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
+                               float *d_arena, uint64_t arena_capacity, uint64_t *d_cursor,
+                               uint64_t *d_scan_start, uint32_t *d_n_points, uint32_t *d_status);
 /* Pack the per-scan regions into one contiguous cloud (scan order) for the xGMI
  * all-gather: d_offsets[B+1] (points), d_packed sized for sum(n_points). */
 int32_t rplgpu_pack_clouds_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t out_stride,

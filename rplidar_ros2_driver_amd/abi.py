@@ -52,6 +52,7 @@ ABI_SYMBOLS = [
     "rplgpu_laserscan_batch_dev",
     "rplgpu_cloud_batch_dev",
     "rplgpu_pack_clouds_dev",
+    "rplgpu_cloud_arena_dev",
     "rplgpu_fill_meta",
     "rplgpu_frame_size",
     "rplgpu_nodes_per_frame",
@@ -156,6 +157,8 @@ def load_library() -> C.CDLL:
     lib.rplgpu_cloud_batch_dev.argtypes = [
         vp, vp, u32, vp, u32, C.POINTER(Params), vp, u32, vp, vp]
     lib.rplgpu_pack_clouds_dev.argtypes = [vp, vp, u32, vp, u32, vp, vp]
+    lib.rplgpu_cloud_arena_dev.argtypes = [
+        vp, vp, u32, vp, u32, C.POINTER(Params), vp, C.c_uint64, vp, vp, vp, vp]
     lib.rplgpu_fill_meta.argtypes = [C.POINTER(Params), u32, C.c_double, C.POINTER(ScanMeta)]
     lib.rplgpu_fill_meta.restype = None
     u8, u64 = C.c_uint8, C.c_uint64
@@ -280,6 +283,14 @@ class RplGpu:
         self._check(self._lib.rplgpu_cloud_batch_dev(
             self._h, d_nodes, n_stride, d_n_per_scan, B, C.byref(params),
             d_xyzi, out_stride, d_n_points, d_status))
+
+    def cloud_arena_dev(self, d_nodes: int, n_stride: int, d_n_per_scan: int, B: int,
+                        params: Params, d_arena: int, arena_capacity: int, d_cursor: int,
+                        d_scan_start: int, d_n_points: int, d_status: int = 0):
+        """Voxelised clouds of the batch in one contiguous arena (no packing pass)."""
+        self._check(self._lib.rplgpu_cloud_arena_dev(
+            self._h, d_nodes, n_stride, d_n_per_scan, B, C.byref(params), d_arena,
+            arena_capacity, d_cursor, d_scan_start, d_n_points, d_status))
 
     def pack_clouds_dev(self, d_xyzi: int, out_stride: int, d_n_points: int, B: int,
                         d_packed: int, d_offsets: int):

@@ -32,7 +32,10 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                               const Tables &T, const uint32_t *keepmask, uint32_t mask_stride,
                               float *xyzi, uint32_t out_stride, uint32_t *n_points,
-                              uint32_t *status);
+                              uint32_t *status, float *arena = nullptr,
+                              unsigned long long arena_capacity = 0,
+                              unsigned long long *arena_cursor = nullptr,
+                              unsigned long long *scan_start = nullptr);
 hipError_t launch_ror_mask(hipStream_t s, const void *nodes, uint32_t n_stride,
                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                            const Tables &T, uint32_t *mask, uint32_t mask_stride);

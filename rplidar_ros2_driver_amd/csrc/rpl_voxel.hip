@@ -215,9 +215,23 @@ __device__ __forceinline__ bool voxel_pair_pass(VoxelLds &L, uint32_t tag, bool 
 // Phase R for one key band: the queue of run records -> output cells in (iy, ix) order.
 // Returns 0 = done (ncell written to *ncell_out), 1 = the band must be bisected (too many rows).
 // ------------------------------------------------------------------------------
+// Where a scan's cells go.  Legacy: a fixed region per scan (xyzi + b*out_stride).  Arena: all
+// scans of a batch share one contiguous cloud; a workgroup reserves exactly the cells of its scan
+// with one atomic on `cursor` once their number is known, so no separate packing pass (and no
+// per-scan slack) is needed; the scans then sit in the arena in completion order and
+// `scan_start[b]` says where.
+struct VoxelArena {
+  float4 *base;                  // null: legacy per-scan regions
+  unsigned long long *cursor;    // next free point
+  unsigned long long capacity;   // points the arena holds
+  unsigned long long *scan_start;
+};
+enum : int { kEmitLegacy = 0, kEmitArenaFirst = 1, kEmitCountOnly = 2, kEmitArenaKnown = 3 };
+
 __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, const double *rcp,
                                               float4 *__restrict__ out, uint32_t out_stride,
-                                              uint32_t b, uint32_t *ncell_out) {
+                                              uint32_t b, uint32_t *ncell_out, int mode,
+                                              const VoxelArena &arena) {
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = clock64();
 #define RPL_MARK(i)                      \
   {                                      \
@@ -363,7 +377,20 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
     // correctly rounded quotient, i.e. the spec's (fp64 sum) / count.
     const double inv_scale = 1.0 / p.vox_scale;  // exact power of two
     const double dL = (double)p.vox_L, dbias = (double)vbias;
-    const uint32_t nemit = min(ncell, out_stride > out_base ? out_stride - out_base : 0u);
+    uint32_t nemit = min(ncell, out_stride > out_base ? out_stride - out_base : 0u);
+    if (mode == kEmitArenaFirst) {  // the only band of this scan: reserve its cells now
+      if (threadIdx.x == 0) {
+        const unsigned long long at = atomicAdd(arena.cursor, (unsigned long long)ncell);
+        L.tmp[28] = (uint32_t)at;
+        L.tmp[29] = (uint32_t)(at >> 32);
+      }
+      __syncthreads();
+      const unsigned long long at = ((unsigned long long)L.tmp[29] << 32) | L.tmp[28];
+      out = arena.base + at;
+      nemit = at >= arena.capacity ? 0u : (uint32_t)min((unsigned long long)ncell, arena.capacity - at);
+    } else if (mode == kEmitCountOnly) {
+      nemit = 0u;  // several bands: first learn the total, the cells are written in a second go
+    }
     for (uint32_t c = threadIdx.x; c < nemit; c += kBlock) {
       uint32_t r = L.bucket[c];
       // a cell is 1.13 records on average: fetch the head and the two records behind it in one
@@ -419,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
     float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
-    uint32_t *__restrict__ status, uint32_t B) {
+    uint32_t *__restrict__ status, uint32_t B, VoxelArena arena) {
   __shared__ VoxelLds L;
 
   if (threadIdx.x < 256) L.rcp[threadIdx.x] = T.rcp[threadIdx.x];  // (first barrier below publishes it)
@@ -429,13 +456,17 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
   for (uint32_t b = blockIdx.x; b < B;) {
   const uint32_t n = min(n_per_scan[b], kMaxN);
   const uint2 *scan = nodes + (size_t)b * n_stride;
-  float4 *out = xyzi + (size_t)b * out_stride;
+  float4 *out = arena.base ? arena.base : xyzi + (size_t)b * out_stride;
+  int emit_mode = arena.base ? kEmitArenaFirst : kEmitLegacy;
+  unsigned long long arena_at = 0ull;  // first point of this scan in the arena
 
   if (threadIdx.x < 16) L.misc[threadIdx.x] = 0u;
   if (threadIdx.x == 0) {
     L.band_lo[0] = 0u;
     L.band_hi[0] = 0xFFFFFFFEu;
     L.misc[3] = 1u;  // stack pointer
+    L.tmp[28] = 0u;  // arena reservation of this scan (stays 0 for a scan without cells)
+    L.tmp[29] = 0u;
   }
   __syncthreads();
 
@@ -555,20 +586,48 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
     };
     if (L.misc[2]) {
       bisect();
+      if (emit_mode == kEmitArenaFirst) emit_mode = kEmitCountOnly;
       continue;
     }
 
     // ---- phase R (out of line) ----------------------------------------------------------
     uint32_t ncell = 0;
-    if (voxel_reduce(L, p, T.rcp, out, out_stride, b, &ncell)) {
+    uint32_t out_limit = out_stride;  // cells this scan may write
+    if (emit_mode == kEmitArenaKnown) {
+      const unsigned long long room = arena_at >= arena.capacity ? 0ull : arena.capacity - arena_at;
+      out_limit = (uint32_t)min(room, 0xFFFFFFFFull);
+    } else if (emit_mode != kEmitLegacy) {
+      out_limit = 0xFFFFFFFFu;  // (first band: bounded inside, at the reservation)
+    }
+    if (voxel_reduce(L, p, T.rcp, out, out_limit, b, &ncell, emit_mode, arena)) {
       bisect();
+      if (emit_mode == kEmitArenaFirst) emit_mode = kEmitCountOnly;
       continue;
     }
+    if (emit_mode == kEmitArenaFirst)  // (the reservation made inside voxel_reduce)
+      arena_at = ((unsigned long long)L.tmp[29] << 32) | L.tmp[28];
     const uint32_t out_base = L.misc[7];
     __syncthreads();
     if (threadIdx.x == 0) L.misc[7] = out_base + ncell;
     __syncthreads();
     t_mark = clock64();
+    if (emit_mode == kEmitCountOnly && L.misc[3] == 0u) {
+      // every band counted: reserve the scan's cells in one piece and go through the bands
+      // again (same bisections, they depend on the data only), this time writing
+      if (threadIdx.x == 0) {
+        const unsigned long long at = atomicAdd(arena.cursor, (unsigned long long)L.misc[7]);
+        L.tmp[28] = (uint32_t)at;
+        L.tmp[29] = (uint32_t)(at >> 32);
+        L.band_lo[0] = 0u;
+        L.band_hi[0] = 0xFFFFFFFEu;
+        L.misc[3] = 1u;
+        L.misc[7] = 0u;
+      }
+      __syncthreads();
+      arena_at = ((unsigned long long)L.tmp[29] << 32) | L.tmp[28];
+      out = arena.base + arena_at;
+      emit_mode = kEmitArenaKnown;
+    }
   }
   if (p.dbg && threadIdx.x == 0) atomicAdd(&p.dbg[8 * b], tacc[0]);
 #undef RPL_MARK
@@ -577,8 +636,16 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t total = L.misc[7];
-    n_points[b] = min(total, out_stride);
-    if (status) status[b] = L.misc[1] | ((total > out_stride) ? RPLGPU_SCAN_OUT_TRUNCATED : 0u);
+    if (arena.base) {
+      const unsigned long long room = arena_at >= arena.capacity ? 0ull : arena.capacity - arena_at;
+      const uint32_t kept = (uint32_t)min((unsigned long long)total, room);
+      arena.scan_start[b] = arena_at;
+      n_points[b] = kept;
+      if (status) status[b] = L.misc[1] | (kept < total ? RPLGPU_SCAN_OUT_TRUNCATED : 0u);
+    } else {
+      n_points[b] = min(total, out_stride);
+      if (status) status[b] = L.misc[1] | ((total > out_stride) ? RPLGPU_SCAN_OUT_TRUNCATED : 0u);
+    }
   }
   if (threadIdx.x == 0) L.tmp[31] = gridDim.x + atomicAdd(&T.work_ctr[0], 1u);
   __syncthreads();  // LDS is reused by the next scan
@@ -633,8 +700,14 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                               const Tables &T, const uint32_t *keepmask, uint32_t mask_stride,
                               float *xyzi, uint32_t out_stride, uint32_t *n_points,
-                              uint32_t *status) {
+                              uint32_t *status, float *arena, unsigned long long arena_capacity,
+                              unsigned long long *arena_cursor, unsigned long long *scan_start) {
   if (B == 0) return hipSuccess;
+  VoxelArena ar;
+  ar.base = (float4 *)arena;
+  ar.cursor = arena_cursor;
+  ar.capacity = arena_capacity;
+  ar.scan_start = scan_start;
   static int n_cu = 0;  // one persistent workgroup per CU
   if (n_cu == 0) {
     int dev = 0;
@@ -648,7 +721,7 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
 #define RPL_LAUNCH_VOXEL(FD, SF)                                                              \
   hipLaunchKernelGGL((k_cloud_voxel<FD, SF>), dim3(grid), dim3(kBlock), 0, s, (const uint2 *)nodes, \
                      n_stride, n_per_scan, p, T, keepmask, mask_stride, (float4 *)xyzi, out_stride, \
-                     n_points, status, B)
+                     n_points, status, B, ar)
   if (p.fast_div) {
     if (p.cell_range_safe) RPL_LAUNCH_VOXEL(true, true); else RPL_LAUNCH_VOXEL(true, false);
   } else {

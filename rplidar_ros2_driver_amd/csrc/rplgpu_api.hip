@@ -432,13 +432,10 @@ int32_t rplgpu_laserscan_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nod
                        d_beam_count);
 }
 
-int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
-                               const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
-                               float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,
-                               uint32_t *d_status) {
-  int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
-  if (rc) return rc;
-  if (!p || !d_xyzi || !d_n_points || out_stride == 0) return RPLGPU_ERR_INVALID_ARG;
+// parameter checks, divisor validation and the E5 mask shared by the cloud entry points
+static int32_t prepare_cloud(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
+                             const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
+                             rpl::KParams *kp_out, const uint32_t **mask_out) {
   if (p->ror_enable && !(p->ror_radius > 0.0f && p->ror_radius <= 1.0e6f)) {
     h->err = "ror_radius must be in (0, 1e6] m";
     return RPLGPU_ERR_INVALID_ARG;
@@ -459,14 +456,52 @@ int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
     kp.fast_div = (h->div4000_ok && h->leaf_ok) ? 1 : 0;
   }
   kp.dbg = h->dbg;
-  const uint32_t *mask = nullptr;
+  *mask_out = nullptr;
   if (p->ror_enable) {  // E5 before E4: per-sample keep bits, then the cloud kernels apply them
     if (!h->d_rormask)
       RPL_HIP(h, hipMalloc((void **)&h->d_rormask, (size_t)h->max_b * kMaskStride * 4u));
     RPL_HIP(h, rpl::launch_ror_mask(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
                                     tables_of(h), h->d_rormask, kMaskStride));
-    mask = h->d_rormask;
+    *mask_out = h->d_rormask;
   }
+  *kp_out = kp;
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_cloud_arena_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
+                               const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
+                               float *d_arena, uint64_t arena_capacity, uint64_t *d_cursor,
+                               uint64_t *d_scan_start, uint32_t *d_n_points, uint32_t *d_status) {
+  int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
+  if (rc) return rc;
+  if (!p || !d_arena || !d_cursor || !d_scan_start || !d_n_points) return RPLGPU_ERR_INVALID_ARG;
+  if (!p->voxel_enable) {
+    h->err = "rplgpu_cloud_arena_dev needs voxel_enable";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  rpl::KParams kp;
+  const uint32_t *mask = nullptr;
+  if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
+  RPL_HIP(h, hipMemsetAsync(d_cursor, 0, 8, h->stream));
+  static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "64-bit cursor");
+  RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
+                                     tables_of(h), mask, kMaskStride, nullptr, 0, d_n_points,
+                                     d_status, d_arena, arena_capacity,
+                                     reinterpret_cast<unsigned long long *>(d_cursor),
+                                     reinterpret_cast<unsigned long long *>(d_scan_start)));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
+                               const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
+                               float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,
+                               uint32_t *d_status) {
+  int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
+  if (rc) return rc;
+  if (!p || !d_xyzi || !d_n_points || out_stride == 0) return RPLGPU_ERR_INVALID_ARG;
+  rpl::KParams kp;
+  const uint32_t *mask = nullptr;
+  if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
   RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(h),
                                p->voxel_enable != 0, mask, kMaskStride, d_xyzi, out_stride,
                                d_n_points, d_status));

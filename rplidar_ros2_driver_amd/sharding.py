@@ -28,13 +28,17 @@ def shard_range(total: int, world_size: int, rank: int) -> Tuple[int, int]:
 
 
 def allgather_clouds(packed: torch.Tensor, n_points: int, scan_counts: torch.Tensor,
-                     group=None):
+                     group=None, scan_starts: torch.Tensor | None = None):
     """All-gather variable-length clouds.
 
-    packed       (cap, 4) float32 — this rank's packed cloud, first ``n_points`` rows valid
+    packed       (cap, 4) float32 — this rank's contiguous cloud, first ``n_points`` rows valid
     scan_counts  (B_local,) int32/int64 — points per local scan (so receivers can split)
-    Returns ``(clouds, counts)``: per-rank list of ``(n_r, 4)`` tensors (views into one
-    receive buffer) and per-rank list of per-scan counts, in rank == scan order.
+    scan_starts  optional (B_local,) int64 — first row of every local scan when the cloud is an
+                 *arena* (``rplgpu_cloud_arena_dev``: scans in completion order); without it the
+                 scans are taken to lie back to back in scan order (``rplgpu_pack_clouds_dev``)
+    Returns ``(clouds, counts)`` or, with ``scan_starts``, ``(clouds, counts, starts)``:
+    per-rank lists of ``(n_r, 4)`` tensors (views into one receive buffer) and of per-scan
+    counts / starts, in rank == scan order.
     """
     world = dist.get_world_size(group)
     dev = packed.device
@@ -54,21 +58,33 @@ def allgather_clouds(packed: torch.Tensor, n_points: int, scan_counts: torch.Ten
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view(world, max_pts, 4)
 
-    cnt_send = torch.zeros(max_scans, dtype=torch.int64, device=dev)
-    cnt_send[: scan_counts.numel()] = scan_counts.to(torch.int64)
-    cnt_recv = torch.empty(world * max_scans, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(cnt_recv, cnt_send, group=group)
-    cnt_recv = cnt_recv.view(world, max_scans)
+    # per-scan counts (and arena starts) travel in one small exchange
+    cols = 2 if scan_starts is not None else 1
+    cnt_send = torch.zeros(cols, max_scans, dtype=torch.int64, device=dev)
+    cnt_send[0, : scan_counts.numel()] = scan_counts.to(torch.int64)
+    if scan_starts is not None:
+        cnt_send[1, : scan_starts.numel()] = scan_starts.to(torch.int64)
+    cnt_recv = torch.empty(world * cols * max_scans, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(cnt_recv, cnt_send.view(-1), group=group)
+    cnt_recv = cnt_recv.view(world, cols, max_scans)
 
     clouds: List[torch.Tensor] = []
     counts: List[torch.Tensor] = []
+    starts: List[torch.Tensor] = []
     for r in range(world):
         clouds.append(recv[r, : int(metas_h[r, 0])])
-        counts.append(cnt_recv[r, : int(metas_h[r, 1])])
+        counts.append(cnt_recv[r, 0, : int(metas_h[r, 1])])
+        if scan_starts is not None:
+            starts.append(cnt_recv[r, 1, : int(metas_h[r, 1])])
+    if scan_starts is not None:
+        return clouds, counts, starts
     return clouds, counts
 
 
-def split_by_scan(cloud: torch.Tensor, counts: torch.Tensor) -> List[torch.Tensor]:
-    """Split one rank's packed cloud back into per-scan clouds."""
+def split_by_scan(cloud: torch.Tensor, counts: torch.Tensor,
+                  starts: torch.Tensor | None = None) -> List[torch.Tensor]:
+    """Split one rank's contiguous cloud back into per-scan clouds (``starts``: arena layout)."""
     sizes = [int(c) for c in counts.cpu().tolist()]
-    return list(torch.split(cloud[: sum(sizes)], sizes)) if sizes else []
+    if starts is None:
+        return list(torch.split(cloud[: sum(sizes)], sizes)) if sizes else []
+    return [cloud[int(a): int(a) + n] for a, n in zip(starts.cpu().tolist(), sizes)]

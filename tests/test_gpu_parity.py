@@ -297,6 +297,60 @@ def test_voxel_more_cells_than_table(gpu, oracle):
     assert got[:, 3].tobytes() == want[:, 3].tobytes()
 
 
+def test_cloud_arena_equals_per_scan_regions(gpu):
+    """rplgpu_cloud_arena_dev: the clouds of a batch in one contiguous arena, every scan
+    reserving exactly its cells.  Each scan's slice must be byte-identical to what the
+    per-scan-region entry point writes; scans of very different size (incl. one that needs key
+    bands, i.e. the count-then-write path, and an all-invalid one) share the arena without gaps;
+    a too small arena truncates and flags instead of overrunning."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    B, n = 40, 32000
+    batch = synth.make_batch(61, B, n)
+    batch[7] = synth.make_scan(5, 0, n, kind="uniform", invalid_p=0.0)   # > table: key bands
+    batch[19]["dist_mm_q2"] = 0                                           # nothing kept
+    lens = np.full(B, n, np.int32)
+    lens[3] = 777
+    for leaf in (0.05, 0.01):
+        p = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1, voxel_leaf=leaf)
+        d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+        d_len = torch.from_numpy(lens).to(dev)
+        stride = n
+        d_xyzi = torch.zeros(B, stride, 4, dtype=torch.float32, device=dev)
+        d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+        gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_xyzi.data_ptr(),
+                            stride, d_np.data_ptr(), d_st.data_ptr())
+        gpu.synchronize()
+        npts = d_np.cpu().numpy().astype(np.int64)
+        assert int(d_st.max()) == 0 and npts[19] == 0 and npts[7] > 7168
+        total = int(npts.sum())
+        for cap in (total + 1000, total, total // 2):
+            d_arena = torch.full((max(cap, 1) + 16, 4), -1.0, dtype=torch.float32, device=dev)
+            d_cur = torch.full((1,), 123, dtype=torch.int64, device=dev)
+            d_start = torch.zeros(B, dtype=torch.int64, device=dev)
+            d_np2 = torch.zeros(B, dtype=torch.int32, device=dev)
+            d_st2 = torch.zeros(B, dtype=torch.int32, device=dev)
+            gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_arena.data_ptr(),
+                                cap, d_cur.data_ptr(), d_start.data_ptr(), d_np2.data_ptr(),
+                                d_st2.data_ptr())
+            gpu.synchronize()
+            assert int(d_cur[0]) == total  # every scan reserved exactly its cells
+            start = d_start.cpu().numpy()
+            np2, st2 = d_np2.cpu().numpy().astype(np.int64), d_st2.cpu().numpy()
+            arena, ref = d_arena.cpu().numpy(), d_xyzi.cpu().numpy()
+            assert np.all(arena[cap:] == -1.0)  # nothing written past the capacity
+            # the reservations tile [0, total) without gaps or overlaps
+            nz = np.nonzero(npts)[0]  # (a scan without cells reserves nothing; its start is 0)
+            order = nz[np.argsort(start[nz], kind="stable")]
+            assert np.array_equal(np.cumsum(npts[order]) - npts[order], start[order])
+            for b in range(B):
+                kept = int(min(max(cap - start[b], 0), npts[b]))
+                assert np2[b] == kept
+                assert bool(st2[b] & abi.SCAN_OUT_TRUNCATED) == (kept < npts[b])
+                assert arena[start[b]: start[b] + kept].tobytes() == ref[b, :kept].tobytes()
+
+
 def test_voxel_cell_range_is_reported(gpu):
     # |cell index| must stay below 32767: 40 m / 1 mm leaf does not -> flagged, not silent
     nodes = synth.make_scan(5, 1, 4000, invalid_p=0.0, r0_range=(35.0, 36.0))

@@ -71,6 +71,22 @@ def _worker(rank, world, port, total, n, q):
         ref = _local_clouds(0, total, n)
         ok = len(full) == total and all(
             f.numpy().tobytes() == w.tobytes() for f, w in zip(full, ref))
+        # arena layout (rplgpu_cloud_arena_dev): the local scans lie in the cloud in completion
+        # order, here reversed, and their starts travel with the counts
+        order = list(range(len(clouds)))[::-1]
+        starts = torch.zeros(len(clouds), dtype=torch.int64)
+        arena = torch.zeros(int(counts.sum()) + 3, 4)
+        at = 0
+        for s_ in order:
+            starts[s_] = at
+            arena[at: at + len(clouds[s_])] = torch.from_numpy(clouds[s_])
+            at += len(clouds[s_])
+        a_clouds, a_counts, a_starts = allgather_clouds(arena, at, counts, scan_starts=starts)
+        full2 = []
+        for r in range(world):
+            full2 += split_by_scan(a_clouds[r], a_counts[r], a_starts[r])
+        ok = ok and len(full2) == total and all(
+            f.numpy().tobytes() == w.tobytes() for f, w in zip(full2, ref))
         q.put((rank, bool(ok), len(full)))
     finally:
         dist.destroy_process_group()
