@@ -179,9 +179,17 @@ __device__ __forceinline__ bool voxel_pair_pass(VoxelLds &L, uint32_t tag, bool 
   // lane l+1's first key; lane 63 sees a value no key can take (its run always ends)
   const uint32_t nextA = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)keyA, 0x130,
                                                                0xF, 0xF, false);  // wave_shl:1
-  const bool e1 = okA && (keyA != keyB);   // a run ends at A
-  const bool e2 = okB && (keyB != nextA);  // a run ends at B
-  const uint64_t m1 = __builtin_amdgcn_ballot_w64(e1), m2 = __builtin_amdgcn_ballot_w64(e2);
+  // run-end masks built in scalar registers: (sample kept) & (key differs from the next one).
+  // Written with explicit compares because `ballot(a && b)` is materialised by the compiler as
+  // v_cndmask + v_cmp per mask; the per-lane predicates for the stores come back from the
+  // masks with inverse_ballot (one s_and_saveexec each).
+  uint64_t ne1, ne2;
+  asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(ne1) : "v"(keyA), "v"(keyB));
+  asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(ne2) : "v"(keyB), "v"(nextA));
+  const uint64_t m1 = __builtin_amdgcn_ballot_w64(okA) & ne1;  // a run ends at A
+  const uint64_t m2 = __builtin_amdgcn_ballot_w64(okB) & ne2;  // a run ends at B
+  const bool e1 = __builtin_amdgcn_inverse_ballot_w64(m1);
+  const bool e2 = __builtin_amdgcn_inverse_ballot_w64(m2);
   const uint32_t total = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
   if (total == 0u) return true;  // wave-uniform: nothing kept in this pass
   // reserve queue slots: one LDS atomic by lane 0, its round trip overlaps the scans below
