@@ -277,6 +277,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1: the same K steps without the exchange (SURVEY.md §8e asks for both curves)
+    compute_only = None
+    if world > 1:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
+                                d_arena.data_ptr(), arena_cap, d_cursor.data_ptr(),
+                                d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+        fence()
+        el2 = time.perf_counter() - t0
+        t = torch.tensor([el2], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el2 = float(t.item())
+        compute_only = {"value": round(B_total * n / (el2 / args.steps) / 1e6, 1),
+                        "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                        "note": "same steps without the all-gather of the clouds"}
+
     status = int(d_st.max().item())
     cells_local = int(d_cursor.item())
 
@@ -395,6 +413,7 @@ def main():
                 "algorithmic_bytes": algo_bytes,
             },
             "cpu_baseline": cpu,
+            "compute_only": compute_only,
             "status_bits": status,
             "cells_out_rank0": cells_local,
             "host_gen_s": round(gen_s, 2),
