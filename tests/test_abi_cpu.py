@@ -88,3 +88,35 @@ def test_synth_is_deterministic_and_shardable():
     assert np.all(a["flag"][:, 0] == 1)
     u = synth.make_scan(9, 0, 2000, kind="uniform", jitter=500, rotate=True)
     assert np.any(np.diff(u["angle_z_q14"].astype(np.int32)) < 0)  # really unsorted
+
+
+def test_host_framer_matches_oracle_framing(oracle):
+    """rplgpu_frame_stream (host code of the product, no GPU involved) against the oracle's
+    restatement of the unpackers' framing rules (pinned against the genuine SDK) on byte soups
+    built to confuse a framer: random bytes, sync-looking bytes everywhere, valid streams with
+    holes, truncated tails."""
+    from rplidar_ros2_driver_amd import capsules as cp
+
+    rng = np.random.default_rng(12)
+    checked = 0
+    for ans in (0x81, 0x82, 0x83, 0x84, 0x85, 0x86):
+        S = cp.FRAME_SIZE[ans]
+        soups = [rng.integers(0, 256, 4000, dtype=np.uint8),
+                 np.full(3 * S + 7, 0xA5, np.uint8),
+                 np.tile(np.array([0xA3, 0x5C], np.uint8), 2 * S),
+                 np.tile(np.array([0xA0, 0xA0, 0x50], np.uint8), S),
+                 (rng.integers(0, 2, 5000, dtype=np.uint8) * 0xFF),
+                 np.zeros(0, np.uint8), np.array([0xA5], np.uint8)]
+        good = cp.make_stream(ans, 30 if ans != 0x81 else 400, 3, payload="random")
+        for cut in (0, 1, S - 1, S, S + 1, 2 * S + 3):
+            soups.append(np.concatenate([good[cut:], rng.integers(0, 256, 11, dtype=np.uint8),
+                                         good[: len(good) - cut]]))
+        for s in soups:
+            o1, g1 = abi.frame_stream(ans, s)
+            o2, g2 = oracle.frame_stream(ans, s)
+            assert list(o1) == list(o2) and list(g1) == list(g2), (hex(ans), len(s))
+            checked += len(o1)
+    assert checked > 1000
+    lib = abi.load_library()
+    assert lib.rplgpu_frame_size(0x42) == 0 and lib.rplgpu_nodes_per_frame(0x85) == 40
+    assert lib.rplgpu_decode_max_frames(0x86) == 512 and lib.rplgpu_decode_max_frames(0x85) == 2048
