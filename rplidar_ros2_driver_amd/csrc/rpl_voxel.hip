@@ -288,6 +288,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
       if (ok) {
         rmin = min(rmin, m.x >> 16);
         rmax = max(rmax, m.x >> 16);
+        atomicAdd(&L.rowstart[(m.x >> 16) & (kRowCap - 1u)], 1u);  // counting sort over rows
       }
     }
     mine[k] = m;
@@ -298,7 +299,6 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
     atomicMin(&L.misc[4], rmin);
     atomicMax(&L.misc[5], rmax);
   }
-  for (uint32_t t = threadIdx.x; t < kRowCap; t += kBlock) L.rowstart[t] = 0u;
   __syncthreads();  // every prefix was read before any record slot is rewritten below
   RPL_MARK(1)
   rmin = L.misc[4];
@@ -309,20 +309,18 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
       flush_dbg();
       return 1u;
     }
-    // counting sort over rows
-#pragma unroll
-    for (int k = 0; k < (int)kRecPerThread; ++k)
-      if (mine[k].x != kEmptyKey) atomicAdd(&L.rowstart[(mine[k].x >> 16) - rmin], 1u);
-    __syncthreads();
     RPL_MARK(2)
-    {  // exclusive scan over kRowCap = 2 rows per thread
-      uint32_t r0 = L.rowstart[2 * threadIdx.x], r1 = L.rowstart[2 * threadIdx.x + 1];
+    {  // exclusive scan over the kRowCap rows in row order (2 per thread); a row iy lives at
+       // iy mod kRowCap, so scan position j is the physical row (j + rmin) mod kRowCap
+      const uint32_t p0 = (2u * threadIdx.x + rmin) & (kRowCap - 1u);
+      const uint32_t p1 = (2u * threadIdx.x + 1u + rmin) & (kRowCap - 1u);
+      uint32_t r0 = L.rowstart[p0], r1 = L.rowstart[p1];
       uint32_t tot;
       uint32_t ex = block_excl_scan(r0 + r1, L.tmp, &tot);
-      L.rowstart[2 * threadIdx.x] = ex;
-      L.rowstart[2 * threadIdx.x + 1] = ex + r0;
-      L.rowfill[2 * threadIdx.x] = ex;
-      L.rowfill[2 * threadIdx.x + 1] = ex + r0;
+      L.rowstart[p0] = ex;
+      L.rowstart[p1] = ex + r0;
+      L.rowfill[p0] = ex;
+      L.rowfill[p1] = ex + r0;
     }
     __syncthreads();
     RPL_MARK(3)
@@ -330,7 +328,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
     for (int k = 0; k < (int)kRecPerThread; ++k) {
       if (mine[k].x != kEmptyKey) {
         uint32_t idx = threadIdx.x + (uint32_t)k * kBlock;
-        uint32_t pos = atomicAdd(&L.rowfill[(mine[k].x >> 16) - rmin], 1u);
+        uint32_t pos = atomicAdd(&L.rowfill[(mine[k].x >> 16) & (kRowCap - 1u)], 1u);
         L.bucket[pos] = (mine[k].x << 16) | idx;  // (ix, record index): unique
       }
     }
@@ -343,7 +341,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
     for (int k = 0; k < (int)kRecPerThread; ++k) {
       if (mine[k].x != kEmptyKey) {
         const uint32_t idx = threadIdx.x + (uint32_t)k * kBlock;
-        const uint32_t row = (mine[k].x >> 16) - rmin;
+        const uint32_t row = (mine[k].x >> 16) & (kRowCap - 1u);
         const uint32_t me = (mine[k].x << 16) | idx;
         const uint32_t s0 = L.rowstart[row], s1 = L.rowfill[row];
         uint32_t rank = s0;
@@ -519,6 +517,9 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
       L.misc[4] = 0xFFFFFFFFu;
       L.misc[5] = 0u;
     }
+    // the row histogram of this band is filled while the records are loaded in phase R (rows
+    // are addressed modulo kRowCap, so the first row need not be known yet)
+    for (uint32_t t = threadIdx.x; t < kRowCap; t += kBlock) L.rowstart[t] = 0u;
     __syncthreads();
 
     // ---- phase S: raw pairs two rounds ahead, table entries one round ahead -------------
