@@ -369,6 +369,28 @@ def main():
 
     if not args.no_decode and rank == 0:
         extra.update(decode_stage(gpu, dev, stream, args.cpu_seconds))
+    if not args.no_laserscan and rank == 0:
+        # secondary: BASELINE config 5 shape — 8 sensors x 32 frames of 32 000 samples with 1 cm
+        # range noise, E5 radius-outlier removal + voxel grid into one fused cloud (arena)
+        Bc = 256
+        c5 = synth.make_batch(args.seed + 5, Bc, n, noise_m=0.01)
+        d_c5 = torch.from_numpy(c5.view(np.uint8).reshape(Bc, n * 8)).to(dev)
+        d_len5 = torch.full((Bc,), n, dtype=torch.int32, device=dev)
+        p5 = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1,
+                             voxel_leaf=0.05, ror_enable=1, ror_radius=0.10, ror_min_neighbors=2)
+        ts = []
+        for it in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            gpu.cloud_arena_dev(d_c5.data_ptr(), n, d_len5.data_ptr(), Bc, p5, d_arena.data_ptr(),
+                                arena_cap, d_cursor.data_ptr(), d_start.data_ptr(),
+                                d_np.data_ptr(), d_st.data_ptr())
+            b.record(stream)
+            torch.cuda.synchronize(dev)
+            ts.append(a.elapsed_time(b))
+        extra["c5_ror_voxel_ms_256scans"] = round(min(ts[1:]), 4)
+        extra["c5_ror_voxel_mpts"] = round(Bc * n / min(ts[1:]) / 1e3, 1)
+        del d_c5
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
