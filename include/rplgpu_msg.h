@@ -1,0 +1,135 @@
+/*
+ * rplgpu_msg.h — publish-ready messages: the LaserScan / PointCloud2
+ * the path produces, laid out as the serialised (CDR) messages a ROS 2 publisher sends, so the
+ * node hands the buffer to `publish(const rclcpp::SerializedMessage &)` without building a typed
+ * message and without a further copy.
+ *
+ * What it replaces in the reference, per scan:
+ *   sensor_msgs::msg::LaserScan scan_msg; ... scan_msg.ranges.assign / [index] = ...;
+ *   scan_pub_->publish(scan_msg);                  src/rplidar_node.cpp:618-682
+ * i.e. two std::vector<float> fills, then the middleware's own serialisation pass over them
+ * (rosidl_typesupport_fastrtps_cpp + eProsima Fast-CDR; third-party, not in the reference tree:
+ * the README names ROS 2 Jazzy, whose default rmw serialises with Fast-CDR 2.2.x as XCDR
+ * version 1, PLAIN_CDR, little endian).  Here the device results are copied ONCE, by DMA,
+ * straight to their final offsets inside the serialised message; for device-resident batches
+ * a kernel assembles B messages in HBM.
+ *
+ * Wire format (OMG DDS-XTypes 1.3 §7.4.1 "plain CDR" as Fast-CDR emits it for ROS 2):
+ *   4-byte encapsulation header 00 01 00 00 (CDR little endian, no options); every primitive
+ *   aligned to its size counted from the byte AFTER that header; string = uint32 length
+ *   including the terminating NUL, the bytes, the NUL; sequence<T> = uint32 element count, the
+ *   elements; bool / uint8 = one byte; no padding after the last member.
+ *   std_msgs/Header = { int32 stamp.sec, uint32 stamp.nanosec, string frame_id }.
+ *   sensor_msgs/LaserScan = Header, float32 angle_min, angle_max, angle_increment,
+ *     time_increment, scan_time, range_min, range_max, float32[] ranges, float32[] intensities.
+ *   sensor_msgs/PointCloud2 = Header, uint32 height, width, PointField[] fields
+ *     ({string name, uint32 offset, uint8 datatype, uint32 count}), bool is_bigendian,
+ *     uint32 point_step, row_step, uint8[] data, bool is_dense — with the E3 layout of
+ *     fields x,y,z,intensity FLOAT32 (=7) at 0/4/8/12, point_step 16, height 1,
+ *     width = #points, row_step = 16*width, is_bigendian false, is_dense true.
+ *
+ * Parity: the reference holds no serialised vectors and Fast-CDR is not in this image, so the
+ * byte layout is checked against an independent restatement of the format (oracle/cdr_oracle.py)
+ * and hand-derived known-answer bytes — "parity unpinned" for the wire format itself; the float
+ * payloads inside the messages are the same bit-exact results as rplgpu.h's entry points.
+ */
+#ifndef RPLGPU_MSG_H_
+#define RPLGPU_MSG_H_
+
+#include "rplgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rplgpu_stamp {
+  int32_t sec;      /* builtin_interfaces/Time */
+  uint32_t nanosec;
+} rplgpu_stamp_t;
+
+/* Byte offsets inside one serialised LaserScan (from the first byte of the encapsulation
+ * header).  All are multiples of 4. */
+typedef struct rplgpu_laserscan_layout {
+  uint32_t scalars_off;         /* angle_min; the 7 float32 scalars follow each other */
+  uint32_t ranges_len_off;      /* uint32 ranges.size() */
+  uint32_t ranges_off;          /* ranges[0] */
+  uint32_t intensities_len_off; /* uint32 intensities.size() */
+  uint32_t intensities_off;     /* intensities[0] */
+  uint32_t total_len;           /* serialised size */
+} rplgpu_laserscan_layout_t;
+
+/* Byte offsets inside one serialised PointCloud2. */
+typedef struct rplgpu_cloud_layout {
+  uint32_t width_off;    /* uint32 width (height precedes it) */
+  uint32_t row_step_off; /* uint32 row_step (point_step precedes it) */
+  uint32_t data_len_off; /* uint32 data.size() = 16 * n_points */
+  uint32_t data_off;     /* first point; a multiple of 4 */
+  uint32_t is_dense_off; /* the last byte */
+  uint32_t total_len;
+} rplgpu_cloud_layout_t;
+
+/* ---- host-only: layout and everything but the bulk arrays (no device needed) ------------- */
+/* frame_id_len = strlen(frame_id).  Returns RPLGPU_ERR_INVALID_ARG if the message would not
+ * fit 32-bit offsets. */
+int32_t rplgpu_msg_laserscan_layout(size_t frame_id_len, uint32_t count,
+                                    rplgpu_laserscan_layout_t *out);
+int32_t rplgpu_msg_cloud_layout(size_t frame_id_len, uint32_t n_points,
+                                rplgpu_cloud_layout_t *out);
+/* Write encapsulation header, Header, the 7 scalars of `meta` and both sequence lengths
+ * (meta->count) into msg[0..cap); the float arrays at ranges_off / intensities_off are left
+ * for the caller (or the DMA) to fill.  RPLGPU_ERR_CAPACITY if total_len > cap. */
+int32_t rplgpu_msg_laserscan_header(const char *frame_id, rplgpu_stamp_t stamp,
+                                    const rplgpu_scan_meta_t *meta, uint8_t *msg, size_t cap,
+                                    rplgpu_laserscan_layout_t *layout);
+/* Write everything of a PointCloud2 but the points (16 * n_points bytes at data_off). */
+int32_t rplgpu_msg_cloud_header(const char *frame_id, rplgpu_stamp_t stamp, uint32_t n_points,
+                                uint8_t *msg, size_t cap, rplgpu_cloud_layout_t *layout);
+
+/* ---- pinned message buffers ---------------------------------------------------------------- */
+/* Page-locked host memory: a message buffer obtained here receives the device results by DMA
+ * with no staging copy (any other host pointer works too, through the runtime's staging). */
+int32_t rplgpu_host_alloc(rplgpu_handle_t h, size_t bytes, void **out);
+int32_t rplgpu_host_free(rplgpu_handle_t h, void *p);
+
+/* ---- single scan: raw nodes -> one serialised message in a HOST buffer --------------------- */
+/* == the body of publish_scan (src/rplidar_node.cpp:568-680) plus the serialisation of the
+ * result.  *msg_len = 0 and meta->published = 0 when publish_scan would have returned without
+ * publishing (:561,:611).  cap must hold the message for the worst case count == n
+ * (rplgpu_msg_laserscan_layout(strlen(frame_id), n)). */
+int32_t rplgpu_scan_to_laserscan_msg(rplgpu_handle_t h, const rplgpu_node_t *nodes, size_t n,
+                                     const rplgpu_params_t *p, double scan_duration,
+                                     const char *frame_id, rplgpu_stamp_t stamp, uint8_t *msg,
+                                     size_t cap, size_t *msg_len, rplgpu_scan_meta_t *meta);
+/* ext E1-E5 -> serialised PointCloud2 (an empty cloud is a valid message: width 0). */
+int32_t rplgpu_scan_to_cloud_msg(rplgpu_handle_t h, const rplgpu_node_t *nodes, size_t n,
+                                 const rplgpu_params_t *p, const char *frame_id,
+                                 rplgpu_stamp_t stamp, uint8_t *msg, size_t cap, size_t *msg_len,
+                                 uint32_t *n_points, uint32_t *status);
+
+/* ---- batches: B serialised messages assembled in DEVICE memory ----------------------------- */
+/* From the outputs of rplgpu_laserscan_batch_dev (same d_ranges / d_intensities / n_stride /
+ * d_beam_count): message b at d_msgs + b*msg_stride (msg_stride a multiple of 4), its length
+ * in d_msg_len[b]; 0 = not published (beam count 0) or msg_stride too small (then d_status[b]
+ * gets RPLGPU_SCAN_OUT_TRUNCATED).  The scalars are computed on the device with the
+ * reference's own expressions (:623-627,:634-638,:665-669; IEEE fp64 divides).
+ * d_stamps: B stamps; d_scan_duration: B doubles; both device pointers. */
+int32_t rplgpu_laserscan_msgs_dev(rplgpu_handle_t h, const float *d_ranges,
+                                  const float *d_intensities, uint32_t n_stride,
+                                  const uint32_t *d_beam_count, uint32_t B,
+                                  const rplgpu_params_t *p, const char *frame_id,
+                                  const rplgpu_stamp_t *d_stamps, const double *d_scan_duration,
+                                  uint8_t *d_msgs, uint32_t msg_stride, uint32_t *d_msg_len,
+                                  uint32_t *d_status);
+/* From the outputs of rplgpu_cloud_batch_dev (d_scan_start = NULL: scan b at
+ * d_xyzi + b*out_stride points) or rplgpu_cloud_arena_dev (d_xyzi = the arena, d_scan_start =
+ * its per-scan starts).  Same message slots as above. */
+int32_t rplgpu_cloud_msgs_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t out_stride,
+                              const uint64_t *d_scan_start, const uint32_t *d_n_points,
+                              uint32_t B, const char *frame_id, const rplgpu_stamp_t *d_stamps,
+                              uint8_t *d_msgs, uint32_t msg_stride, uint32_t *d_msg_len,
+                              uint32_t *d_status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPLGPU_MSG_H_ */

@@ -4,7 +4,8 @@ Only what the hot path needs lives here:
 
 * ``csrc/``      hand-written HIP kernels + the extern "C" ABI (``include/rplgpu.h``)
 * ``lib/``       the built ``librplgpu.so`` (git-ignored, built by ``__graft_entry__.build()``)
-* ``abi.py``     thin ctypes binding over that ABI (no torch types cross it)
+* ``abi.py``     thin ctypes binding over that ABI (``include/rplgpu.h``, ``include/rplgpu_msg.h``;
+                 no torch types cross it)
 * ``synth.py``   deterministic synthetic raw-scan generators (bench / tests input)
 * ``capsules.py`` deterministic synthetic recorded answer streams (encoder for the decode stage)
 * ``sharding.py`` scan-index sharding + all-gather of the filtered clouds (RCCL / gloo)
@@ -17,6 +18,7 @@ from .abi import (  # noqa: F401
     NODE_DTYPE,
     Params,
     ScanMeta,
+    Stamp,
     RplGpu,
     RplGpuError,
     load_library,
@@ -27,6 +29,7 @@ __all__ = [
     "NODE_DTYPE",
     "Params",
     "ScanMeta",
+    "Stamp",
     "RplGpu",
     "RplGpuError",
     "load_library",

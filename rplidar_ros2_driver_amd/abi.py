@@ -62,6 +62,17 @@ ABI_SYMBOLS = [
     "rplgpu_segment_batch_dev",
     "rplgpu_scans_to_batch_dev",
     "rplgpu_decode_stream",
+    # include/rplgpu_msg.h
+    "rplgpu_msg_laserscan_layout",
+    "rplgpu_msg_cloud_layout",
+    "rplgpu_msg_laserscan_header",
+    "rplgpu_msg_cloud_header",
+    "rplgpu_host_alloc",
+    "rplgpu_host_free",
+    "rplgpu_scan_to_laserscan_msg",
+    "rplgpu_scan_to_cloud_msg",
+    "rplgpu_laserscan_msgs_dev",
+    "rplgpu_cloud_msgs_dev",
 ]
 
 
@@ -113,6 +124,27 @@ class ScanMeta(C.Structure):
         ("count", C.c_uint32),
         ("published", C.c_int32),
     ]
+
+
+class Stamp(C.Structure):
+    """Mirror of ``rplgpu_stamp_t`` (builtin_interfaces/Time)."""
+
+    _fields_ = [("sec", C.c_int32), ("nanosec", C.c_uint32)]
+
+
+class LaserScanLayout(C.Structure):
+    """Mirror of ``rplgpu_laserscan_layout_t``."""
+
+    _fields_ = [(k, C.c_uint32) for k in (
+        "scalars_off", "ranges_len_off", "ranges_off", "intensities_len_off",
+        "intensities_off", "total_len")]
+
+
+class CloudLayout(C.Structure):
+    """Mirror of ``rplgpu_cloud_layout_t``."""
+
+    _fields_ = [(k, C.c_uint32) for k in (
+        "width_off", "row_step_off", "data_len_off", "data_off", "is_dense_off", "total_len")]
 
 
 def library_path() -> Path:
@@ -177,6 +209,21 @@ def load_library() -> C.CDLL:
     lib.rplgpu_scans_to_batch_dev.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, vp, u32, u32, vp]
     lib.rplgpu_decode_stream.argtypes = [vp, u8, u32, vp, sz, vp, vp, sz, C.POINTER(sz), vp, sz,
                                          C.POINTER(sz), C.POINTER(u32)]
+    cs = C.c_char_p
+    lib.rplgpu_msg_laserscan_layout.argtypes = [sz, u32, C.POINTER(LaserScanLayout)]
+    lib.rplgpu_msg_cloud_layout.argtypes = [sz, u32, C.POINTER(CloudLayout)]
+    lib.rplgpu_msg_laserscan_header.argtypes = [cs, Stamp, C.POINTER(ScanMeta), vp, sz,
+                                                C.POINTER(LaserScanLayout)]
+    lib.rplgpu_msg_cloud_header.argtypes = [cs, Stamp, u32, vp, sz, C.POINTER(CloudLayout)]
+    lib.rplgpu_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.rplgpu_host_free.argtypes = [vp, vp]
+    lib.rplgpu_scan_to_laserscan_msg.argtypes = [vp, vp, sz, C.POINTER(Params), C.c_double, cs,
+                                                 Stamp, vp, sz, C.POINTER(sz), C.POINTER(ScanMeta)]
+    lib.rplgpu_scan_to_cloud_msg.argtypes = [vp, vp, sz, C.POINTER(Params), cs, Stamp, vp, sz,
+                                             C.POINTER(sz), C.POINTER(u32), C.POINTER(u32)]
+    lib.rplgpu_laserscan_msgs_dev.argtypes = [vp, vp, vp, u32, vp, u32, C.POINTER(Params), cs,
+                                              vp, vp, vp, u32, vp, vp]
+    lib.rplgpu_cloud_msgs_dev.argtypes = [vp, vp, u32, vp, vp, u32, cs, vp, vp, u32, vp, vp]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default
@@ -197,6 +244,7 @@ class RplGpu:
     def __init__(self, device: int = 0, max_samples_per_scan: int = MAX_SAMPLES_PER_SCAN,
                  max_batch: int = 4096):
         self._lib = load_library()
+        self._pinned = {}
         h = C.c_void_p()
         rc = self._lib.rplgpu_create(device, max_samples_per_scan, max_batch, C.byref(h))
         if rc != OK:
@@ -302,6 +350,65 @@ class RplGpu:
         self._lib.rplgpu_fill_meta(C.byref(params), count, scan_duration, C.byref(meta))
         return meta
 
+    # -- serialised messages (include/rplgpu_msg.h) ----------------------
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """Pinned host bytes (``rplgpu_host_alloc``) as a uint8 array; free with ``host_free``."""
+        ptr = C.c_void_p()
+        self._check(self._lib.rplgpu_host_alloc(self._h, nbytes, C.byref(ptr)))
+        buf = (C.c_uint8 * nbytes).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=np.uint8)
+        self._pinned[arr.ctypes.data] = ptr.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        ptr = self._pinned.pop(arr.ctypes.data)
+        self._check(self._lib.rplgpu_host_free(self._h, ptr))
+
+    def scan_to_laserscan_msg(self, nodes: np.ndarray, params: Params, scan_duration: float,
+                              frame_id: str, sec: int, nanosec: int, out: np.ndarray | None = None):
+        """Serialised sensor_msgs/LaserScan of one scan: ``(bytes view, meta)``; the view is
+        empty when publish_scan would not have published."""
+        n = len(nodes)
+        if out is None:
+            out = np.empty(msg_laserscan_layout(len(frame_id.encode()), max(n, 1)).total_len,
+                           np.uint8)
+        meta = ScanMeta()
+        ln = C.c_size_t(0)
+        self._check(self._lib.rplgpu_scan_to_laserscan_msg(
+            self._h, _nodes_ptr(nodes), n, C.byref(params), scan_duration, frame_id.encode(),
+            Stamp(sec, nanosec), out.ctypes.data, out.nbytes, C.byref(ln), C.byref(meta)))
+        return out[: ln.value], meta
+
+    def scan_to_cloud_msg(self, nodes: np.ndarray, params: Params, frame_id: str, sec: int,
+                          nanosec: int, out: np.ndarray | None = None,
+                          allow_overflow: bool = False):
+        """Serialised sensor_msgs/PointCloud2 of one scan: ``(bytes view, n_points, status)``."""
+        n = len(nodes)
+        if out is None:
+            out = np.empty(msg_cloud_layout(len(frame_id.encode()), max(n, 1)).total_len, np.uint8)
+        ln = C.c_size_t(0)
+        npts, status = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.rplgpu_scan_to_cloud_msg(
+            self._h, _nodes_ptr(nodes), n, C.byref(params), frame_id.encode(),
+            Stamp(sec, nanosec), out.ctypes.data, out.nbytes, C.byref(ln), C.byref(npts),
+            C.byref(status)), allow=(ERR_SCAN_OVERFLOW,) if allow_overflow else ())
+        return out[: ln.value], npts.value, status.value
+
+    def laserscan_msgs_dev(self, d_ranges: int, d_intens: int, n_stride: int, d_beam_count: int,
+                           B: int, params: Params, frame_id: str, d_stamps: int,
+                           d_scan_duration: int, d_msgs: int, msg_stride: int, d_msg_len: int,
+                           d_status: int = 0):
+        self._check(self._lib.rplgpu_laserscan_msgs_dev(
+            self._h, d_ranges, d_intens, n_stride, d_beam_count, B, C.byref(params),
+            frame_id.encode(), d_stamps, d_scan_duration, d_msgs, msg_stride, d_msg_len, d_status))
+
+    def cloud_msgs_dev(self, d_xyzi: int, out_stride: int, d_scan_start: int, d_n_points: int,
+                       B: int, frame_id: str, d_stamps: int, d_msgs: int, msg_stride: int,
+                       d_msg_len: int, d_status: int = 0):
+        self._check(self._lib.rplgpu_cloud_msgs_dev(
+            self._h, d_xyzi, out_stride, d_scan_start, d_n_points, B, frame_id.encode(),
+            d_stamps, d_msgs, msg_stride, d_msg_len, d_status))
+
     # -- decode stage: recorded answer streams -> nodes -> scans (SURVEY §8(f) rows 1-2) -----
     def decode_stream(self, ans_type: int, data: np.ndarray, sample_duration_us: int = 125,
                       state=(0, 0)):
@@ -347,6 +454,45 @@ class RplGpu:
         self._check(self._lib.rplgpu_scans_to_batch_dev(
             self._h, d_seg_nodes, seg_stride, d_scan_off, scan_cap, d_n_scans, B, d_scan_base,
             d_batch, n_stride, max_scans, d_n_per_scan))
+
+
+def msg_laserscan_layout(frame_id_len: int, count: int) -> LaserScanLayout:
+    L = LaserScanLayout()
+    rc = load_library().rplgpu_msg_laserscan_layout(frame_id_len, count, C.byref(L))
+    if rc:
+        raise RplGpuError(rc, "rplgpu_msg_laserscan_layout")
+    return L
+
+
+def msg_cloud_layout(frame_id_len: int, n_points: int) -> CloudLayout:
+    L = CloudLayout()
+    rc = load_library().rplgpu_msg_cloud_layout(frame_id_len, n_points, C.byref(L))
+    if rc:
+        raise RplGpuError(rc, "rplgpu_msg_cloud_layout")
+    return L
+
+
+def msg_laserscan_header(frame_id: str, sec: int, nanosec: int, meta: ScanMeta,
+                         out: np.ndarray) -> LaserScanLayout:
+    """Host-only: everything of a serialised LaserScan but the two float arrays, into ``out``."""
+    L = LaserScanLayout()
+    rc = load_library().rplgpu_msg_laserscan_header(
+        frame_id.encode(), Stamp(sec, nanosec), C.byref(meta), out.ctypes.data, out.nbytes,
+        C.byref(L))
+    if rc:
+        raise RplGpuError(rc, "rplgpu_msg_laserscan_header")
+    return L
+
+
+def msg_cloud_header(frame_id: str, sec: int, nanosec: int, n_points: int,
+                     out: np.ndarray) -> CloudLayout:
+    """Host-only: everything of a serialised PointCloud2 but the points, into ``out``."""
+    L = CloudLayout()
+    rc = load_library().rplgpu_msg_cloud_header(
+        frame_id.encode(), Stamp(sec, nanosec), n_points, out.ctypes.data, out.nbytes, C.byref(L))
+    if rc:
+        raise RplGpuError(rc, "rplgpu_msg_cloud_header")
+    return L
 
 
 def frame_stream(ans_type: int, data: np.ndarray):

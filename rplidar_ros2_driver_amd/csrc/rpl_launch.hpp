@@ -4,7 +4,12 @@
 #include <stdint.h>
 
 #include "rplgpu.h"
+#include "rplgpu_msg.h"
 #include "rpl_device.hpp"
+
+namespace rplmsg {
+struct Prefix;
+}
 
 namespace rpl {
 
@@ -63,5 +68,18 @@ hipError_t launch_scans_to_batch(hipStream_t s, const void *seg_nodes, uint32_t 
                                  void *batch, uint32_t n_stride, uint32_t max_scans,
                                  uint32_t *n_per_scan);
 uint32_t decode_max_frames(int ans);
+
+// serialised-message assembly (rpl_msg.hip)
+hipError_t launch_msg_laserscan(hipStream_t s, const float *ranges, const float *intens,
+                                uint32_t n_stride, const uint32_t *beam_count, uint32_t B,
+                                int scan_processing, const rplgpu_stamp_t *stamps,
+                                const double *scan_duration, const rplmsg::Prefix &P,
+                                uint8_t *msgs, uint32_t msg_stride, uint32_t *msg_len,
+                                uint32_t *status);
+hipError_t launch_msg_cloud(hipStream_t s, const float *xyzi, uint32_t out_stride,
+                            uint32_t max_points, const unsigned long long *scan_start,
+                            const uint32_t *n_points, uint32_t B, const rplgpu_stamp_t *stamps,
+                            const rplmsg::Prefix &P, uint8_t *msgs, uint32_t msg_stride,
+                            uint32_t *msg_len, uint32_t *status);
 
 }  // namespace rpl

@@ -16,7 +16,9 @@
 #include <vector>
 
 #include "rplgpu.h"
+#include "rplgpu_msg.h"
 #include "rpl_launch.hpp"
+#include "rpl_msg.hpp"
 
 struct rplgpu_ctx {
   int device = -1;
@@ -830,6 +832,237 @@ int32_t rplgpu_decode_stream(rplgpu_handle_t h, uint8_t ans_type, uint32_t sampl
     state[2] = 0;
     state[3] = 0;
   }
+  return RPLGPU_OK;
+}
+
+// ---- serialised messages (include/rplgpu_msg.h) ------------------
+
+int32_t rplgpu_msg_laserscan_layout(size_t frame_id_len, uint32_t count,
+                                    rplgpu_laserscan_layout_t *out) {
+  if (!out || frame_id_len > (1u << 20) || count > (1u << 27)) return RPLGPU_ERR_INVALID_ARG;
+  rplgpu_scan_meta_t m{};
+  m.count = count;
+  rplmsg::Writer w(nullptr, 0);
+  std::string fid(frame_id_len, 'x');
+  rplmsg::write_laserscan(w, fid.data(), frame_id_len, rplgpu_stamp_t{0, 0}, m, out);
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_msg_cloud_layout(size_t frame_id_len, uint32_t n_points,
+                                rplgpu_cloud_layout_t *out) {
+  if (!out || frame_id_len > (1u << 20) || n_points > (1u << 27)) return RPLGPU_ERR_INVALID_ARG;
+  rplmsg::Writer w(nullptr, 0);
+  std::string fid(frame_id_len, 'x');
+  rplmsg::write_cloud(w, fid.data(), frame_id_len, rplgpu_stamp_t{0, 0}, n_points, out);
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_msg_laserscan_header(const char *frame_id, rplgpu_stamp_t stamp,
+                                    const rplgpu_scan_meta_t *meta, uint8_t *msg, size_t cap,
+                                    rplgpu_laserscan_layout_t *layout) {
+  if (!frame_id || !meta || !msg) return RPLGPU_ERR_INVALID_ARG;
+  const size_t fl = std::strlen(frame_id);
+  rplgpu_laserscan_layout_t L;
+  if (int32_t rc = rplgpu_msg_laserscan_layout(fl, meta->count, &L)) return rc;
+  if (layout) *layout = L;
+  if (L.total_len > cap) return RPLGPU_ERR_CAPACITY;
+  rplmsg::Writer w(msg, cap);
+  rplmsg::write_laserscan(w, frame_id, fl, stamp, *meta, &L);
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_msg_cloud_header(const char *frame_id, rplgpu_stamp_t stamp, uint32_t n_points,
+                                uint8_t *msg, size_t cap, rplgpu_cloud_layout_t *layout) {
+  if (!frame_id || !msg) return RPLGPU_ERR_INVALID_ARG;
+  const size_t fl = std::strlen(frame_id);
+  rplgpu_cloud_layout_t L;
+  if (int32_t rc = rplgpu_msg_cloud_layout(fl, n_points, &L)) return rc;
+  if (layout) *layout = L;
+  if (L.total_len > cap) return RPLGPU_ERR_CAPACITY;
+  rplmsg::Writer w(msg, cap);
+  rplmsg::write_cloud(w, frame_id, fl, stamp, n_points, &L);
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_host_alloc(rplgpu_handle_t h, size_t bytes, void **out) {
+  if (!h || !out || bytes == 0) return RPLGPU_ERR_INVALID_ARG;
+  *out = nullptr;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_host_free(rplgpu_handle_t h, void *p) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  if (!p) return RPLGPU_OK;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, hipHostFree(p));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_scan_to_laserscan_msg(rplgpu_handle_t h, const rplgpu_node_t *nodes, size_t n,
+                                     const rplgpu_params_t *p, double scan_duration,
+                                     const char *frame_id, rplgpu_stamp_t stamp, uint8_t *msg,
+                                     size_t cap, size_t *msg_len, rplgpu_scan_meta_t *meta) {
+  if (!h || !p || !meta || !frame_id || !msg || !msg_len || (n && !nodes))
+    return RPLGPU_ERR_INVALID_ARG;
+  if (n > h->max_n) return RPLGPU_ERR_CAPACITY;
+  std::memset(meta, 0, sizeof(*meta));
+  *msg_len = 0;
+  if (n == 0) return RPLGPU_OK;  // :561-563
+  rplgpu_laserscan_layout_t L;
+  if (int32_t rc = rplgpu_msg_laserscan_layout(std::strlen(frame_id), (uint32_t)n, &L)) return rc;
+  if (L.total_len > cap) {
+    h->err = "message buffer smaller than the worst case (count == n)";
+    return RPLGPU_ERR_CAPACITY;
+  }
+  RPL_HIP(h, hipSetDevice(h->device));
+  uint32_t *h_small = reinterpret_cast<uint32_t *>(h->h_pin + (size_t)h->max_n * 24);
+  std::memcpy(h->h_pin, nodes, n * 8);
+  h_small[0] = (uint32_t)n;
+  float *d_r = reinterpret_cast<float *>(h->d_out);
+  float *d_i = d_r + n;
+  RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
+  if (int32_t lrc = run_laserscan(h, h->d_nodes, (uint32_t)n, h->d_small, 1, *p, d_r, d_i,
+                                  h->d_small + 1))
+    return lrc;
+  RPL_HIP(h, hipMemcpyAsync(h_small + 1, h->d_small + 1, 4, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipStreamSynchronize(h->stream));
+  const uint32_t count = h_small[1];
+  rplgpu_fill_meta(p, count, scan_duration, meta);
+  if (count == 0) return RPLGPU_OK;  // :611-613: nothing is published
+  if (int32_t rc = rplgpu_msg_laserscan_header(frame_id, stamp, meta, msg, cap, &L)) return rc;
+  // the two arrays go by DMA to their final place inside the serialised message
+  RPL_HIP(h, hipMemcpyAsync(msg + L.ranges_off, d_r, (size_t)count * 4, hipMemcpyDeviceToHost,
+                            h->stream));
+  RPL_HIP(h, hipMemcpyAsync(msg + L.intensities_off, d_i, (size_t)count * 4,
+                            hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipStreamSynchronize(h->stream));
+  *msg_len = L.total_len;
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_scan_to_cloud_msg(rplgpu_handle_t h, const rplgpu_node_t *nodes, size_t n,
+                                 const rplgpu_params_t *p, const char *frame_id,
+                                 rplgpu_stamp_t stamp, uint8_t *msg, size_t cap, size_t *msg_len,
+                                 uint32_t *n_points, uint32_t *status) {
+  if (!h || !p || !frame_id || !msg || !msg_len || !n_points || (n && !nodes))
+    return RPLGPU_ERR_INVALID_ARG;
+  if (n > h->max_n) return RPLGPU_ERR_CAPACITY;
+  *n_points = 0;
+  *msg_len = 0;
+  if (status) *status = 0;
+  rplgpu_cloud_layout_t L;
+  if (int32_t rc = rplgpu_msg_cloud_layout(std::strlen(frame_id), (uint32_t)n, &L)) return rc;
+  if (L.total_len > cap) {
+    h->err = "message buffer smaller than the worst case (n points)";
+    return RPLGPU_ERR_CAPACITY;
+  }
+  uint32_t *h_small = reinterpret_cast<uint32_t *>(h->h_pin + (size_t)h->max_n * 24);
+  h_small[1] = h_small[2] = 0;
+  if (n) {
+    std::memcpy(h->h_pin, nodes, n * 8);
+    h_small[0] = (uint32_t)n;
+    RPL_HIP(h, hipSetDevice(h->device));
+    RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
+    RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
+    int32_t rc = rplgpu_cloud_batch_dev(h, reinterpret_cast<const rplgpu_node_t *>(h->d_nodes),
+                                        (uint32_t)n, h->d_small, 1, p,
+                                        reinterpret_cast<float *>(h->d_out), (uint32_t)n,
+                                        h->d_small + 1, h->d_small + 2);
+    if (rc) return rc;
+    RPL_HIP(h, hipMemcpyAsync(h_small + 1, h->d_small + 1, 8, hipMemcpyDeviceToHost, h->stream));
+    RPL_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  const uint32_t np = h_small[1];
+  if (int32_t rc = rplgpu_msg_cloud_header(frame_id, stamp, np, msg, cap, &L)) return rc;
+  if (np) {
+    RPL_HIP(h, hipMemcpyAsync(msg + L.data_off, h->d_out, (size_t)np * 16, hipMemcpyDeviceToHost,
+                              h->stream));
+    RPL_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  *n_points = np;
+  *msg_len = L.total_len;
+  if (status) *status = h_small[2];
+  return (h_small[2] & (RPLGPU_SCAN_CELL_RANGE | RPLGPU_SCAN_TABLE_FULL)) ? RPLGPU_ERR_SCAN_OVERFLOW
+                                                                          : RPLGPU_OK;
+}
+
+static int32_t make_prefix(rplgpu_handle_t h, const char *frame_id, bool cloud,
+                           const rplgpu_params_t *p, rplmsg::Prefix *P) {
+  const size_t fl = std::strlen(frame_id);
+  if (fl > rplmsg::kMaxFrameId) {
+    h->err = "frame_id longer than 255 bytes";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  std::memset(P, 0, sizeof(*P));
+  rplmsg::Writer w(reinterpret_cast<uint8_t *>(P->words), sizeof(P->words));
+  P->stamp_off = 4;
+  if (cloud) {
+    rplgpu_cloud_layout_t L;
+    rplmsg::write_cloud(w, frame_id, fl, rplgpu_stamp_t{0, 0}, 0, &L);
+    P->len = L.data_off;
+    P->a_off = L.width_off;
+    P->b_off = L.row_step_off;
+    P->c_off = L.data_len_off;
+  } else {
+    rplgpu_scan_meta_t m;
+    rplgpu_fill_meta(p, 1, 0.0, &m);  // angle_min/max, range_min/max: the per-publisher constants
+    m.count = 0;
+    rplgpu_laserscan_layout_t L;
+    rplmsg::write_laserscan(w, frame_id, fl, rplgpu_stamp_t{0, 0}, m, &L);
+    P->len = L.ranges_off;
+    P->a_off = L.scalars_off;
+    P->b_off = L.ranges_len_off;
+  }
+  if (P->len > sizeof(P->words) || (P->len & 3u)) {
+    h->err = "message prefix does not fit the device template";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_laserscan_msgs_dev(rplgpu_handle_t h, const float *d_ranges,
+                                  const float *d_intensities, uint32_t n_stride,
+                                  const uint32_t *d_beam_count, uint32_t B,
+                                  const rplgpu_params_t *p, const char *frame_id,
+                                  const rplgpu_stamp_t *d_stamps, const double *d_scan_duration,
+                                  uint8_t *d_msgs, uint32_t msg_stride, uint32_t *d_msg_len,
+                                  uint32_t *d_status) {
+  if (!h || !p || !frame_id) return RPLGPU_ERR_INVALID_ARG;
+  if (B == 0) return RPLGPU_OK;
+  if (!d_ranges || !d_intensities || !d_beam_count || !d_stamps || !d_scan_duration || !d_msgs ||
+      !d_msg_len || n_stride == 0 || (msg_stride & 3u))
+    return RPLGPU_ERR_INVALID_ARG;
+  rplmsg::Prefix P;
+  if (int32_t rc = make_prefix(h, frame_id, false, p, &P)) return rc;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_msg_laserscan(h->stream, d_ranges, d_intensities, n_stride, d_beam_count,
+                                       B, p->scan_processing != 0, d_stamps, d_scan_duration, P,
+                                       d_msgs, msg_stride, d_msg_len, d_status));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_cloud_msgs_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t out_stride,
+                              const uint64_t *d_scan_start, const uint32_t *d_n_points,
+                              uint32_t B, const char *frame_id, const rplgpu_stamp_t *d_stamps,
+                              uint8_t *d_msgs, uint32_t msg_stride, uint32_t *d_msg_len,
+                              uint32_t *d_status) {
+  if (!h || !frame_id) return RPLGPU_ERR_INVALID_ARG;
+  if (B == 0) return RPLGPU_OK;
+  if (!d_xyzi || !d_n_points || !d_stamps || !d_msgs || !d_msg_len || (msg_stride & 3u) ||
+      (!d_scan_start && out_stride == 0))
+    return RPLGPU_ERR_INVALID_ARG;
+  rplmsg::Prefix P;
+  if (int32_t rc = make_prefix(h, frame_id, true, nullptr, &P)) return rc;
+  RPL_HIP(h, hipSetDevice(h->device));
+  // a scan never yields more points than it has samples
+  const uint32_t max_points = d_scan_start ? h->max_n : std::min(out_stride, h->max_n);
+  RPL_HIP(h, rpl::launch_msg_cloud(h->stream, d_xyzi, out_stride, max_points,
+                                   reinterpret_cast<const unsigned long long *>(d_scan_start),
+                                   d_n_points, B, d_stamps, P, d_msgs, msg_stride, d_msg_len,
+                                   d_status));
   return RPLGPU_OK;
 }
 

@@ -1,0 +1,213 @@
+"""GPU tests of the serialised-message stage (include/rplgpu_msg.h):
+raw nodes -> publish-ready LaserScan / PointCloud2 bytes, single scan (DMA into the message)
+and batches assembled on the device, against oracle publish_scan / cloud pipeline results
+serialised by the independent restatement in oracle/cdr_oracle.py.  Byte-exact."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from rplidar_ros2_driver_amd import Params, abi, synth
+from tests import oracle_lib
+from tests.cases import CASES
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+import cdr_oracle as cdr  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+FID = "laser_frame"
+
+
+def _unique_angles(nodes):
+    v = nodes[nodes["dist_mm_q2"] != 0]
+    return len(np.unique(v["angle_z_q14"])) == len(v)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_laserscan_msg_matches_oracle(gpu, oracle, name):
+    nodes = CASES[name]
+    for is_new, inverted, mode in [(0, 0, 1), (1, 1, 1), (0, 1, 0), (1, 0, 0)]:
+        p = Params.defaults(is_new_protocol=is_new, inverted=inverted, scan_processing=mode,
+                            range_max=40.0)
+        wr, wi, wm = oracle.publish_scan(nodes, oracle_lib.copy_params(p), 0.125)
+        msg, gm = gpu.scan_to_laserscan_msg(nodes, p, 0.125, FID, 1727000000, 123456789)
+        assert bytes(gm) == bytes(wm)
+        if not wm.published:
+            assert len(msg) == 0  # publish_scan returns without publishing (:611-613)
+            continue
+        # the arrays inside the message are the arrays of the plain entry point ...
+        gr, gi, _ = gpu.scan_to_laserscan(nodes, p, 0.125)
+        assert msg.tobytes() == cdr.laserscan_msg(FID, 1727000000, 123456789, wm, gr, gi)
+        # ... and the oracle's wherever upstream's unstable sort leaves no choice
+        if _unique_angles(nodes):
+            assert msg.tobytes() == cdr.laserscan_msg(FID, 1727000000, 123456789, wm, wr, wi)
+        back = cdr.deserialize("LaserScan", msg.tobytes())
+        assert len(back["ranges"]) == wm.count == len(back["intensities"])
+
+
+def test_laserscan_msg_empty_and_capacity(gpu):
+    p = Params.defaults()
+    msg, m = gpu.scan_to_laserscan_msg(np.zeros(0, abi.NODE_DTYPE), p, 0.1, FID, 0, 0)
+    assert len(msg) == 0 and not m.published  # :561-563
+    nodes = CASES["c1_like_360"]
+    small = np.zeros(abi.msg_laserscan_layout(len(FID), 359).total_len, np.uint8)
+    with pytest.raises(abi.RplGpuError) as e:  # must hold the worst case count == n
+        gpu.scan_to_laserscan_msg(nodes, p, 0.1, FID, 0, 0, out=small)
+    assert e.value.code == abi.ERR_CAPACITY and not small.any()
+
+
+@pytest.mark.parametrize("name", ["c1_like_360", "ring_8192_rot_jit", "c2_32000", "all_invalid"])
+def test_cloud_msg_matches_oracle(gpu, oracle, name):
+    nodes = CASES[name]
+    for voxel in (0, 1):
+        p = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=voxel, inverted=voxel)
+        msg, npts, status = gpu.scan_to_cloud_msg(nodes, p, FID, 17, 42)
+        xyzi, st2 = gpu.scan_to_cloud(nodes, p)
+        assert status == st2 == 0 and npts == len(xyzi)
+        assert msg.tobytes() == cdr.cloud_msg(FID, 17, 42, xyzi)
+        if voxel:
+            want, _, _ = oracle.cloud_pipeline(nodes, oracle_lib.copy_params(p))
+        else:
+            want = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(p))
+        back = cdr.deserialize("PointCloud2", msg.tobytes())
+        assert back["width"] == len(want) and back["row_step"] == 16 * len(want)
+        got = back["data"].view(np.float32).reshape(-1, 4)
+        if len(want):
+            assert np.max(np.abs(got[:, :3].astype(np.float64) - want[:, :3])) <= 1e-6
+            assert got[:, 3].tobytes() == want[:, 3].tobytes()
+    # an empty cloud is still a message (width 0)
+    msg, npts, _ = gpu.scan_to_cloud_msg(np.zeros(0, abi.NODE_DTYPE), Params.defaults(), "", 0, 0)
+    assert npts == 0 and msg.tobytes() == cdr.cloud_msg("", 0, 0, np.zeros((0, 4), np.float32))
+
+
+def test_pinned_message_buffer(gpu):
+    nodes = CASES["c2_32000"]
+    p = Params.defaults(range_max=40.0)
+    want, _ = gpu.scan_to_laserscan_msg(nodes, p, 0.1, FID, 5, 6)
+    pin = gpu.host_alloc(abi.msg_cloud_layout(len(FID), len(nodes)).total_len + 5)
+    try:
+        pin[:] = 0xEE
+        got, _ = gpu.scan_to_laserscan_msg(nodes, p, 0.1, FID, 5, 6, out=pin)
+        assert got.tobytes() == want.tobytes()
+        assert np.all(pin[len(got):][-5:] == 0xEE)
+        pv = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
+        wantc, n1, _ = gpu.scan_to_cloud_msg(nodes, pv, FID, 5, 6)
+        gotc, n2, _ = gpu.scan_to_cloud_msg(nodes, pv, FID, 5, 6, out=pin)
+        assert n1 == n2 and gotc.tobytes() == wantc.tobytes()
+    finally:
+        gpu.host_free(pin)
+
+
+def _batch(torch, seed, B, n):
+    batch = synth.make_batch(seed, B, n, jitter=2)
+    lens = np.array([n - 17 * b for b in range(B)], np.uint32)
+    lens[2] = 0
+    dev = torch.device("cuda:0")
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+    d_len = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    return batch, lens, d_nodes, d_len
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_laserscan_msgs_dev_matches_oracle(gpu, oracle, mode):
+    import torch
+    B, n = 20, 3000
+    batch, lens, d_nodes, d_len = _batch(torch, 31 + mode, B, n)
+    dev = d_nodes.device
+    p = Params.defaults(range_max=40.0, scan_processing=mode, inverted=mode)
+    d_r = torch.empty(B, n, dtype=torch.float32, device=dev)
+    d_i = torch.empty(B, n, dtype=torch.float32, device=dev)
+    d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    gpu.laserscan_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_r.data_ptr(),
+                            d_i.data_ptr(), d_cnt.data_ptr())
+    stamps = np.stack([np.arange(B) + 1_700_000_000, np.arange(B) * 37_000_001 % 10**9], 1)
+    durs = 0.05 + 0.003 * np.arange(B)
+    d_stamps = torch.from_numpy(stamps.astype(np.int32)).to(dev)
+    d_dur = torch.from_numpy(durs).to(dev)
+    stride = abi.msg_laserscan_layout(len(FID), n).total_len
+    d_msgs = torch.full((B, stride), 0xEE, dtype=torch.uint8, device=dev)
+    d_ml = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    gpu.laserscan_msgs_dev(d_r.data_ptr(), d_i.data_ptr(), n, d_cnt.data_ptr(), B, p, FID,
+                           d_stamps.data_ptr(), d_dur.data_ptr(), d_msgs.data_ptr(), stride,
+                           d_ml.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    msgs, ml = d_msgs.cpu().numpy(), d_ml.cpu().numpy()
+    r, i = d_r.cpu().numpy(), d_i.cpu().numpy()
+    assert not d_st.cpu().numpy().any()
+    for b in range(B):
+        wr, wi, wm = oracle.publish_scan(batch[b, : lens[b]], oracle_lib.copy_params(p), durs[b])
+        if not wm.published:
+            assert ml[b] == 0 and np.all(msgs[b] == 0xEE)
+            continue
+        want = cdr.laserscan_msg(FID, int(stamps[b, 0]), int(stamps[b, 1]), wm,
+                                 r[b, : wm.count], i[b, : wm.count])
+        assert ml[b] == len(want)
+        assert msgs[b, : ml[b]].tobytes() == want  # scalars computed on the device: bit-exact
+        assert np.all(msgs[b, ml[b]:] == 0xEE)     # and nothing written past the message
+        if mode:
+            assert want == cdr.laserscan_msg(FID, int(stamps[b, 0]), int(stamps[b, 1]), wm, wr, wi)
+    # a slot too small for some scans: those report length 0 + OUT_TRUNCATED, the rest are intact
+    small = abi.msg_laserscan_layout(len(FID), int(np.sort(d_cnt.cpu().numpy())[B // 2])).total_len
+    d_ml.fill_(-1)
+    gpu.laserscan_msgs_dev(d_r.data_ptr(), d_i.data_ptr(), n, d_cnt.data_ptr(), B, p, FID,
+                           d_stamps.data_ptr(), d_dur.data_ptr(), d_msgs.data_ptr(), small,
+                           d_ml.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    ml2, st = d_ml.cpu().numpy(), d_st.cpu().numpy()
+    for b in range(B):
+        fits = ml[b] <= small
+        assert ml2[b] == (ml[b] if fits else 0)
+        assert bool(st[b] & abi.SCAN_OUT_TRUNCATED) == (not fits)
+
+
+def test_cloud_msgs_dev_from_regions_and_arena(gpu, oracle):
+    import torch
+    B, n = 20, 3000
+    batch, lens, d_nodes, d_len = _batch(torch, 77, B, n)
+    dev = d_nodes.device
+    pv = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
+    out_stride = 3000
+    d_xyzi = torch.zeros(B, out_stride, 4, dtype=torch.float32, device=dev)
+    d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, pv, d_xyzi.data_ptr(),
+                        out_stride, d_np.data_ptr(), d_st.data_ptr())
+    stamps = np.stack([np.arange(B) - 3, np.arange(B) * 1001], 1)
+    d_stamps = torch.from_numpy(stamps.astype(np.int32)).to(dev)
+    stride = (abi.msg_cloud_layout(len(FID), out_stride).total_len + 3) & ~3
+    d_msgs = torch.full((B, stride), 0xEE, dtype=torch.uint8, device=dev)
+    d_ml = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    gpu.cloud_msgs_dev(d_xyzi.data_ptr(), out_stride, 0, d_np.data_ptr(), B, FID,
+                       d_stamps.data_ptr(), d_msgs.data_ptr(), stride, d_ml.data_ptr(),
+                       d_st.data_ptr())
+    gpu.synchronize()
+    assert not d_st.cpu().numpy().any()
+    msgs, ml, npts = d_msgs.cpu().numpy(), d_ml.cpu().numpy(), d_np.cpu().numpy()
+    xyzi = d_xyzi.cpu().numpy()
+    for b in range(B):
+        want_pts, _, _ = oracle.cloud_pipeline(batch[b, : lens[b]], oracle_lib.copy_params(pv))
+        assert npts[b] == len(want_pts)
+        want = cdr.cloud_msg(FID, int(stamps[b, 0]), int(stamps[b, 1]), xyzi[b, : npts[b]])
+        assert ml[b] == len(want) and msgs[b, : ml[b]].tobytes() == want
+        assert np.all(msgs[b, ml[b]:] == 0xEE)
+
+    # the same clouds through the arena (completion order, per-scan starts)
+    cap = int(npts.sum()) + 64
+    d_arena = torch.zeros(cap, 4, dtype=torch.float32, device=dev)
+    d_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_start = torch.zeros(B, dtype=torch.int64, device=dev)
+    gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, pv, d_arena.data_ptr(), cap,
+                        d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+    d_msgs2 = torch.full((B, stride), 0xEE, dtype=torch.uint8, device=dev)
+    d_ml.fill_(-1)
+    gpu.cloud_msgs_dev(d_arena.data_ptr(), 0, d_start.data_ptr(), d_np.data_ptr(), B, FID,
+                       d_stamps.data_ptr(), d_msgs2.data_ptr(), stride, d_ml.data_ptr(),
+                       d_st.data_ptr())
+    gpu.synchronize()
+    assert not d_st.cpu().numpy().any()
+    assert np.array_equal(d_ml.cpu().numpy(), ml)
+    assert d_msgs2.cpu().numpy().tobytes() == msgs.tobytes()
