@@ -365,7 +365,28 @@ def main():
             "ascend_mpts": round(B * n / res["ascend"] / 1e3, 1),
             "laserscan_mpts": round(B * n / res["laserscan"] / 1e3, 1),
         }
-        del d_nodes2, d_r, d_i
+        # secondary: the LaserScans of the batch as serialised (CDR) messages in HBM
+        from rplidar_ros2_driver_amd import abi as _abi
+        fid = "laser_frame"
+        mstride = _abi.msg_laserscan_layout(len(fid), n).total_len
+        d_msgs = torch.empty(B, mstride, dtype=torch.uint8, device=dev)
+        d_ml = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_stamps = torch.zeros(B, 2, dtype=torch.int32, device=dev)
+        d_dur = torch.full((B,), 0.1, dtype=torch.float64, device=dev)
+        ts = []
+        for it in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            gpu.laserscan_msgs_dev(d_r.data_ptr(), d_i.data_ptr(), n, d_cnt.data_ptr(), B, pl, fid,
+                                   d_stamps.data_ptr(), d_dur.data_ptr(), d_msgs.data_ptr(),
+                                   mstride, d_ml.data_ptr(), 0)
+            b.record(stream)
+            torch.cuda.synchronize(dev)
+            ts.append(a.elapsed_time(b))
+        msg_bytes = int(d_ml.to(torch.int64).sum().item())
+        extra["laserscan_msgs_ms"] = round(min(ts[1:]), 4)
+        extra["laserscan_msgs_gbps_rw"] = round(2 * msg_bytes / min(ts[1:]) / 1e6, 1)
+        del d_nodes2, d_r, d_i, d_msgs
 
     if not args.no_decode and rank == 0:
         extra.update(decode_stage(gpu, dev, stream, args.cpu_seconds))

@@ -9,6 +9,9 @@
 //   host_selftest replay <ans_type> <sample_duration_us> <stream.bin> <out.bin>
 //   out.bin: u32 n_nodes, u32 n_reset_calls, u32 n_err, u32 n_scans, nodes[n_nodes],
 //            reset positions, then per scan: u32 len, nodes[len]   (replay_recording + ScanAssembler)
+//   host_selftest serialized <nodes.bin> <out.bin> <is_new> <inverted> <scan_processing> <cloud 1|2>
+//   out.bin: u32 published, u32 len_scan, LaserScan message bytes, u32 len_cloud, PointCloud2
+//            message bytes   (frame_id "laser_frame", stamp 1727000000.123456789, duration 0.125)
 //   no arguments: config-1 smoke run (3 Dummy scans through the whole path).
 #include <cmath>
 #include <cstdio>
@@ -39,6 +42,35 @@ struct PointCloud2 {  // field names of sensor_msgs/msg/PointCloud2
   std::vector<uint8_t> data;
   bool is_dense = false;
 };
+struct RclSerialized {  // the fields of rcl_serialized_message_t (rcutils_uint8_array_t) used here
+  uint8_t *buffer = nullptr;
+  size_t buffer_length = 0, buffer_capacity = 0;
+};
+class SerializedMessage {  // the two rclcpp::SerializedMessage members the host mirror calls
+ public:
+  void reserve(size_t capacity) {
+    if (capacity > store_.size()) store_.resize(capacity);
+    raw_.buffer = store_.data();
+    raw_.buffer_capacity = store_.size();
+  }
+  RclSerialized &get_rcl_serialized_message() { return raw_; }
+ private:
+  std::vector<uint8_t> store_;
+  RclSerialized raw_;
+};
+std::vector<rplgpu_node_t> read_nodes(const char *path, bool *ok) {
+  std::vector<rplgpu_node_t> nodes;
+  *ok = false;
+  std::FILE *f = std::fopen(path, "rb");
+  if (!f) return nodes;
+  std::fseek(f, 0, SEEK_END);
+  const long bytes = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  nodes.resize(static_cast<size_t>(bytes) / 8);
+  *ok = nodes.empty() || std::fread(nodes.data(), 8, nodes.size(), f) == nodes.size();
+  std::fclose(f);
+  return nodes;
+}
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -95,6 +127,41 @@ int main(int argc, char **argv) {
       std::fwrite(&len, 4, 1, o);
       std::fwrite(s.data(), 8, s.size(), o);
     }
+    std::fclose(o);
+    return 0;
+  }
+  if (argc == 8 && std::string(argv[1]) == "serialized") {
+    bool ok = false;
+    const std::vector<rplgpu_node_t> nodes = read_nodes(argv[2], &ok);
+    if (!ok) return 4;
+    rplgpu_host::ScanConfig cfg;
+    cfg.is_new_protocol = std::atoi(argv[4]) != 0;
+    cfg.inverted = std::atoi(argv[5]) != 0;
+    cfg.scan_processing = std::atoi(argv[6]) != 0;
+    cfg.cached_current_max_range = 40.0f;
+    SerializedMessage scan_msg, cloud_msg;
+    scan_msg.reserve(16);
+    cloud_msg.reserve(16);
+    const bool published = path.fill_serialized_laser_scan(nodes, cfg, 0.125, "laser_frame",
+                                                           1727000000, 123456789u, scan_msg);
+    cfg.clip_enable = true;
+    cfg.voxel_enable = std::atoi(argv[7]) == 2;
+    if (!path.fill_serialized_point_cloud2(nodes, cfg, "laser_frame", 1727000000, 123456789u,
+                                           cloud_msg) && !nodes.empty()) {
+      std::fprintf(stderr, "cloud failed: %s\n", path.last_error().c_str());
+      return 5;
+    }
+    std::FILE *o = std::fopen(argv[3], "wb");
+    if (!o) return 6;
+    const uint32_t pub = published ? 1u : 0u;
+    const auto &a = scan_msg.get_rcl_serialized_message();
+    const auto &c = cloud_msg.get_rcl_serialized_message();
+    const uint32_t la = static_cast<uint32_t>(a.buffer_length), lc = static_cast<uint32_t>(c.buffer_length);
+    std::fwrite(&pub, 4, 1, o);
+    std::fwrite(&la, 4, 1, o);
+    std::fwrite(a.buffer, 1, la, o);
+    std::fwrite(&lc, 4, 1, o);
+    std::fwrite(c.buffer, 1, lc, o);
     std::fclose(o);
     return 0;
   }

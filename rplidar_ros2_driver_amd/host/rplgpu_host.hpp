@@ -9,6 +9,10 @@
 //            but not including, scan_pub_->publish(scan_msg) at :682)
 //   ext PointCloud2 (x, y, z, intensity FLOAT32; point_step 16) with clip / radius-outlier /
 //         voxel grid -> rplgpu_host::ScanPath::fill_point_cloud2(nodes, ..., cloud_msg)
+//   msg the same two, but ending in scan_pub_->publish(const rclcpp::SerializedMessage &):
+//         the device results land by DMA inside the serialised (CDR) message, no typed message,
+//         no std::vector fills, no middleware serialisation pass (include/rplgpu_msg.h)
+//         -> rplgpu_host::ScanPath::fill_serialized_laser_scan / fill_serialized_point_cloud2
 //   pre LIDARSampleDataUnpacker::onSampleData -> LIDARSampleDataListener callbacks
 //         (src/sdk/src/dataunpacker/dataunpacker.h:48-88) and ScanDataHolder
 //         (src/sdk/src/sl_lidar_driver.cpp:272-315), for RECORDED answer streams
@@ -31,6 +35,7 @@
 #include <vector>
 
 #include "rplgpu.h"
+#include "rplgpu_msg.h"
 
 namespace rplgpu_host {
 
@@ -155,6 +160,57 @@ class ScanPath {
     scan_msg.time_increment = meta.time_increment;    // :637 / :668
     scan_msg.ranges.assign(ranges_.begin(), ranges_.begin() + meta.count);
     scan_msg.intensities.assign(intens_.begin(), intens_.begin() + meta.count);
+    return true;
+  }
+
+  // == publish_scan :561-682 for a publisher that sends serialised messages: `out` is an
+  // rclcpp::SerializedMessage (or anything with reserve(size_t) and
+  // get_rcl_serialized_message() -> {uint8_t *buffer; size_t buffer_length, buffer_capacity}).
+  // On success `out` holds the complete CDR-serialised sensor_msgs/msg/LaserScan — header
+  // stamp / frame_id (:620-621) included — ready for publish(out).  Same return rule as
+  // fill_laser_scan.
+  template <class NodeT, class SerializedT>
+  bool fill_serialized_laser_scan(const std::vector<NodeT> &nodes, const ScanConfig &cfg,
+                                  double scan_duration, const std::string &frame_id, int32_t sec,
+                                  uint32_t nanosec, SerializedT &out) {
+    if (nodes.empty()) return false;  // :561-563
+    if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
+    rplgpu_laserscan_layout_t L;
+    if (rplgpu_msg_laserscan_layout(frame_id.size(), static_cast<uint32_t>(nodes.size()), &L))
+      return fail("frame_id too long");
+    out.reserve(L.total_len);  // worst case: every node becomes a beam
+    auto &raw = out.get_rcl_serialized_message();
+    const rplgpu_params_t p = cfg.to_params();
+    rplgpu_scan_meta_t meta;
+    size_t len = 0;
+    if (rplgpu_scan_to_laserscan_msg(h_, as_nodes(nodes.data()), nodes.size(), &p, scan_duration,
+                                     frame_id.c_str(), rplgpu_stamp_t{sec, nanosec}, raw.buffer,
+                                     raw.buffer_capacity, &len, &meta) != RPLGPU_OK)
+      return note_error();
+    raw.buffer_length = len;
+    return meta.published != 0;  // :611-613
+  }
+
+  // ext: the serialised sensor_msgs/msg/PointCloud2 of fill_point_cloud2.
+  template <class NodeT, class SerializedT>
+  bool fill_serialized_point_cloud2(const std::vector<NodeT> &nodes, const ScanConfig &cfg,
+                                    const std::string &frame_id, int32_t sec, uint32_t nanosec,
+                                    SerializedT &out) {
+    if (nodes.empty()) return false;
+    if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
+    rplgpu_cloud_layout_t L;
+    if (rplgpu_msg_cloud_layout(frame_id.size(), static_cast<uint32_t>(nodes.size()), &L))
+      return fail("frame_id too long");
+    out.reserve(L.total_len);
+    auto &raw = out.get_rcl_serialized_message();
+    const rplgpu_params_t p = cfg.to_params();
+    size_t len = 0;
+    uint32_t n_points = 0, status = 0;
+    if (rplgpu_scan_to_cloud_msg(h_, as_nodes(nodes.data()), nodes.size(), &p, frame_id.c_str(),
+                                 rplgpu_stamp_t{sec, nanosec}, raw.buffer, raw.buffer_capacity,
+                                 &len, &n_points, &status) != RPLGPU_OK)
+      return note_error();
+    raw.buffer_length = len;
     return true;
   }
 

@@ -39,6 +39,18 @@ bool replay(rplgpu_host::ScanPath &p, const std::vector<uint8_t> &bytes) {
   return p.replay_recording(0x85, 125, bytes.data(), bytes.size(), l, state) &&
          p.replay_recording(0x82, 125, bytes.data(), bytes.size(), a, state);
 }
+struct rcl_like { uint8_t *buffer; size_t buffer_length, buffer_capacity; };
+struct SerializedMessage {  // shape of rclcpp::SerializedMessage
+  void reserve(size_t) {}
+  rcl_like &get_rcl_serialized_message() { return raw; }
+  rcl_like raw;
+};
+bool serialized(rplgpu_host::ScanPath &p, std::vector<sdk_node> &nodes) {
+  SerializedMessage m;
+  rplgpu_host::ScanConfig cfg;
+  return p.fill_serialized_laser_scan(nodes, cfg, 0.1, "laser", 1, 2u, m) &&
+         p.fill_serialized_point_cloud2(nodes, cfg, "laser", 1, 2u, m);
+}
 bool use(rplgpu_host::ScanPath &p, std::vector<sdk_node> &nodes) {
   sensor_msgs::msg::LaserScan scan_msg;
   sensor_msgs::msg::PointCloud2 cloud;
@@ -127,6 +139,49 @@ def test_host_selftest_matches_oracle(tmp_path, oracle, name, mode):
     if npts:
         assert np.max(np.abs(cloud[:, :2].astype(np.float64) - wc[:, :2])) <= 1e-6
         assert cloud[:, 3].tobytes() == wc[:, 3].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c1_like_360", "ring_8192", "all_invalid", "c2_32000"])
+@pytest.mark.parametrize("mode", [(0, 0, 1), (1, 1, 0)])
+def test_host_selftest_serialized_messages(tmp_path, oracle, name, mode):
+    """publish_scan ending in publish(SerializedMessage): the C++ host mirror must hand back the
+    exact CDR bytes of the oracle's LaserScan / voxelised PointCloud2 for the same nodes."""
+    import sys
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import cdr_oracle as cdr
+    is_new, inverted, scan_processing = mode
+    exe = _build_selftest()
+    nodes = CASES[name]
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    nodes.tofile(fin)
+    r = subprocess.run([str(exe), "serialized", str(fin), str(fout), str(is_new), str(inverted),
+                        str(scan_processing), "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    buf = fout.read_bytes()
+    pub, la = struct.unpack_from("<II", buf, 0)
+    scan_bytes = buf[8: 8 + la]
+    lc, = struct.unpack_from("<I", buf, 8 + la)
+    cloud_bytes = buf[12 + la: 12 + la + lc]
+    p = Params.defaults(is_new_protocol=is_new, inverted=inverted,
+                        scan_processing=scan_processing, range_max=40.0)
+    wr, wi, wm = oracle.publish_scan(nodes, oracle_lib.copy_params(p), 0.125)
+    assert pub == wm.published
+    if pub:  # these cases have unique angles: the oracle's arrays are the only right answer
+        assert scan_bytes == cdr.laserscan_msg("laser_frame", 1727000000, 123456789, wm, wr, wi)
+    else:
+        assert la == 0
+    pv = Params.defaults(is_new_protocol=is_new, inverted=inverted, clip_enable=1,
+                         range_max=40.0, voxel_enable=1)
+    want, _, _ = oracle.cloud_pipeline(nodes, oracle_lib.copy_params(pv))
+    back = cdr.deserialize("PointCloud2", cloud_bytes)
+    assert back["header"] == {"stamp": {"sec": 1727000000, "nanosec": 123456789},
+                              "frame_id": "laser_frame"}
+    assert back["width"] == len(want) and back["height"] == 1 and back["is_dense"]
+    got = back["data"].view(np.float32).reshape(-1, 4)
+    if len(want):
+        assert np.max(np.abs(got[:, :3].astype(np.float64) - want[:, :3])) <= 1e-6
+        assert got[:, 3].tobytes() == want[:, 3].tobytes()
 
 
 @pytest.mark.gpu
