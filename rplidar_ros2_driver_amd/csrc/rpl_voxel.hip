@@ -350,7 +350,16 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
           const uint32_t v = L.bucket[s0 + j];  // in bounds: the array is padded by 8
           rank += ((s0 + j < s1) && (v < me)) ? 1u : 0u;
         }
-        for (uint32_t m = s0 + 8u; m < s1; ++m) rank += (L.bucket[m] < me);
+        uint32_t m = s0 + 8u;
+        if (m < s1) {  // a long row (noisy scans, walls along x): 16-byte reads once aligned
+          const uint32_t ma = min((m + 3u) & ~3u, s1);
+          for (; m < ma; ++m) rank += (L.bucket[m] < me);
+          for (; m + 4u <= s1; m += 4u) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&L.bucket[m]);
+            rank += (v.x < me) + (v.y < me) + (v.z < me) + (v.w < me);
+          }
+          for (; m < s1; ++m) rank += (L.bucket[m] < me);
+        }
         L.rec[rank] = mine[k];
       }
     }

@@ -7,7 +7,8 @@ sys.path.insert(0, ".")
 from rplidar_ros2_driver_amd import Params, RplGpu, synth, abi
 
 B, n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 32000
-batch = synth.make_batch(2026, B, n)
+NOISE = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+batch = synth.make_batch(2026, B, n, noise_m=NOISE)
 dev = torch.device("cuda:0")
 d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
 d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
