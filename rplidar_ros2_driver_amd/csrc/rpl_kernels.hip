@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
   __shared__ SortLds s_sort;
   const uint32_t b = blockIdx.x;
   if (SORT && need_sort[b] == 0u) return;
-  const uint32_t n = min(n_per_scan[b], kMaxN);
+  const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   uint2 *scan = nodes + (size_t)b * n_stride;
 
   uint2 v[kIters];
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_raw(
   __shared__ SortLds s_sort;
 
   const uint32_t b = blockIdx.x;
-  const uint32_t n = min(n_per_scan[b], kMaxN);
+  const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   const uint2 *scan = nodes + (size_t)b * n_stride;
   float *out_r = ranges + (size_t)b * n_stride;
   float *out_i = intens + (size_t)b * n_stride;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud(
   __shared__ uint32_t s_tmp[32];
 
   const uint32_t b = blockIdx.x;
-  const uint32_t n = min(n_per_scan[b], kMaxN);
+  const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   const uint2 *scan = nodes + (size_t)b * n_stride;
   float4 *out = xyzi + (size_t)b * out_stride;
 

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
   __shared__ uint32_t s_cnt;
 
   const uint32_t b = blockIdx.x;
-  const uint32_t n = min(n_per_scan[b], kMaxN);
+  const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   const uint2 *scan = nodes + (size_t)b * n_stride;
   float *out_r = ranges + (size_t)b * n_stride;
   float *out_i = intens + (size_t)b * n_stride;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
                                                      uint32_t mask_stride) {
   __shared__ RorLds L;
   const uint32_t b = blockIdx.x;
-  const uint32_t n = min(n_per_scan[b], kMaxN);
+  const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   const uint2 *scan = nodes + (size_t)b * n_stride;
   uint32_t *mask = mask_out + (size_t)b * mask_stride;
   const float2 *cs = p.inverted ? T.cs_inv : T.cs;

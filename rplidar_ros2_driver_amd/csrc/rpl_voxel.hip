@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
   // one per scan only adds 4096 dispatches); the first scan is blockIdx.x, the next ones come
   // from a shared counter, so a workgroup that drew cheap scans simply takes more of them
   for (uint32_t b = blockIdx.x; b < B;) {
-  const uint32_t n = min(n_per_scan[b], kMaxN);
+  const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   const uint2 *scan = nodes + (size_t)b * n_stride;
   float4 *out = arena.base ? arena.base : xyzi + (size_t)b * out_stride;
   int emit_mode = arena.base ? kEmitArenaFirst : kEmitLegacy;

@@ -433,6 +433,36 @@ def test_batch_dev_matches_single_scan_and_oracle(gpu, oracle):
         assert asc[b, lens[b]:].tobytes() == batch[b, lens[b]:].tobytes()  # tail untouched
 
 
+def test_scan_length_is_clamped_to_its_slot(gpu):
+    """A length word larger than the slot (caller bug) must not make a kernel read the next
+    scan: every batch kernel uses min(n_per_scan[b], n_stride)."""
+    torch = _torch()
+    B, n = 6, 2000
+    batch = synth.make_batch(5, B, n, jitter=1)
+    dev = torch.device("cuda:0")
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+    outs = []
+    for extra in (0, 777):
+        d_len = torch.full((B,), n + extra, dtype=torch.int32, device=dev)
+        d_r = torch.zeros(B, n, dtype=torch.float32, device=dev)
+        d_i = torch.zeros(B, n, dtype=torch.float32, device=dev)
+        d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+        p = Params.defaults(range_max=40.0)
+        gpu.laserscan_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_r.data_ptr(),
+                                d_i.data_ptr(), d_cnt.data_ptr())
+        pv = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1, ror_enable=1)
+        d_xyzi = torch.zeros(B, n, 4, dtype=torch.float32, device=dev)
+        d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+        gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, pv, d_xyzi.data_ptr(), n,
+                            d_np.data_ptr(), d_st.data_ptr())
+        d_asc = d_nodes.clone()
+        gpu.ascend_batch_dev(d_asc.data_ptr(), n, d_len.data_ptr(), B, d_st.data_ptr())
+        gpu.synchronize()
+        outs.append([t.cpu().numpy().tobytes() for t in (d_r, d_i, d_cnt, d_xyzi, d_np, d_asc)])
+    assert outs[0] == outs[1]
+
+
 def test_c5_eight_sensors_fused_cloud(gpu, oracle):
     """BASELINE config 5 on one device: 8 sensors x one 32 000-sample scan each, E1 clip ->
     E5 radius-outlier removal -> E4 voxel grid, packed into ONE fused cloud (sensor order;
