@@ -51,12 +51,21 @@ struct DecCfg {
       !kFiltered ? 1u : ANS == RPLGPU_ANS_DENSE_CAPSULED ? kDecMaxFrames * 40u / 64u : kUdMaxFrames;
   static constexpr uint32_t kSmoothSlots = ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? kUdMaxFrames * 64u : 1u;
   static constexpr uint32_t kCrcWords = ANS == RPLGPU_ANS_HQ ? 1024u : 1u;
+  static constexpr uint32_t kStageWords = ANS == RPLGPU_ANS_HQ ? (kDecBlock / 64) * 64 * 17 : 1u;
 };
 
 __device__ __forceinline__ uint32_t ld8(const uint8_t *p) { return p[0]; }
-__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return p[0] | ((uint32_t)p[1] << 8); }
+// frames start at any byte: the fields are read with one (possibly unaligned) load each -- the
+// target runs in unaligned access mode, so these become single global_load_ushort / _dword
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) {
+  uint16_t v;
+  __builtin_memcpy(&v, p, 2);
+  return v;
+}
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
-  return p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+  uint32_t v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
 }
 
 __host__ __device__ constexpr uint32_t dec_frame_size(int ans) {
@@ -105,22 +114,75 @@ __device__ __forceinline__ uint32_t varbitscale(uint32_t scaled, uint32_t &lvl) 
 // CRC of handler_hqnode.cpp:124-126 / sl_crc.cpp:36-101: reflected CRC-32, the data zero padded
 // by 4 - (len & 3) bytes -- so the padded length is always a multiple of four and the CRC can
 // be advanced a 32-bit word at a time (slicing-by-4: four independent table look-ups per word
-// instead of four dependent ones).  One thread per frame, tables (4 x 256 words) in LDS.
-__device__ __forceinline__ uint32_t crc32_padded(const uint8_t *p, uint32_t len,
-                                                 const uint32_t *t) {
-  uint32_t crc = 0xFFFFFFFFu;
-  const uint32_t full = len & ~3u;
-  for (uint32_t i = 0; i < full; i += 4u) {
-    crc ^= ld32(p + i);
-    crc = t[768u + (crc & 0xFFu)] ^ t[512u + ((crc >> 8) & 0xFFu)] ^ t[256u + ((crc >> 16) & 0xFFu)] ^
-          t[crc >> 24];
+// instead of four dependent ones); tables (4 x 256 words) in LDS.
+__device__ __forceinline__ uint32_t crc32_word(uint32_t crc, const uint32_t *t) {
+  return t[768u + (crc & 0xFFu)] ^ t[512u + ((crc >> 8) & 0xFFu)] ^ t[256u + ((crc >> 16) & 0xFFu)] ^
+         t[crc >> 24];
+}
+
+// LDS traffic of ONE wave is ordered by the hardware; this only keeps the compiler from moving
+// the staged reads above the staging writes (or the next writes above the reads).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// HQ frames (781 bytes, CRC-32 over the first 777, handler_hqnode.cpp:99-133), 64 at a time per
+// wave.  A thread walking its own frame touches a new cache line with every lane of every load
+// and needs it again 31 loads later, when it is long gone (131 M nodes: 2.0 ms).  Here the
+// wave fetches the frames together -- 16 lanes per frame, 16 ALIGNED dwords each, 13 pieces --
+// into a transposed LDS tile, and then every lane runs the serial CRC of its own frame out of
+// LDS; the frame's byte alignment is undone with one v_alignbit per word.  Aligned dwords that
+// hold at least one frame byte never leave the buffer's pages.
+// Returns bit 0 = CRC ok, bits 8..15 = the frame's first byte (sync byte 0xA5).
+__device__ __forceinline__ uint32_t hq_crc_64frames(const uint8_t *base, uint32_t my_off,
+                                                    uint32_t nlive, uint32_t *stg,
+                                                    const uint32_t *t) {
+  const uint32_t lane = lane_id(), c = lane & 15u;
+  const uint32_t sh = ((uint32_t)(uintptr_t)(base + my_off) & 3u) * 8u;
+  // lane (4*it + q, c) fetches word c of every piece of frame 4*it + q: its 16 frame addresses
+  // (aligned down) are fixed for the whole call
+  const uint32_t *src[16];
+#pragma unroll
+  for (uint32_t it = 0; it < 16u; ++it) {
+    const uint32_t fj = it * 4u + (lane >> 4);
+    const uint32_t off_j = (uint32_t)__shfl((int)my_off, (int)fj);
+    src[it] = fj < nlive
+                  ? reinterpret_cast<const uint32_t *>((uintptr_t)(base + off_j) & ~(uintptr_t)3) + c
+                  : nullptr;
   }
-  uint32_t tail = 0;  // the last 0..3 data bytes followed by the zero padding
-  for (uint32_t i = full; i < len; ++i) tail |= (uint32_t)p[i] << (8u * (i - full));
-  crc ^= tail;
-  crc = t[768u + (crc & 0xFFu)] ^ t[512u + ((crc >> 8) & 0xFFu)] ^ t[256u + ((crc >> 16) & 0xFFu)] ^
-        t[crc >> 24];
-  return crc ^ 0xFFFFFFFFu;
+  uint32_t v[16];
+  auto fetch = [&](uint32_t p) {  // 16 independent loads in flight
+#pragma unroll
+    for (uint32_t it = 0; it < 16u; ++it)
+      v[it] = (src[it] && p * 16u + c < 196u) ? src[it][p * 16u] : 0u;
+  };
+  fetch(0u);
+  uint32_t crc = 0xFFFFFFFFu, prev = 0u, stored = 0u, first = 0u;
+  for (uint32_t p = 0; p < 13u; ++p) {
+#pragma unroll
+    for (uint32_t it = 0; it < 16u; ++it) stg[(it * 4u + (lane >> 4)) * 17u + c] = v[it];
+    wave_lds_sync();
+    if (p + 1u < 13u) fetch(p + 1u);  // the next piece travels while this one is consumed
+#pragma unroll
+    for (uint32_t j = 0; j < 16u; ++j) {
+      const uint32_t g = p * 16u + j;  // aligned word g holds frame bytes 4g - r .. 4g + 3 - r
+      const uint32_t a = stg[lane * 17u + j];
+      if (g >= 1u && g <= 194u) {  // frame word g-1 = data bytes 4(g-1) .. 4(g-1)+3
+        const uint32_t u = __builtin_amdgcn_alignbit(a, prev, sh);
+        if (g == 1u) first = u & 0xFFu;
+        crc = crc32_word(crc ^ u, t);
+      } else if (g == 195u) {  // bytes 776..779: the last data byte, then the stored CRC
+        const uint32_t u = __builtin_amdgcn_alignbit(a, prev, sh);
+        crc = crc32_word(crc ^ (u & 0xFFu), t);  // zero padded to 780 bytes (sl_crc.cpp:83-99)
+        stored = (u >> 8) | (((a >> sh) & 0xFFu) << 24);
+      }
+      prev = a;
+    }
+    wave_lds_sync();
+  }
+  return (((crc ^ 0xFFFFFFFFu) == stored) ? 1u : 0u) | (first << 8);
 }
 
 template <int ANS>
@@ -131,6 +193,7 @@ struct DecodeLds {
   unsigned long long rawbits[DecCfg<ANS>::kRawBitWords];  // dense types: raw sync bit per node
   uint16_t smooth[DecCfg<ANS>::kSmoothSlots];  // ultra-dense: bit15 scale 0, bits 0..13 raw dist_q2
   uint32_t crc_table[DecCfg<ANS>::kCrcWords];  // HQ: slicing-by-4 tables
+  uint32_t stage[DecCfg<ANS>::kStageWords];    // HQ: per wave, 64 frames x 16 words (+1 pad)
   uint32_t tmp[40];
   uint32_t misc[8];  // 0 status, 3 last sync out, 4 last dist out, 5 error count
 };
@@ -200,18 +263,30 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
 
   // ---- P1: per frame: framing check (unframed input only), checksum, header word ---------
   uint32_t my_err = 0, unframed = 0;
-  for (uint32_t k = tid; k < nf && (DecCfg<ANS>::kTable || !foff); k += kDecBlock) {
+  if (ANS == RPLGPU_ANS_HQ) {  // handler_hqnode.cpp:99-172, a wave per 64 frames
+    uint32_t *stg = L.stage + wave_id() * (64u * 17u);
+    for (uint32_t k0 = wave_id() * 64u; k0 < nf; k0 += kDecBlock) {
+      const uint32_t k = k0 + lane_id();
+      const bool live = k < nf;
+      const uint32_t my_off = live ? (foff ? foff[k] : k * S) : 0u;
+      const uint32_t res = hq_crc_64frames(base, my_off, min(nf - k0, 64u), stg, L.crc_table);
+      if (live) {
+        if (!foff && (res >> 8) != 0xA5u) unframed = 1;
+        L.frame[k] = (res & 1u) ? 0x80000000u : 0u;
+        my_err += (res & 1u) ? 0u : 1u;
+      }
+    }
+  }
+  for (uint32_t k = tid; k < nf && ANS != RPLGPU_ANS_HQ && (DecCfg<ANS>::kTable || !foff);
+       k += kDecBlock) {
     const uint8_t *f = frame_ptr(k);
     uint32_t rec = 0;
     if (ANS == RPLGPU_ANS_MEASUREMENT) {  // handler_normalnode.cpp:88-112
       const uint32_t b0 = ld8(f), b1 = ld8(f + 1);
       if (!foff && !((((b0 >> 1) ^ b0) & 1u) && (b1 & 1u))) unframed = 1;
       continue;  // nothing to tabulate
-    } else if (ANS == RPLGPU_ANS_HQ) {  // handler_hqnode.cpp:99-172
-      if (!foff && ld8(f) != 0xA5u) unframed = 1;
-      const bool ok = crc32_padded(f, S - 4u, L.crc_table) == ld32(f + S - 4u);
-      rec = ok ? 0x80000000u : 0u;
-      my_err += ok ? 0u : 1u;
+    } else if (ANS == RPLGPU_ANS_HQ) {
+      continue;  // done above
     } else {  // the four capsule types: handler_capsules.cpp:107-194 and siblings
       const uint32_t b0 = ld8(f), b1 = ld8(f + 1);
       if (!foff && ((b0 >> 4) != 0xAu || (b1 >> 4) != 0x5u)) unframed = 1;
