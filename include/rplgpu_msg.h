@@ -129,6 +129,26 @@ int32_t rplgpu_cloud_msgs_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t o
                               uint8_t *d_msgs, uint32_t msg_stride, uint32_t *d_msg_len,
                               uint32_t *d_status);
 
+
+/* ---- several sensors -> one fused cloud (first step) ------------------ */
+/* Rigid transform of the clouds of B scans, in place: d_pose holds B row-major 3x4 matrices
+ * [R | t] (tf2: target frame <- frame_id of scan b; the reference itself only ever broadcasts
+ * the identity, src/rplidar_node.cpp:183-197).  Same addressing as rplgpu_cloud_msgs_dev
+ * (d_scan_start = NULL: per-scan regions of out_stride points; else the arena).  float32,
+ *   x' = ((r00*x + r01*y) + r02*z) + t0   (products, then sums left to right, no FMA),
+ * y', z' likewise, intensity untouched. */
+int32_t rplgpu_transform_clouds_dev(rplgpu_handle_t h, float *d_xyzi, uint32_t out_stride,
+                                    const uint64_t *d_scan_start, const uint32_t *d_n_points,
+                                    uint32_t B, const float *d_pose);
+/* The whole arena as ONE serialised PointCloud2 (the fused cloud of BASELINE config 5):
+ * width = min(*d_total_points, arena_capacity) with d_total_points the arena cursor of
+ * rplgpu_cloud_arena_dev — no host round trip.  *d_msg_len (device) = serialised size, or 0 +
+ * RPLGPU_SCAN_OUT_TRUNCATED in *d_status when msg_capacity is too small. */
+int32_t rplgpu_fused_cloud_msg_dev(rplgpu_handle_t h, const float *d_arena,
+                                   const uint64_t *d_total_points, uint64_t arena_capacity,
+                                   const char *frame_id, rplgpu_stamp_t stamp, uint8_t *d_msg,
+                                   uint64_t msg_capacity, uint64_t *d_msg_len, uint32_t *d_status);
+
 #ifdef __cplusplus
 }
 #endif

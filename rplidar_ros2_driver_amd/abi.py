@@ -73,6 +73,8 @@ ABI_SYMBOLS = [
     "rplgpu_scan_to_cloud_msg",
     "rplgpu_laserscan_msgs_dev",
     "rplgpu_cloud_msgs_dev",
+    "rplgpu_transform_clouds_dev",
+    "rplgpu_fused_cloud_msg_dev",
 ]
 
 
@@ -224,6 +226,8 @@ def load_library() -> C.CDLL:
     lib.rplgpu_laserscan_msgs_dev.argtypes = [vp, vp, vp, u32, vp, u32, C.POINTER(Params), cs,
                                               vp, vp, vp, u32, vp, vp]
     lib.rplgpu_cloud_msgs_dev.argtypes = [vp, vp, u32, vp, vp, u32, cs, vp, vp, u32, vp, vp]
+    lib.rplgpu_transform_clouds_dev.argtypes = [vp, vp, u32, vp, vp, u32, vp]
+    lib.rplgpu_fused_cloud_msg_dev.argtypes = [vp, vp, vp, u64, cs, Stamp, vp, u64, vp, vp]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default
@@ -408,6 +412,20 @@ class RplGpu:
         self._check(self._lib.rplgpu_cloud_msgs_dev(
             self._h, d_xyzi, out_stride, d_scan_start, d_n_points, B, frame_id.encode(),
             d_stamps, d_msgs, msg_stride, d_msg_len, d_status))
+
+    def transform_clouds_dev(self, d_xyzi: int, out_stride: int, d_scan_start: int,
+                             d_n_points: int, B: int, d_pose: int):
+        """In-place rigid transform of B clouds, one row-major 3x4 float pose per scan."""
+        self._check(self._lib.rplgpu_transform_clouds_dev(
+            self._h, d_xyzi, out_stride, d_scan_start, d_n_points, B, d_pose))
+
+    def fused_cloud_msg_dev(self, d_arena: int, d_total_points: int, arena_capacity: int,
+                            frame_id: str, sec: int, nanosec: int, d_msg: int, msg_capacity: int,
+                            d_msg_len: int, d_status: int = 0):
+        """The whole arena as one serialised PointCloud2 in device memory."""
+        self._check(self._lib.rplgpu_fused_cloud_msg_dev(
+            self._h, d_arena, d_total_points, arena_capacity, frame_id.encode(),
+            Stamp(sec, nanosec), d_msg, msg_capacity, d_msg_len, d_status))
 
     # -- decode stage: recorded answer streams -> nodes -> scans (SURVEY §8(f) rows 1-2) -----
     def decode_stream(self, ans_type: int, data: np.ndarray, sample_duration_us: int = 125,

@@ -82,4 +82,14 @@ hipError_t launch_msg_cloud(hipStream_t s, const float *xyzi, uint32_t out_strid
                             const rplmsg::Prefix &P, uint8_t *msgs, uint32_t msg_stride,
                             uint32_t *msg_len, uint32_t *status);
 
+hipError_t launch_msg_fused(hipStream_t s, const float *arena,
+                            const unsigned long long *total_points,
+                            unsigned long long arena_capacity, rplgpu_stamp_t stamp,
+                            const rplmsg::Prefix &P, uint8_t *msg, unsigned long long msg_capacity,
+                            unsigned long long *msg_len, uint32_t *status);
+// several sensors into one frame (rpl_fuse.hip)
+hipError_t launch_transform_clouds(hipStream_t s, float *xyzi, uint32_t out_stride,
+                                   uint32_t max_points, const unsigned long long *scan_start,
+                                   const uint32_t *n_points, uint32_t B, const float *pose);
+
 }  // namespace rpl

@@ -113,7 +113,53 @@ __global__ __launch_bounds__(kMsgThreads) void k_msg_cloud(
   }
 }
 
+// The whole arena (clouds of every scan, e.g. of several sensors after rpl_fuse.hip) as ONE
+// PointCloud2: width = *total points (a device word: the arena cursor), no host round trip.
+__global__ __launch_bounds__(kMsgThreads) void k_msg_fused(
+    const uint32_t *__restrict__ arena, const unsigned long long *__restrict__ total_points,
+    unsigned long long arena_capacity, rplgpu_stamp_t stamp, rplmsg::Prefix P,
+    uint8_t *__restrict__ msg8, unsigned long long msg_capacity,
+    unsigned long long *__restrict__ msg_len, uint32_t *__restrict__ status) {
+  const unsigned long long np = min(*total_points, arena_capacity);  // the cursor may overshoot
+  const unsigned long long total = (unsigned long long)P.len + 16ull * np + 1ull;
+  const bool fits = total <= msg_capacity && np < (1ull << 28);  // 32-bit lengths on the wire
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *msg_len = fits ? total : 0ull;
+    if (status && !fits) atomicOr(status, RPLGPU_SCAN_OUT_TRUNCATED);
+  }
+  if (!fits) return;
+  uint32_t *msg = reinterpret_cast<uint32_t *>(msg8);
+  if (blockIdx.x == 0) {
+    put_prefix(msg, P);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      msg[P.stamp_off / 4] = (uint32_t)stamp.sec;
+      msg[P.stamp_off / 4 + 1] = stamp.nanosec;
+      msg[P.a_off / 4] = (uint32_t)np;
+      msg[P.b_off / 4] = 16u * (uint32_t)np;
+      msg[P.c_off / 4] = 16u * (uint32_t)np;
+      msg8[(size_t)P.len + 16ull * np] = 1;  // is_dense
+    }
+  }
+  uint32_t *out = msg + P.len / 4;
+  const unsigned long long nw = 4ull * np;
+  for (unsigned long long j = (unsigned long long)blockIdx.x * kMsgThreads + threadIdx.x; j < nw;
+       j += (unsigned long long)gridDim.x * kMsgThreads)
+    out[j] = arena[j];
+}
+
 }  // namespace
+
+hipError_t launch_msg_fused(hipStream_t s, const float *arena,
+                            const unsigned long long *total_points,
+                            unsigned long long arena_capacity, rplgpu_stamp_t stamp,
+                            const rplmsg::Prefix &P, uint8_t *msg, unsigned long long msg_capacity,
+                            unsigned long long *msg_len, uint32_t *status) {
+  hipLaunchKernelGGL(k_msg_fused, dim3(2048), dim3(kMsgThreads), 0, s,
+                     reinterpret_cast<const uint32_t *>(arena), total_points, arena_capacity, stamp,
+                     P, msg, msg_capacity, msg_len, status);
+  return hipGetLastError();
+}
 
 hipError_t launch_msg_laserscan(hipStream_t s, const float *ranges, const float *intens,
                                 uint32_t n_stride, const uint32_t *beam_count, uint32_t B,

@@ -1066,4 +1066,35 @@ int32_t rplgpu_cloud_msgs_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t o
   return RPLGPU_OK;
 }
 
+int32_t rplgpu_transform_clouds_dev(rplgpu_handle_t h, float *d_xyzi, uint32_t out_stride,
+                                    const uint64_t *d_scan_start, const uint32_t *d_n_points,
+                                    uint32_t B, const float *d_pose) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  if (B == 0) return RPLGPU_OK;
+  if (!d_xyzi || !d_n_points || !d_pose || (!d_scan_start && out_stride == 0))
+    return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  const uint32_t max_points = d_scan_start ? h->max_n : std::min(out_stride, h->max_n);
+  RPL_HIP(h, rpl::launch_transform_clouds(
+                 h->stream, d_xyzi, out_stride, max_points,
+                 reinterpret_cast<const unsigned long long *>(d_scan_start), d_n_points, B, d_pose));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_fused_cloud_msg_dev(rplgpu_handle_t h, const float *d_arena,
+                                   const uint64_t *d_total_points, uint64_t arena_capacity,
+                                   const char *frame_id, rplgpu_stamp_t stamp, uint8_t *d_msg,
+                                   uint64_t msg_capacity, uint64_t *d_msg_len, uint32_t *d_status) {
+  if (!h || !frame_id || !d_arena || !d_total_points || !d_msg || !d_msg_len)
+    return RPLGPU_ERR_INVALID_ARG;
+  rplmsg::Prefix P;
+  if (int32_t rc = make_prefix(h, frame_id, true, nullptr, &P)) return rc;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_msg_fused(h->stream, d_arena,
+                                   reinterpret_cast<const unsigned long long *>(d_total_points),
+                                   arena_capacity, stamp, P, d_msg, msg_capacity,
+                                   reinterpret_cast<unsigned long long *>(d_msg_len), d_status));
+  return RPLGPU_OK;
+}
+
 }  // extern "C"

@@ -211,3 +211,73 @@ def test_cloud_msgs_dev_from_regions_and_arena(gpu, oracle):
     assert not d_st.cpu().numpy().any()
     assert np.array_equal(d_ml.cpu().numpy(), ml)
     assert d_msgs2.cpu().numpy().tobytes() == msgs.tobytes()
+
+
+def test_c5_fused_cloud_message_with_sensor_poses(gpu, oracle):
+    """BASELINE config 5 as one message: 8 sensors, each with its own mounting pose; per-sensor
+    clip -> radius-outlier removal -> voxel grid into the arena, rigid transform of every cloud
+    into the common frame, then the whole arena as ONE serialised PointCloud2 — all on the
+    device.  Against the oracle clouds transformed by oracle/fusion_oracle.py and serialised by
+    oracle/cdr_oracle.py."""
+    import torch
+    import fusion_oracle as fo
+    S, n = 8, 32000
+    batch = np.stack([synth.make_scan(700 + s, 0, n, noise_m=0.01) for s in range(S)])
+    dev = torch.device("cuda:0")
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(S, n * 8)).to(dev)
+    d_len = torch.full((S,), n, dtype=torch.int32, device=dev)
+    p = Params.defaults(clip_enable=1, range_max=40.0, ror_enable=1, voxel_enable=1)
+    cap = S * 16384
+    d_arena = torch.zeros(cap, 4, dtype=torch.float32, device=dev)
+    d_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_start = torch.zeros(S, dtype=torch.int64, device=dev)
+    d_np = torch.zeros(S, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(S, dtype=torch.int32, device=dev)
+    gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), S, p, d_arena.data_ptr(), cap,
+                        d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+    poses = np.stack([fo.planar_pose(0.7 * s - 1.0, 0.35 * s, -0.2 * s, 0.05 * s) for s in range(S)])
+    poses[3] = np.array([[0.36, 0.48, -0.8, 1.0], [-0.8, 0.6, 0.0, 2.0], [0.48, 0.64, 0.6, 0.5]],
+                        np.float32)  # a tilted mount: full 3-D rotation
+    d_pose = torch.from_numpy(poses.reshape(S, 12)).to(dev)
+    gpu.transform_clouds_dev(d_arena.data_ptr(), 0, d_start.data_ptr(), d_np.data_ptr(), S,
+                             d_pose.data_ptr())
+    msg_cap = abi.msg_cloud_layout(len(FID), cap).total_len
+    d_msg = torch.full((msg_cap,), 0xEE, dtype=torch.uint8, device=dev)
+    d_ml = torch.zeros(1, dtype=torch.int64, device=dev)
+    gpu.fused_cloud_msg_dev(d_arena.data_ptr(), d_cur.data_ptr(), cap, FID, 99, 7,
+                            d_msg.data_ptr(), msg_cap, d_ml.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    assert not d_st.cpu().numpy().any()
+    total, ml = int(d_cur.item()), int(d_ml.item())
+    starts, npts = d_start.cpu().numpy(), d_np.cpu().numpy()
+    arena = d_arena.cpu().numpy()
+    msg = d_msg.cpu().numpy()
+    # the message is the arena, whatever order the scans completed in
+    assert msg[:ml].tobytes() == cdr.cloud_msg(FID, 99, 7, arena[:total])
+    assert np.all(msg[ml:] == 0xEE)
+    for s in range(S):
+        want, _, _ = oracle.cloud_pipeline(batch[s], oracle_lib.copy_params(p))
+        assert npts[s] == len(want)
+        got = arena[starts[s]: starts[s] + npts[s]]
+        ref = fo.transform_cloud(want, poses[s])
+        # the voxel centroids agree with the oracle to 1e-6 m (bit-exact for |x|,|y| >= 3 cm), the
+        # transform adds at most a few ulp of the translated coordinates on top
+        assert np.max(np.abs(got[:, :3].astype(np.float64) - ref[:, :3])) <= 3e-6
+        assert got[:, 3].tobytes() == ref[:, 3].tobytes()
+    # the transform itself, on exactly known inputs: bit for bit
+    pts = np.random.default_rng(4).uniform(-40, 40, (S, 5000, 4)).astype(np.float32)
+    d_pts = torch.from_numpy(pts).to(dev)
+    d_cnt = torch.from_numpy(np.array([5000, 0, 1, 4999, 17, 4096, 4097, 5000], np.int32)).to(dev)
+    gpu.transform_clouds_dev(d_pts.data_ptr(), 5000, 0, d_cnt.data_ptr(), S, d_pose.data_ptr())
+    gpu.synchronize()
+    out, cnt = d_pts.cpu().numpy(), d_cnt.cpu().numpy()
+    for s in range(S):
+        assert out[s, : cnt[s]].tobytes() == fo.transform_cloud(pts[s, : cnt[s]], poses[s]).tobytes()
+        assert out[s, cnt[s]:].tobytes() == pts[s, cnt[s]:].tobytes()  # nothing past the cloud
+    # a message buffer too small: length 0 + flag, nothing written
+    d_msg.fill_(0xEE)
+    gpu.fused_cloud_msg_dev(d_arena.data_ptr(), d_cur.data_ptr(), cap, FID, 99, 7,
+                            d_msg.data_ptr(), ml - 1, d_ml.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    assert int(d_ml.item()) == 0 and int(d_st[0].item()) & abi.SCAN_OUT_TRUNCATED
+    assert bool((d_msg == 0xEE).all())
