@@ -334,8 +334,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
     }
     __syncthreads();
     RPL_MARK(4)
-    // rank inside the row = number of smaller entries of the same row (rows are short on
-    // ring-like scans: the first 8 entries are compared without a loop), then permute the
+    // rank inside the row = number of smaller entries of the same row, then permute the
     // records in place (they are all in registers; nobody reads rec now)
 #pragma unroll
     for (int k = 0; k < (int)kRecPerThread; ++k) {
@@ -344,21 +343,37 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
         const uint32_t row = (mine[k].x >> 16) & (kRowCap - 1u);
         const uint32_t me = (mine[k].x << 16) | idx;
         const uint32_t s0 = L.rowstart[row], s1 = L.rowfill[row];
+        // the row segment [s0, s1) as aligned 16-byte blocks: the first and the last block are
+        // compared under position masks, the ones between them as they are; the first six
+        // reads are issued together (one LDS round trip covers rows of up to 24 records)
+        const uint32_t a0 = s0 & ~3u, e0 = (s1 + 3u) & ~3u;  // s1 > s0: this record is in it
         uint32_t rank = s0;
-#pragma unroll
-        for (uint32_t j = 0; j < 8; ++j) {
-          const uint32_t v = L.bucket[s0 + j];  // in bounds: the array is padded by 8
-          rank += ((s0 + j < s1) && (v < me)) ? 1u : 0u;
+        {
+          const uint4 v = *reinterpret_cast<const uint4 *>(&L.bucket[a0]);
+          rank += (a0 >= s0 && a0 < s1 && v.x < me) + (a0 + 1u >= s0 && a0 + 1u < s1 && v.y < me) +
+                  (a0 + 2u >= s0 && a0 + 2u < s1 && v.z < me) + (a0 + 3u < s1 && v.w < me);
         }
-        uint32_t m = s0 + 8u;
-        if (m < s1) {  // a long row (noisy scans, walls along x): 16-byte reads once aligned
-          const uint32_t ma = min((m + 3u) & ~3u, s1);
-          for (; m < ma; ++m) rank += (L.bucket[m] < me);
-          for (; m + 4u <= s1; m += 4u) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(&L.bucket[m]);
-            rank += (v.x < me) + (v.y < me) + (v.z < me) + (v.w < me);
+        if (e0 - a0 > 4u) {
+          const uint32_t l0 = e0 - 4u;  // last block: l0 >= a0 + 4 > s0
+          const uint4 w = *reinterpret_cast<const uint4 *>(&L.bucket[l0]);
+          rank += (w.x < me) + (l0 + 1u < s1 && w.y < me) + (l0 + 2u < s1 && w.z < me) +
+                  (l0 + 3u < s1 && w.w < me);
+#pragma unroll
+          for (uint32_t j = 1; j <= 4u; ++j) {
+            if (a0 + 4u * j < l0) {
+              const uint4 v = *reinterpret_cast<const uint4 *>(&L.bucket[a0 + 4u * j]);
+              rank += (v.x < me) + (v.y < me) + (v.z < me) + (v.w < me);
+            }
           }
-          for (; m < s1; ++m) rank += (L.bucket[m] < me);
+          for (uint32_t m = a0 + 20u; m < l0; m += 16u) {  // long rows: four blocks per trip
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+              if (m + 4u * j < l0) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(&L.bucket[m + 4u * j]);
+                rank += (v.x < me) + (v.y < me) + (v.z < me) + (v.w < me);
+              }
+            }
+          }
         }
         L.rec[rank] = mine[k];
       }
