@@ -61,6 +61,9 @@ def parse_args():
                     help="target wall time of the CPU baseline sample (0 disables)")
     ap.add_argument("--no-laserscan", action="store_true",
                     help="skip the secondary ascend+LaserScan measurement")
+    ap.add_argument("--no-c5", action="store_true",
+                    help="skip the secondary config-5 measurement (it launches the headline kernel "
+                         "on a small noisy batch; profiles of the headline launch use this flag)")
     ap.add_argument("--no-decode", action="store_true",
                     help="skip the secondary decode-stage measurement (capsules -> nodes -> scans)")
     return ap.parse_args()
@@ -390,7 +393,7 @@ def main():
 
     if not args.no_decode and rank == 0:
         extra.update(decode_stage(gpu, dev, stream, args.cpu_seconds))
-    if not args.no_laserscan and rank == 0:
+    if not args.no_laserscan and not args.no_c5 and rank == 0:
         # secondary: BASELINE config 5 shape — 8 sensors x 32 frames of 32 000 samples with 1 cm
         # range noise, E5 radius-outlier removal + voxel grid into one fused cloud (arena)
         Bc = min(256, B)

@@ -9,7 +9,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     if name.startswith("void "):
         name = name[5:]
     return name.replace("rpl::", "")
