@@ -3,9 +3,9 @@
 Every scan is independent, so a batch shards by contiguous scan index with no exchange
 needed to *compute*; one exchange *assembles* the result: a variable-length all-gather
 of the per-rank packed clouds.  With ``torch.distributed`` backend ``nccl`` this is RCCL
-over xGMI (fully connected, point-to-point links): counts first (8 x int64), then one
-padded ``all_gather_into_tensor`` so each link carries 1/G of the payload exactly once —
-no ring all-reduce anywhere.  The same code runs on ``gloo`` with CPU tensors, which is
+over xGMI (fully connected, point-to-point links): counts first (3 x int64 per rank), then one
+padded ``all_gather_into_tensor`` — the per-scan table riding behind the points — so each link
+carries 1/G of the payload exactly once; no ring all-reduce anywhere.  The same code runs on ``gloo`` with CPU tensors, which is
 how the N>1 logic is tested without GPUs.
 """
 from __future__ import annotations
@@ -31,7 +31,8 @@ def allgather_clouds(packed: torch.Tensor, n_points: int, scan_counts: torch.Ten
                      group=None, scan_starts: torch.Tensor | None = None):
     """All-gather variable-length clouds.
 
-    packed       (cap, 4) float32 — this rank's contiguous cloud, first ``n_points`` rows valid
+    packed       (cap, 4) float32 — this rank's contiguous cloud, first ``n_points`` rows valid;
+                 rows past ``n_points`` are scratch (the per-scan table may be written there)
     scan_counts  (B_local,) int32/int64 — points per local scan (so receivers can split)
     scan_starts  optional (B_local,) int64 — first row of every local scan when the cloud is an
                  *arena* (``rplgpu_cloud_arena_dev``: scans in completion order); without it the
@@ -42,31 +43,54 @@ def allgather_clouds(packed: torch.Tensor, n_points: int, scan_counts: torch.Ten
     """
     world = dist.get_world_size(group)
     dev = packed.device
-    meta = torch.tensor([int(n_points), int(scan_counts.numel())], dtype=torch.int64, device=dev)
+    meta = torch.tensor([int(n_points), int(scan_counts.numel()), int(packed.shape[0])],
+                        dtype=torch.int64, device=dev)
     # outputs are allocated flat (concatenation along dim 0): the one layout both the
     # nccl (RCCL) and gloo implementations of all_gather_into_tensor accept
-    metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    metas = torch.empty(world * 3, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(metas, meta, group=group)
-    metas_h = metas.view(world, 2).cpu()
+    metas_h = metas.view(world, 3).cpu()
     max_pts = int(metas_h[:, 0].max())
     max_scans = int(metas_h[:, 1].max())
 
-    send = packed[:max_pts] if packed.shape[0] >= max_pts else torch.cat(
-        [packed, packed.new_zeros(max_pts - packed.shape[0], 4)])
-    send = send.contiguous().view(-1)
-    recv = torch.empty(world * max_pts * 4, dtype=packed.dtype, device=dev)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.view(world, max_pts, 4)
-
-    # per-scan counts (and arena starts) travel in one small exchange
+    # per-scan counts (and arena starts) as one small int64 table
     cols = 2 if scan_starts is not None else 1
-    cnt_send = torch.zeros(cols, max_scans, dtype=torch.int64, device=dev)
-    cnt_send[0, : scan_counts.numel()] = scan_counts.to(torch.int64)
+    table = torch.zeros(cols, max_scans, dtype=torch.int64, device=dev)
+    table[0, : scan_counts.numel()] = scan_counts.to(torch.int64)
     if scan_starts is not None:
-        cnt_send[1, : scan_starts.numel()] = scan_starts.to(torch.int64)
-    cnt_recv = torch.empty(world * cols * max_scans, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(cnt_recv, cnt_send.view(-1), group=group)
-    cnt_recv = cnt_recv.view(world, cols, max_scans)
+        table[1, : scan_starts.numel()] = scan_starts.to(torch.int64)
+    table_rows = (cols * max_scans * 8 + 15) // 16  # cloud rows (16 B) the table occupies
+
+    # When every rank's buffer has room behind max_pts (an arena always has: it is sized for the
+    # worst case), the table rides in those rows and ONE collective moves everything; the rows
+    # past n_points are scratch by contract.  All ranks take the same branch: the capacities
+    # travelled with the counts.
+    in_band = (packed.dtype == torch.float32 and packed.is_contiguous()
+               and int(metas_h[:, 2].min()) >= max_pts + table_rows)
+    allgather_clouds.last_in_band = bool(in_band)  # (for the tests)
+    if in_band:
+        rows = max_pts + table_rows
+        if table_rows:
+            packed[max_pts:rows].view(torch.int64).view(-1)[: cols * max_scans] = table.view(-1)
+        send = packed[:rows].view(-1)
+        recv = torch.empty(world * rows * 4, dtype=packed.dtype, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        recv = recv.view(world, rows, 4)
+        if table_rows:
+            cnt_recv = recv[:, max_pts:].reshape(world, -1).view(torch.int64)[:, : cols * max_scans]
+            cnt_recv = cnt_recv.reshape(world, cols, max_scans)
+        else:
+            cnt_recv = torch.zeros(world, cols, 0, dtype=torch.int64, device=dev)
+    else:
+        send = packed[:max_pts] if packed.shape[0] >= max_pts else torch.cat(
+            [packed, packed.new_zeros(max_pts - packed.shape[0], 4)])
+        send = send.contiguous().view(-1)
+        recv = torch.empty(world * max_pts * 4, dtype=packed.dtype, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        recv = recv.view(world, max_pts, 4)
+        cnt_recv = torch.empty(world * cols * max_scans, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(cnt_recv, table.view(-1), group=group)
+        cnt_recv = cnt_recv.view(world, cols, max_scans)
 
     clouds: List[torch.Tensor] = []
     counts: List[torch.Tensor] = []

@@ -87,6 +87,21 @@ def _worker(rank, world, port, total, n, q):
             full2 += split_by_scan(a_clouds[r], a_counts[r], a_starts[r])
         ok = ok and len(full2) == total and all(
             f.numpy().tobytes() == w.tobytes() for f, w in zip(full2, ref))
+        # a roomy arena (the real one is sized for the worst case): the per-scan table rides
+        # behind the points and one collective moves everything
+        roomy = torch.zeros(at + 4096, 4)
+        roomy[:at] = arena[:at]
+        ok = ok and allgather_clouds.last_in_band is False  # the tight arena above: two collectives
+        b_clouds, b_counts, b_starts = allgather_clouds(roomy, at, counts, scan_starts=starts)
+        ok = ok and allgather_clouds.last_in_band is True
+        full3 = []
+        for r in range(world):
+            full3 += split_by_scan(b_clouds[r], b_counts[r], b_starts[r])
+        ok = ok and roomy[:at].numpy().tobytes() == arena[:at].numpy().tobytes()  # points intact
+        ok = ok and len(full3) == total and all(
+            f.numpy().tobytes() == w.tobytes() for f, w in zip(full3, ref))
+        c_clouds, c_counts = allgather_clouds(roomy, at, counts)  # in-band, counts only
+        ok = ok and all(torch.equal(c_counts[r], b_counts[r]) for r in range(world))
         q.put((rank, bool(ok), len(full)))
     finally:
         dist.destroy_process_group()
