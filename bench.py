@@ -257,9 +257,8 @@ def main():
         gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
                             d_arena.data_ptr(), arena_cap, d_cursor.data_ptr(),
                             d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
-        if world > 1:
-            total = int(d_cursor.item())
-            return allgather_clouds(d_arena, total, d_np, scan_starts=d_start)
+        if world > 1:  # the cursor stays on the device: one host sync (the sizes) per exchange
+            return allgather_clouds(d_arena, d_cursor, d_np, scan_starts=d_start)
         return None
 
     def fence():

@@ -27,12 +27,14 @@ def shard_range(total: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, hi
 
 
-def allgather_clouds(packed: torch.Tensor, n_points: int, scan_counts: torch.Tensor,
+def allgather_clouds(packed: torch.Tensor, n_points, scan_counts: torch.Tensor,
                      group=None, scan_starts: torch.Tensor | None = None):
     """All-gather variable-length clouds.
 
     packed       (cap, 4) float32 — this rank's contiguous cloud, first ``n_points`` rows valid;
                  rows past ``n_points`` are scratch (the per-scan table may be written there)
+    n_points     int, or a 1-element integer tensor on ``packed``'s device (the arena cursor; it
+                 is clamped to the capacity, as the kernel clamps what it writes)
     scan_counts  (B_local,) int32/int64 — points per local scan (so receivers can split)
     scan_starts  optional (B_local,) int64 — first row of every local scan when the cloud is an
                  *arena* (``rplgpu_cloud_arena_dev``: scans in completion order); without it the
@@ -43,8 +45,13 @@ def allgather_clouds(packed: torch.Tensor, n_points: int, scan_counts: torch.Ten
     """
     world = dist.get_world_size(group)
     dev = packed.device
-    meta = torch.tensor([int(n_points), int(scan_counts.numel()), int(packed.shape[0])],
-                        dtype=torch.int64, device=dev)
+    if torch.is_tensor(n_points):  # e.g. the arena cursor, still on the device: no host round trip
+        meta = torch.cat([n_points.reshape(1).to(torch.int64).clamp(max=int(packed.shape[0])),
+                          torch.tensor([int(scan_counts.numel()), int(packed.shape[0])],
+                                       dtype=torch.int64, device=dev)])
+    else:
+        meta = torch.tensor([int(n_points), int(scan_counts.numel()), int(packed.shape[0])],
+                            dtype=torch.int64, device=dev)
     # outputs are allocated flat (concatenation along dim 0): the one layout both the
     # nccl (RCCL) and gloo implementations of all_gather_into_tensor accept
     metas = torch.empty(world * 3, dtype=torch.int64, device=dev)

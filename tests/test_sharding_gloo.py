@@ -100,8 +100,9 @@ def _worker(rank, world, port, total, n, q):
         ok = ok and roomy[:at].numpy().tobytes() == arena[:at].numpy().tobytes()  # points intact
         ok = ok and len(full3) == total and all(
             f.numpy().tobytes() == w.tobytes() for f, w in zip(full3, ref))
-        c_clouds, c_counts = allgather_clouds(roomy, at, counts)  # in-band, counts only
+        c_clouds, c_counts = allgather_clouds(roomy, torch.tensor([at]), counts)  # device-side count
         ok = ok and all(torch.equal(c_counts[r], b_counts[r]) for r in range(world))
+        ok = ok and all(c_clouds[r].shape == b_clouds[r].shape for r in range(world))
         q.put((rank, bool(ok), len(full)))
     finally:
         dist.destroy_process_group()
