@@ -218,8 +218,12 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RPL_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, exchange, max over ranks)
+    # with a single rank — the only way to exercise it on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("RPL_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B_total, n = args.scans, args.samples
@@ -257,12 +261,12 @@ def main():
         gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
                             d_arena.data_ptr(), arena_cap, d_cursor.data_ptr(),
                             d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
-        if world > 1:  # the cursor stays on the device: one host sync (the sizes) per exchange
+        if use_dist:  # the cursor stays on the device: one host sync (the sizes) per exchange
             return allgather_clouds(d_arena, d_cursor, d_np, scan_starts=d_start)
         return None
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -274,14 +278,14 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # N > 1: the same K steps without the exchange (SURVEY.md §8e asks for both curves)
     compute_only = None
-    if world > 1:
+    if use_dist:
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -471,7 +475,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     gpu.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -281,3 +281,53 @@ def test_c5_fused_cloud_message_with_sensor_poses(gpu, oracle):
     gpu.synchronize()
     assert int(d_ml.item()) == 0 and int(d_st[0].item()) & abi.SCAN_OUT_TRUNCATED
     assert bool((d_msg == 0xEE).all())
+
+
+def test_allgather_clouds_on_device_single_rank_rccl(gpu):
+    """The N > 1 exchange code with CUDA tensors and the nccl (= RCCL) backend, world size 1 —
+    everything but a second GPU: device-side count, in-band table, views, splits."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from rplidar_ros2_driver_amd.sharding import allgather_clouds, split_by_scan
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda:0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        B, n = 12, 3000
+        batch, lens, d_nodes, d_len = _batch(torch, 91, B, n)
+        pv = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
+        cap = B * 4096
+        d_arena = torch.zeros(cap, 4, dtype=torch.float32, device=dev)
+        d_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_start = torch.zeros(B, dtype=torch.int64, device=dev)
+        d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+        gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, pv, d_arena.data_ptr(),
+                            cap, d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(),
+                            d_st.data_ptr())
+        gpu.synchronize()
+        want = d_arena.clone()
+        clouds, counts, starts = allgather_clouds(d_arena, d_cur, d_np, scan_starts=d_start)
+        assert allgather_clouds.last_in_band
+        torch.cuda.synchronize()
+        total = int(d_cur.item())
+        assert len(clouds) == 1 and clouds[0].shape == (total, 4)
+        assert torch.equal(clouds[0], want[:total])
+        assert torch.equal(counts[0].cpu(), d_np.cpu().to(torch.int64))
+        assert torch.equal(starts[0].cpu(), d_start.cpu())
+        per_scan = split_by_scan(clouds[0], counts[0], starts[0])
+        for b in range(B):
+            a = int(d_start[b])
+            assert torch.equal(per_scan[b], want[a: a + int(d_np[b])])
+        # a buffer without room behind the points: the two-collective branch, same result
+        tight = want[:total].clone()
+        c2, n2, s2 = allgather_clouds(tight, total, d_np, scan_starts=d_start)
+        assert not allgather_clouds.last_in_band
+        assert torch.equal(c2[0], clouds[0]) and torch.equal(n2[0], counts[0])
+    finally:
+        if created:
+            dist.destroy_process_group()
