@@ -461,6 +461,9 @@ def main():
                 "kernel_ms_avg": round(k_ms_avg, 4),
                 "kernel_ms_min": round(k_ms[0], 4),
                 "algorithmic_bytes": algo_bytes,
+                "note": "priced against HBM as SURVEY 8(d) asks; the binding resource is vector "
+                        "issue: SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 4 waves per SIMD) = 0.69 "
+                        "in profiles/r01/rocprof_summary_v9.txt (DESIGN.md section 8)",
             },
             "cpu_baseline": cpu,
             "compute_only": compute_only,
