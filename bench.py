@@ -424,6 +424,39 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         cpu = cpu_baseline(batch_np, lens_np, params, args.cpu_seconds)
 
+    if rank == 0 and not args.no_laserscan and not args.no_c5:
+        # secondary: BASELINE config 2 — ONE 32 000-sample scan through the host-buffer entry
+        # points the node calls per scan (H2D + kernels + D2H + sync), wall clock per call
+        one = np.ascontiguousarray(batch_np[0])
+        pl1 = Params.defaults(range_max=40.0)
+        pin = gpu.host_alloc(1 << 20)
+        lat = {}
+        for name, fn in (
+            ("laserscan", lambda: gpu.scan_to_laserscan(one, pl1, 0.1)),
+            ("laserscan_msg_pinned", lambda: gpu.scan_to_laserscan_msg(one, pl1, 0.1, "laser_frame",
+                                                                       1, 2, out=pin)),
+            ("voxel_cloud", lambda: gpu.scan_to_cloud(one, params)),
+        ):
+            for _ in range(20):
+                fn()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                fn()
+            lat[name] = (time.perf_counter() - t0) / 200 * 1e6
+        gpu.host_free(pin)
+        extra["single_scan_us"] = {k: round(v, 1) for k, v in lat.items()}
+        if args.cpu_seconds > 0:  # the CPU loop the node runs today, same scan, one core
+            from tests import oracle_lib
+            orc = oracle_lib.load_oracle()
+            op = oracle_lib.copy_params(pl1)
+            t0 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t0 < 0.5:
+                orc.publish_scan(one, op, 0.1)
+                reps += 1
+            extra["single_scan_us"]["cpu_publish_scan_oracle"] = round(
+                (time.perf_counter() - t0) / reps * 1e6, 1)
+
     if rank == 0:
         traffic, traffic_src = measured_traffic("k_cloud_voxel", B, n)
         ms_per_step = elapsed / args.steps * 1e3
