@@ -497,6 +497,10 @@ def main():
                 "note": "priced against HBM as SURVEY 8(d) asks; the binding resource is vector "
                         "issue: SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 4 waves per SIMD) = 0.69 "
                         "in profiles/r01/rocprof_summary_v9.txt (DESIGN.md section 8)",
+                # SQ_INSTS_VALU of that profile: 167.6 M wave-instructions per 131.072 M samples
+                "valu": {"lane_ops_per_sample": 81.9,
+                         "peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
+                         "frac": round(B * n / (k_ms_avg * 1e-3) * 81.9 / (256 * 4 * 16 * 2.4e9), 4)},
             },
             "cpu_baseline": cpu,
             "compute_only": compute_only,
