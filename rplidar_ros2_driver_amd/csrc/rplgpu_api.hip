@@ -48,6 +48,7 @@ struct rplgpu_ctx {
 namespace {
 
 constexpr uint32_t kMaskStride = rpl::kMaxN / 32u;  // keep-mask words per scan
+constexpr size_t kTail = 64;  // bytes behind a staging region for the words that travel with it
 
 thread_local std::string g_create_err;
 
@@ -257,6 +258,19 @@ int32_t run_laserscan(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride,
   return RPLGPU_OK;
 }
 
+// Single-scan staging (pinned host side): nodes | length word ... results | result words.
+inline unsigned char *stage_out(const rplgpu_ctx *c) { return c->h_pin + (size_t)c->max_n * 8 + kTail; }
+
+// nodes + their count to the device in ONE copy; *d_n = device address of the count word
+int32_t upload_scan(rplgpu_ctx *c, const rplgpu_node_t *nodes, size_t n, const uint32_t **d_n) {
+  std::memcpy(c->h_pin, nodes, n * 8);
+  const uint32_t words[2] = {(uint32_t)n, 0u};  // count, status (cleared)
+  std::memcpy(c->h_pin + n * 8, words, 8);
+  RPL_HIP(c, hipMemcpyAsync(c->d_nodes, c->h_pin, n * 8 + 8, hipMemcpyHostToDevice, c->stream));
+  *d_n = reinterpret_cast<const uint32_t *>(c->d_nodes + n * 8);
+  return RPLGPU_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -347,9 +361,11 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
     return fail(rc);
 
   const size_t n = c->max_n;
-  if (hipHostMalloc((void **)&c->h_pin, n * 8 + n * 16 + 64, hipHostMallocDefault) != hipSuccess ||
-      hipMalloc((void **)&c->d_nodes, n * 8) != hipSuccess ||
-      hipMalloc((void **)&c->d_out, n * 16) != hipSuccess ||
+  // single-scan staging: the length word travels right behind the nodes and the result words
+  // right behind the results, so that a call is one copy in and one copy out
+  if (hipHostMalloc((void **)&c->h_pin, n * 8 + n * 16 + 2 * kTail, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void **)&c->d_nodes, n * 8 + kTail) != hipSuccess ||
+      hipMalloc((void **)&c->d_out, n * 16 + kTail) != hipSuccess ||
       hipMalloc((void **)&c->d_small, 128) != hipSuccess) {
     c->err = "staging allocation failed";
     return fail(RPLGPU_ERR_HIP);
@@ -530,17 +546,16 @@ int32_t rplgpu_ascend(rplgpu_handle_t h, rplgpu_node_t *nodes, size_t n, uint32_
     return RPLGPU_OK;
   }
   RPL_HIP(h, hipSetDevice(h->device));
-  uint32_t *h_small = reinterpret_cast<uint32_t *>(h->h_pin + (size_t)h->max_n * 24);
-  std::memcpy(h->h_pin, nodes, n * 8);
-  h_small[0] = (uint32_t)n;
-  RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
-  RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
-  RPL_HIP(h, rpl::launch_ascend(h->stream, h->d_nodes, (uint32_t)n, h->d_small, 1, h->d_small + 2,
+  const uint32_t *d_n;
+  if (int32_t rc = upload_scan(h, nodes, n, &d_n)) return rc;
+  uint32_t *d_status = const_cast<uint32_t *>(d_n) + 1;  // travels back with the nodes
+  RPL_HIP(h, rpl::launch_ascend(h->stream, h->d_nodes, (uint32_t)n, d_n, 1, d_status,
                                 h->d_small + 20));
-  RPL_HIP(h, hipMemcpyAsync(h->h_pin, h->d_nodes, n * 8, hipMemcpyDeviceToHost, h->stream));
-  RPL_HIP(h, hipMemcpyAsync(h_small + 2, h->d_small + 2, 4, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h->h_pin, h->d_nodes, n * 8 + 8, hipMemcpyDeviceToHost, h->stream));
   RPL_HIP(h, hipStreamSynchronize(h->stream));
-  const bool all_invalid = (h_small[2] & RPLGPU_SCAN_ALL_INVALID) != 0;
+  uint32_t st;
+  std::memcpy(&st, h->h_pin + n * 8 + 4, 4);
+  const bool all_invalid = (st & RPLGPU_SCAN_ALL_INVALID) != 0;
   if (!all_invalid) std::memcpy(nodes, h->h_pin, n * 8);
   if (sl_result) *sl_result = all_invalid ? 0x80008001u : 0u;
   return RPLGPU_OK;
@@ -554,21 +569,18 @@ int32_t rplgpu_scan_to_laserscan(rplgpu_handle_t h, const rplgpu_node_t *nodes, 
   std::memset(meta, 0, sizeof(*meta));
   if (n == 0) return RPLGPU_OK;  // :561-563
   RPL_HIP(h, hipSetDevice(h->device));
-  uint32_t *h_small = reinterpret_cast<uint32_t *>(h->h_pin + (size_t)h->max_n * 24);
-  unsigned char *h_out = h->h_pin + (size_t)h->max_n * 8;
-  std::memcpy(h->h_pin, nodes, n * 8);
-  h_small[0] = (uint32_t)n;
+  unsigned char *h_out = stage_out(h);
+  const uint32_t *d_n;
+  if (int32_t rc = upload_scan(h, nodes, n, &d_n)) return rc;
   float *d_r = reinterpret_cast<float *>(h->d_out);
   float *d_i = d_r + n;
-  RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
-  RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
-  if (int32_t lrc = run_laserscan(h, h->d_nodes, (uint32_t)n, h->d_small, 1, *p, d_r, d_i,
-                                  h->d_small + 1))
+  uint32_t *d_count = reinterpret_cast<uint32_t *>(d_i + n);  // travels back with the arrays
+  if (int32_t lrc = run_laserscan(h, h->d_nodes, (uint32_t)n, d_n, 1, *p, d_r, d_i, d_count))
     return lrc;
-  RPL_HIP(h, hipMemcpyAsync(h_out, h->d_out, n * 8, hipMemcpyDeviceToHost, h->stream));
-  RPL_HIP(h, hipMemcpyAsync(h_small + 1, h->d_small + 1, 4, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h_out, h->d_out, n * 8 + 4, hipMemcpyDeviceToHost, h->stream));
   RPL_HIP(h, hipStreamSynchronize(h->stream));
-  const uint32_t count = h_small[1];
+  uint32_t count;
+  std::memcpy(&count, h_out + n * 8, 4);
   rplgpu_fill_meta(p, count, scan_duration, meta);
   if (count) {
     std::memcpy(ranges, h_out, (size_t)count * 4);
@@ -585,21 +597,19 @@ int32_t rplgpu_scan_to_cloud(rplgpu_handle_t h, const rplgpu_node_t *nodes, size
   *n_points = 0;
   if (status) *status = 0;
   if (n == 0) return RPLGPU_OK;
-  uint32_t *h_small = reinterpret_cast<uint32_t *>(h->h_pin + (size_t)h->max_n * 24);
-  unsigned char *h_out = h->h_pin + (size_t)h->max_n * 8;
-  std::memcpy(h->h_pin, nodes, n * 8);
-  h_small[0] = (uint32_t)n;
+  unsigned char *h_out = stage_out(h);
   RPL_HIP(h, hipSetDevice(h->device));
-  RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
-  RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
+  const uint32_t *d_n;
+  if (int32_t urc = upload_scan(h, nodes, n, &d_n)) return urc;
+  uint32_t *d_words = reinterpret_cast<uint32_t *>(h->d_out + n * 16);  // n_points, status
   int32_t rc = rplgpu_cloud_batch_dev(h, reinterpret_cast<const rplgpu_node_t *>(h->d_nodes),
-                                      (uint32_t)n, h->d_small, 1, p,
-                                      reinterpret_cast<float *>(h->d_out), (uint32_t)n,
-                                      h->d_small + 1, h->d_small + 2);
+                                      (uint32_t)n, d_n, 1, p, reinterpret_cast<float *>(h->d_out),
+                                      (uint32_t)n, d_words, d_words + 1);
   if (rc) return rc;
-  RPL_HIP(h, hipMemcpyAsync(h_out, h->d_out, n * 16, hipMemcpyDeviceToHost, h->stream));
-  RPL_HIP(h, hipMemcpyAsync(h_small + 1, h->d_small + 1, 8, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h_out, h->d_out, n * 16 + 8, hipMemcpyDeviceToHost, h->stream));
   RPL_HIP(h, hipStreamSynchronize(h->stream));
+  uint32_t h_small[3] = {0, 0, 0};
+  std::memcpy(h_small + 1, h_out + n * 16, 8);
   *n_points = h_small[1];
   if (status) *status = h_small[2];
   std::memcpy(xyzi, h_out, (size_t)h_small[1] * 16);
@@ -917,19 +927,17 @@ int32_t rplgpu_scan_to_laserscan_msg(rplgpu_handle_t h, const rplgpu_node_t *nod
     return RPLGPU_ERR_CAPACITY;
   }
   RPL_HIP(h, hipSetDevice(h->device));
-  uint32_t *h_small = reinterpret_cast<uint32_t *>(h->h_pin + (size_t)h->max_n * 24);
-  std::memcpy(h->h_pin, nodes, n * 8);
-  h_small[0] = (uint32_t)n;
+  uint32_t *h_small = reinterpret_cast<uint32_t *>(stage_out(h));  // pinned scratch word
+  const uint32_t *d_n;
+  if (int32_t rc = upload_scan(h, nodes, n, &d_n)) return rc;
   float *d_r = reinterpret_cast<float *>(h->d_out);
   float *d_i = d_r + n;
-  RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
-  RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
-  if (int32_t lrc = run_laserscan(h, h->d_nodes, (uint32_t)n, h->d_small, 1, *p, d_r, d_i,
-                                  h->d_small + 1))
+  uint32_t *d_count = reinterpret_cast<uint32_t *>(d_i + n);
+  if (int32_t lrc = run_laserscan(h, h->d_nodes, (uint32_t)n, d_n, 1, *p, d_r, d_i, d_count))
     return lrc;
-  RPL_HIP(h, hipMemcpyAsync(h_small + 1, h->d_small + 1, 4, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipMemcpyAsync(h_small, d_count, 4, hipMemcpyDeviceToHost, h->stream));
   RPL_HIP(h, hipStreamSynchronize(h->stream));
-  const uint32_t count = h_small[1];
+  const uint32_t count = h_small[0];
   rplgpu_fill_meta(p, count, scan_duration, meta);
   if (count == 0) return RPLGPU_OK;  // :611-613: nothing is published
   if (int32_t rc = rplgpu_msg_laserscan_header(frame_id, stamp, meta, msg, cap, &L)) return rc;
@@ -959,20 +967,19 @@ int32_t rplgpu_scan_to_cloud_msg(rplgpu_handle_t h, const rplgpu_node_t *nodes, 
     h->err = "message buffer smaller than the worst case (n points)";
     return RPLGPU_ERR_CAPACITY;
   }
-  uint32_t *h_small = reinterpret_cast<uint32_t *>(h->h_pin + (size_t)h->max_n * 24);
+  uint32_t *h_small = reinterpret_cast<uint32_t *>(stage_out(h));  // pinned scratch words
   h_small[1] = h_small[2] = 0;
   if (n) {
-    std::memcpy(h->h_pin, nodes, n * 8);
-    h_small[0] = (uint32_t)n;
     RPL_HIP(h, hipSetDevice(h->device));
-    RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8, hipMemcpyHostToDevice, h->stream));
-    RPL_HIP(h, hipMemcpyAsync(h->d_small, h_small, 4, hipMemcpyHostToDevice, h->stream));
+    const uint32_t *d_n;
+    if (int32_t urc = upload_scan(h, nodes, n, &d_n)) return urc;
+    uint32_t *d_words = reinterpret_cast<uint32_t *>(h->d_out + n * 16);  // n_points, status
     int32_t rc = rplgpu_cloud_batch_dev(h, reinterpret_cast<const rplgpu_node_t *>(h->d_nodes),
-                                        (uint32_t)n, h->d_small, 1, p,
+                                        (uint32_t)n, d_n, 1, p,
                                         reinterpret_cast<float *>(h->d_out), (uint32_t)n,
-                                        h->d_small + 1, h->d_small + 2);
+                                        d_words, d_words + 1);
     if (rc) return rc;
-    RPL_HIP(h, hipMemcpyAsync(h_small + 1, h->d_small + 1, 8, hipMemcpyDeviceToHost, h->stream));
+    RPL_HIP(h, hipMemcpyAsync(h_small + 1, d_words, 8, hipMemcpyDeviceToHost, h->stream));
     RPL_HIP(h, hipStreamSynchronize(h->stream));
   }
   const uint32_t np = h_small[1];
