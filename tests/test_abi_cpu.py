@@ -120,3 +120,30 @@ def test_host_framer_matches_oracle_framing(oracle):
     lib = abi.load_library()
     assert lib.rplgpu_frame_size(0x42) == 0 and lib.rplgpu_nodes_per_frame(0x85) == 40
     assert lib.rplgpu_decode_max_frames(0x86) == 512 and lib.rplgpu_decode_max_frames(0x85) == 2048
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing in the package (Python, C++ host mirror, HIP
+    sources, the Makefiles) may import, include, link or open anything under oracle/ or
+    /root/reference.  bench.py may, in its cpu_baseline legs only, through tests/oracle_lib.py."""
+    pkg = ROOT / "rplidar_ros2_driver_amd"
+    pat = re.compile(r"oracle|/root/reference|liboracle|_ref/")
+    offenders = []
+    for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.hpp")) + \
+            list(pkg.rglob("*.cpp")) + list(pkg.rglob("Makefile")) + list((ROOT / "include").glob("*.h")):
+        for ln, line in enumerate(f.read_text().splitlines(), 1):
+            code = line.split("//")[0].split("#")[0] if f.suffix in (".hip", ".hpp", ".cpp", ".h") else line
+            if f.suffix == ".py":
+                code = line.split("#")[0]
+                if code.strip().startswith(('"""', "'''")) or "``" in code:
+                    continue
+            if pat.search(code) and ("import" in code or "include" in code or "open(" in code
+                                     or "CDLL" in code or "-l" in code or "Path(" in code):
+                offenders.append(f"{f.relative_to(ROOT)}:{ln}: {line.strip()}")
+    assert not offenders, "\n".join(offenders)
+    bench = (ROOT / "bench.py").read_text()
+    assert "from tests import oracle_lib" in bench  # the cpu_baseline legs, and only those:
+    for m in re.finditer(r"oracle_lib\.", bench):
+        head = bench[: m.start()]
+        fn = re.findall(r"\ndef (\w+)\(", head)[-1]
+        assert fn in ("cpu_baseline", "decode_stage", "main"), fn
