@@ -140,6 +140,22 @@ int32_t rplgpu_cloud_msgs_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t o
 int32_t rplgpu_transform_clouds_dev(rplgpu_handle_t h, float *d_xyzi, uint32_t out_stride,
                                     const uint64_t *d_scan_start, const uint32_t *d_n_points,
                                     uint32_t B, const float *d_pose);
+/* Motion de-skew of the plain cloud (E1 clip, E2 polar -> XYZ, optionally the E5 mask; not
+ * with voxel_enable): d_motion holds per scan (vx, vy, wz, time_increment) — the sensor's planar
+ * twist in its own frame at the first sample [m/s, m/s, rad/s] and the time between samples [s]
+ * (LaserScan.time_increment, src/rplidar_node.cpp:637,668).  Sample i (its index in the scan as
+ * handed in, i.e. acquisition order) was taken at tau = float(i) * time_increment; its point
+ * moves to the sensor pose at the first sample:
+ *   a = wz * tau;  a2 = a * a
+ *   s = a * (1 + a2 * (-1/6 + a2 * (1/120)))            (Horner, every operation rounded to
+ *   c = 1 + a2 * (-1/2 + a2 * (1/24 + a2 * (-1/720)))    float32 once, no FMA)
+ *   x' = (c*x - s*y) + vx*tau;   y' = (s*x + c*y) + vy*tau
+ * valid for |a| <= 0.5 rad (polynomial error < 2e-8).  Output as rplgpu_cloud_batch_dev. */
+int32_t rplgpu_cloud_deskew_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
+                                      uint32_t n_stride, const uint32_t *d_n_per_scan, uint32_t B,
+                                      const rplgpu_params_t *p, const float *d_motion,
+                                      float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,
+                                      uint32_t *d_status);
 /* The whole arena as ONE serialised PointCloud2 (the fused cloud of BASELINE config 5):
  * width = min(*d_total_points, arena_capacity) with d_total_points the arena cursor of
  * rplgpu_cloud_arena_dev — no host round trip.  *d_msg_len (device) = serialised size, or 0 +

@@ -40,3 +40,33 @@ def planar_pose(yaw_rad: float, tx: float, ty: float, tz: float = 0.0) -> np.nda
     """A 2-D lidar mounted flat: rotation about z + translation, as a (3, 4) float32 [R | t]."""
     c, s = np.float32(np.cos(yaw_rad)), np.float32(np.sin(yaw_rad))
     return np.array([[c, -s, 0, tx], [s, c, 0, ty], [0, 0, 1, tz]], np.float32)
+
+
+def deskew_cloud(xyzi: np.ndarray, sample_index: np.ndarray, motion) -> np.ndarray:
+    """E6 motion de-skew (include/rplgpu_msg.h): xyzi (n, 4) float32 = the plain cloud,
+    sample_index (n,) = input index of every kept sample, motion = (vx, vy, wz, time_increment).
+    Every operation rounded to float32, in the documented order."""
+    f = np.float32
+    p = np.asarray(xyzi, np.float32).reshape(-1, 4)
+    vx, vy, wz, dt = (f(v) for v in motion)
+    tau = (np.asarray(sample_index).astype(np.float32) * dt).astype(np.float32)
+    a = (wz * tau).astype(np.float32)
+    a2 = (a * a).astype(np.float32)
+    ts = (a2 * (f(1.0) / f(120.0))).astype(np.float32)
+    ts = (ts + (f(-1.0) / f(6.0))).astype(np.float32)
+    ts = (a2 * ts).astype(np.float32)
+    ts = (ts + f(1.0)).astype(np.float32)
+    sn = (a * ts).astype(np.float32)
+    tc = (a2 * (f(-1.0) / f(720.0))).astype(np.float32)
+    tc = (tc + (f(1.0) / f(24.0))).astype(np.float32)
+    tc = (a2 * tc).astype(np.float32)
+    tc = (tc + f(-0.5)).astype(np.float32)
+    tc = (a2 * tc).astype(np.float32)
+    cn = (tc + f(1.0)).astype(np.float32)
+    x, y = p[:, 0], p[:, 1]
+    out = p.copy()
+    out[:, 0] = (((cn * x).astype(np.float32) - (sn * y).astype(np.float32)).astype(np.float32)
+                 + (vx * tau).astype(np.float32)).astype(np.float32)
+    out[:, 1] = (((sn * x).astype(np.float32) + (cn * y).astype(np.float32)).astype(np.float32)
+                 + (vy * tau).astype(np.float32)).astype(np.float32)
+    return out

@@ -75,6 +75,7 @@ ABI_SYMBOLS = [
     "rplgpu_cloud_msgs_dev",
     "rplgpu_transform_clouds_dev",
     "rplgpu_fused_cloud_msg_dev",
+    "rplgpu_cloud_deskew_batch_dev",
 ]
 
 
@@ -228,6 +229,8 @@ def load_library() -> C.CDLL:
     lib.rplgpu_cloud_msgs_dev.argtypes = [vp, vp, u32, vp, vp, u32, cs, vp, vp, u32, vp, vp]
     lib.rplgpu_transform_clouds_dev.argtypes = [vp, vp, u32, vp, vp, u32, vp]
     lib.rplgpu_fused_cloud_msg_dev.argtypes = [vp, vp, vp, u64, cs, Stamp, vp, u64, vp, vp]
+    lib.rplgpu_cloud_deskew_batch_dev.argtypes = [
+        vp, vp, u32, vp, u32, C.POINTER(Params), vp, vp, u32, vp, vp]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default
@@ -418,6 +421,14 @@ class RplGpu:
         """In-place rigid transform of B clouds, one row-major 3x4 float pose per scan."""
         self._check(self._lib.rplgpu_transform_clouds_dev(
             self._h, d_xyzi, out_stride, d_scan_start, d_n_points, B, d_pose))
+
+    def cloud_deskew_batch_dev(self, d_nodes: int, n_stride: int, d_n_per_scan: int, B: int,
+                               params: Params, d_motion: int, d_xyzi: int, out_stride: int,
+                               d_n_points: int, d_status: int = 0):
+        """Plain clouds with motion de-skew; d_motion: B x (vx, vy, wz, time_increment) float32."""
+        self._check(self._lib.rplgpu_cloud_deskew_batch_dev(
+            self._h, d_nodes, n_stride, d_n_per_scan, B, C.byref(params), d_motion, d_xyzi,
+            out_stride, d_n_points, d_status))
 
     def fused_cloud_msg_dev(self, d_arena: int, d_total_points: int, arena_capacity: int,
                             frame_id: str, sec: int, nanosec: int, d_msg: int, msg_capacity: int,

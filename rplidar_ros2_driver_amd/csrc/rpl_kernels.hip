@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_cloud(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
     float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
-    uint32_t *__restrict__ status) {
+    uint32_t *__restrict__ status, const float *__restrict__ motion) {
   __shared__ uint64_t s_mask[kChunks];
   __shared__ uint32_t s_cbase[kChunks];
   __shared__ uint32_t s_tmp[32];
@@ -368,6 +368,11 @@ __global__ __launch_bounds__(kBlock) void k_cloud(
   const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   const uint2 *scan = nodes + (size_t)b * n_stride;
   float4 *out = xyzi + (size_t)b * out_stride;
+  // E6 (include/rplgpu_msg.h): motion of the sensor during the scan, (vx, vy, wz, time_increment)
+  float mvx = 0.0f, mvy = 0.0f, mwz = 0.0f, mdt = 0.0f;
+  if (motion) {
+    mvx = motion[4 * b], mvy = motion[4 * b + 1], mwz = motion[4 * b + 2], mdt = motion[4 * b + 3];
+  }
 
   uint2 v[kIters];
   load_scan(scan, n, v);
@@ -399,8 +404,28 @@ __global__ __launch_bounds__(kBlock) void k_cloud(
       if (r < out_stride) {
         float dm = nd_dist_m(nd_dist(v[j]));
         float2 c = cs[nd_q14(v[j])];
-        out[r] = make_float4(dm * c.x, dm * c.y, 0.0f,
-                             nd_intensity(nd_quality(v[j]), p.is_new_protocol));
+        float x = dm * c.x, y = dm * c.y;
+        if (motion) {  // the point as seen from the sensor pose at the first sample
+          const float tau = (float)sample_index(j) * mdt;
+          const float a = mwz * tau, a2 = a * a;
+          // sin / cos as fixed polynomials (|a| <= 0.5 rad: error < 2e-8), every operation
+          // rounded once, in this order -- the oracle does the same, bit for bit
+          float ts = a2 * (1.0f / 120.0f);
+          ts = ts + (-1.0f / 6.0f);
+          ts = a2 * ts;
+          ts = ts + 1.0f;
+          const float sn = a * ts;
+          float tc = a2 * (-1.0f / 720.0f);
+          tc = tc + (1.0f / 24.0f);
+          tc = a2 * tc;
+          tc = tc + (-0.5f);
+          tc = a2 * tc;
+          const float cn = tc + 1.0f;
+          const float x1 = (cn * x - sn * y) + mvx * tau;
+          const float y1 = (sn * x + cn * y) + mvy * tau;
+          x = x1, y = y1;
+        }
+        out[r] = make_float4(x, y, 0.0f, nd_intensity(nd_quality(v[j]), p.is_new_protocol));
       }
     }
   }
@@ -465,7 +490,8 @@ hipError_t launch_laserscan_raw(hipStream_t s, const void *nodes, uint32_t n_str
 hipError_t launch_cloud(hipStream_t s, const void *nodes, uint32_t n_stride,
                         const uint32_t *n_per_scan, uint32_t B, const KParams &p, const Tables &T,
                         bool voxel, const uint32_t *keepmask, uint32_t mask_stride, float *xyzi,
-                        uint32_t out_stride, uint32_t *n_points, uint32_t *status) {
+                        uint32_t out_stride, uint32_t *n_points, uint32_t *status,
+                        const float *motion) {
   if (B == 0) return hipSuccess;
   if (voxel) {
     return launch_cloud_voxel(s, nodes, n_stride, n_per_scan, B, p, T, keepmask, mask_stride, xyzi,
@@ -473,7 +499,7 @@ hipError_t launch_cloud(hipStream_t s, const void *nodes, uint32_t n_stride,
   } else {
     hipLaunchKernelGGL(k_cloud, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
                        n_per_scan, p, T, keepmask, mask_stride, (float4 *)xyzi, out_stride,
-                       n_points, status);
+                       n_points, status, motion);
   }
   return hipGetLastError();
 }

@@ -32,7 +32,8 @@ hipError_t launch_laserscan_raw(hipStream_t s, const void *nodes, uint32_t n_str
 hipError_t launch_cloud(hipStream_t s, const void *nodes, uint32_t n_stride,
                         const uint32_t *n_per_scan, uint32_t B, const KParams &p, const Tables &T,
                         bool voxel, const uint32_t *keepmask, uint32_t mask_stride, float *xyzi,
-                        uint32_t out_stride, uint32_t *n_points, uint32_t *status);
+                        uint32_t out_stride, uint32_t *n_points, uint32_t *status,
+                        const float *motion = nullptr);  // E6 de-skew (plain cloud only)
 hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_stride,
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                               const Tables &T, const uint32_t *keepmask, uint32_t mask_stride,

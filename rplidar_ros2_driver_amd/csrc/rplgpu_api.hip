@@ -1104,4 +1104,25 @@ int32_t rplgpu_fused_cloud_msg_dev(rplgpu_handle_t h, const float *d_arena,
   return RPLGPU_OK;
 }
 
+int32_t rplgpu_cloud_deskew_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
+                                      uint32_t n_stride, const uint32_t *d_n_per_scan, uint32_t B,
+                                      const rplgpu_params_t *p, const float *d_motion,
+                                      float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,
+                                      uint32_t *d_status) {
+  int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
+  if (rc) return rc;
+  if (!p || !d_motion || !d_xyzi || !d_n_points || out_stride == 0) return RPLGPU_ERR_INVALID_ARG;
+  if (p->voxel_enable) {
+    h->err = "de-skew works on the plain cloud (voxel_enable = 0)";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  rpl::KParams kp;
+  const uint32_t *mask = nullptr;
+  if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
+  RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(h),
+                               false, mask, kMaskStride, d_xyzi, out_stride, d_n_points, d_status,
+                               d_motion));
+  return RPLGPU_OK;
+}
+
 }  // extern "C"

@@ -331,3 +331,47 @@ def test_allgather_clouds_on_device_single_rank_rccl(gpu):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_deskewed_cloud_matches_oracle(gpu, oracle):
+    """E6 motion de-skew of the plain cloud (include/rplgpu_msg.h): bit for bit against the
+    numpy restatement applied to the oracle's cloud."""
+    import torch
+    import fusion_oracle as fo
+    B, n = 6, 5000
+    batch, lens, d_nodes, d_len = _batch(torch, 123, B, n)
+    dev = d_nodes.device
+    motion = np.array([[0.0, 0.0, 0.0, 0.0], [1.5, -0.7, 0.9, 2.0e-5], [0.0, 0.0, -3.0, 2.0e-5],
+                       [-12.0, 4.0, 0.0, 1.0e-4], [0.3, 0.2, 0.5, 3.125e-6], [2.0, 2.0, 4.9, 2.0e-5]],
+                      np.float32)
+    d_motion = torch.from_numpy(motion).to(dev)
+    d_xyzi = torch.zeros(B, n, 4, dtype=torch.float32, device=dev)
+    d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    for clip in (0, 1):
+        p = Params.defaults(clip_enable=clip, q_min=30 * clip, range_min=0.5, range_max=25.0,
+                            inverted=clip)
+        gpu.cloud_deskew_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p,
+                                   d_motion.data_ptr(), d_xyzi.data_ptr(), n, d_np.data_ptr(),
+                                   d_st.data_ptr())
+        gpu.synchronize()
+        got, npts = d_xyzi.cpu().numpy(), d_np.cpu().numpy()
+        for b in range(B):
+            nodes = batch[b, : lens[b]]
+            plain = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(p))
+            d = nodes["dist_mm_q2"]
+            dm = d.astype(np.float32) / np.float32(4000.0)
+            keep = d != 0
+            if clip:
+                keep &= (nodes["quality"] >= 30) & (dm >= np.float32(0.5)) & (dm <= np.float32(25.0))
+            idx = np.flatnonzero(keep)
+            assert len(idx) == len(plain) == npts[b]
+            want = fo.deskew_cloud(plain, idx, motion[b])
+            assert got[b, : npts[b]].tobytes() == want.tobytes(), (clip, b)
+            if b == 0:  # no motion: the plain cloud, untouched
+                assert want.tobytes() == plain.tobytes()
+    # voxel_enable is refused: de-skew belongs in front of the cell computation
+    with pytest.raises(abi.RplGpuError):
+        gpu.cloud_deskew_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B,
+                                   Params.defaults(voxel_enable=1), d_motion.data_ptr(),
+                                   d_xyzi.data_ptr(), n, d_np.data_ptr(), d_st.data_ptr())
