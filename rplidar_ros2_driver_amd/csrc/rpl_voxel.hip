@@ -432,19 +432,22 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
       const bool m1 = (r + 1u < nrec) && (q1.x == key);
       const bool m2 = m1 && (r + 2u < nrec) && (q2.x == key);
       double sx = (double)q0.y, sy = (double)q0.z;
-      uint32_t cw = q0.w;
-      if (m1) { sx += (double)q1.y; sy += (double)q1.z; cw += q1.w; }
+      // count and intensity sum are packed per RECORD (<= 128 samples: 16 bits each suffice);
+      // per CELL they are summed apart -- a large or close cell collects thousands of samples
+      // and its intensity sum passes 2^16 (found by tests/test_gpu_fuzz.py)
+      uint32_t cnt = q0.w >> 16, isum = q0.w & 0xFFFFu;
+      if (m1) { sx += (double)q1.y; sy += (double)q1.z; cnt += q1.w >> 16; isum += q1.w & 0xFFFFu; }
       if (m2) {
-        sx += (double)q2.y; sy += (double)q2.z; cw += q2.w;
+        sx += (double)q2.y; sy += (double)q2.z; cnt += q2.w >> 16; isum += q2.w & 0xFFFFu;
         for (r += 3u; r < nrec; ++r) {  // segmented sum over the rest of this cell's records
           const uint4 q = L.rec[r];
           if (q.x != key) break;
           sx += (double)q.y;
           sy += (double)q.z;
-          cw += q.w;
+          cnt += q.w >> 16;
+          isum += q.w & 0xFFFFu;
         }
       }
-      const uint32_t cnt = cw >> 16, isum = cw & 0xFFFFu;
       const double ix = (double)((int)(key & 0xFFFFu) - 32768);
       const double iy = (double)((int)(key >> 16) - 32768);
       // RN(1/count): from the LDS copy of the host-built table for small counts, else the IEEE
