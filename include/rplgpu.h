@@ -140,7 +140,8 @@ int32_t rplgpu_scan_to_cloud(rplgpu_handle_t h, const rplgpu_node_t *nodes, size
                              uint32_t *status);
 
 /* ---- batches, DEVICE-resident buffers (no host copies, async on the stream) */
-/* d_nodes: B scans, scan b at d_nodes + b*n_stride, d_n_per_scan[b] samples used. */
+/* d_nodes: B scans, scan b at d_nodes + b*n_stride, d_n_per_scan[b] samples used (clamped to
+ * n_stride and RPLGPU_MAX_SAMPLES_PER_SCAN: a kernel never reads past a scan's slot). */
 int32_t rplgpu_ascend_batch_dev(rplgpu_handle_t h, rplgpu_node_t *d_nodes, uint32_t n_stride,
                                 const uint32_t *d_n_per_scan, uint32_t B, uint32_t *d_status);
 /* d_ranges/d_intensities: B*n_stride floats; d_beam_count: B. */
