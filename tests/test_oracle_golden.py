@@ -114,6 +114,41 @@ def test_live_publish_scan_vs_real_node(oracle, reflibs):
             assert r.tobytes() == rr.tobytes() and i.tobytes() == ri.tobytes(), (name, kind, inv, sp)
 
 
+def test_live_publish_scan_fuzz_vs_real_node(oracle, reflibs):
+    """Random scans (duplicate angles, any u32 distance, every size class) through the oracle's
+    restatement and through the GENUINE RPlidarNode::publish_scan built from /root/reference:
+    both run libstdc++'s std::sort with the same comparator, so even the tie order agrees."""
+    if reflibs is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this box)")
+    rng = np.random.default_rng(11)
+    for t in range(400):
+        n = int(rng.choice([1, 2, 3, 17, 360, 1000, int(rng.integers(1, 5000))]))
+        x = np.zeros(n, oracle_lib.NODE)
+        x["angle_z_q14"] = rng.integers(0, 65536, n) if t % 3 else np.sort(rng.integers(0, 65536, n))
+        kind_d = t % 4
+        if kind_d == 0:
+            d = rng.integers(0, 2**32, n, dtype=np.uint64)
+        elif kind_d == 1:
+            d = rng.integers(0, 200000, n)
+        elif kind_d == 2:
+            d = rng.choice([0, 1, 599, 600, 47999, 48000, 48001, 4000], n)
+        else:
+            d = (rng.uniform(0.1, 30.0) * 4000 + rng.normal(0, 40, n)).clip(0, 2**32 - 1)
+        x["dist_mm_q2"] = (np.asarray(d, np.uint64) * (rng.random(n) > rng.random())).astype(np.uint32)
+        x["quality"] = rng.integers(0, 256, n)
+        x["flag"] = rng.integers(0, 4, n)
+        kind, inv, sp = int(rng.integers(0, 3)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        rmax = float(rng.choice([12.0, 40.0, 8.0]))
+        dur = float(rng.choice([0.1, 0.0731, 0.2]))
+        p = oracle_lib.params(is_new_protocol=int(kind == 2), inverted=inv, scan_processing=sp,
+                              range_max=rmax)
+        r, i, m = oracle.publish_scan(x, p, dur)
+        rr, ri, rm = reflibs.publish_scan(x, driver_kind=kind, inverted=inv, scan_processing=sp,
+                                          range_max=rmax, scan_duration=dur)
+        assert bytes(m) == bytes(rm), (t, n, kind, inv, sp)
+        assert r.tobytes() == rr.tobytes() and i.tobytes() == ri.tobytes(), (t, n, kind, inv, sp)
+
+
 # ---- extension oracle: internal consistency (parity unpinned, spec = SURVEY §8 a-ext) -----
 def test_clip_disabled_reduces_to_reference(oracle):
     nodes = CASES["c1_like_360"]

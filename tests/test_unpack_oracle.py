@@ -120,3 +120,43 @@ def test_unpack_matches_genuine_live(oracle, ans):
 
 
 test_unpack_matches_genuine_live.dense_last = 0
+
+
+def test_unpack_fuzz_vs_genuine_live(oracle):
+    """Random lengths, heavy fault rates and pure byte soup through the oracle's restatement and
+    through the GENUINE SDK unpackers + ScanDataHolder (fed in random chunk sizes)."""
+    ref = oracle_lib.load_ref_unpack()
+    if ref is None:
+        pytest.skip("oracle/_ref/libunpackref.so not built (no /root/reference here)")
+    rng = np.random.default_rng(4242)
+    for t in range(240):
+        ans = ALL_ANS[t % len(ALL_ANS)]
+        nf = int(rng.choice([1, 2, 3, 17, 64, int(rng.integers(1, 200))])) * (8 if ans == 0x81 else 1)
+        dur = int(rng.choice([125, 32, 20, 2, 1000000, 476]))
+        mode = int(rng.integers(0, 4))
+        frames = cp.make_frames(ans, nf, int(rng.integers(0, 1 << 30)),
+                                payload=str(rng.choice(["random", "ring"])),
+                                frames_per_rev=float(rng.choice([1.5, 3.1, 12.3, 40.0, 300.0])),
+                                first_sync=bool(rng.integers(0, 2)))
+        if mode == 0:
+            data = frames.reshape(-1)
+        elif mode == 1:
+            data = cp.corrupt_stream(ans, frames, int(rng.integers(0, 1 << 30)))
+        elif mode == 2:
+            data = cp.corrupt_stream(ans, frames, int(rng.integers(0, 1 << 30)), p_checksum=0.3,
+                                     p_sync=0.2, p_garbage=0.2, p_revstart=0.2, p_jump=0.2)
+        else:
+            data = rng.integers(0, 256, int(rng.integers(0, 3000)), dtype=np.uint8)
+        chunk = int(rng.choice([0, 1, 7, 84, 1000, 33]))
+        r_nodes, r_rst, r_err = ref.unpack(ans, data, dur, chunk=chunk)
+        last = test_unpack_matches_genuine_live.dense_last if ans == 0x85 else 0
+        o_nodes, o_rst, o_err, st = oracle.unpack(ans, data, dur, state=(last, 0))
+        if ans == 0x85:
+            test_unpack_matches_genuine_live.dense_last = st[0]
+        ctx = (t, hex(ans), nf, mode, chunk)
+        assert o_nodes.tobytes() == r_nodes.tobytes(), ctx
+        assert list(o_rst) == list(r_rst) and o_err == r_err, ctx
+        mc = int(rng.choice([64, 8192, 5]))
+        so, offs = oracle.segment(o_nodes, o_rst, mc)
+        rso, roffs = ref.segment(o_nodes, o_rst, mc)
+        assert so.tobytes() == rso.tobytes() and list(offs) == list(roffs), ctx
