@@ -66,8 +66,41 @@ def gen_cases():
     cases["c2_32000_newproto"] = synth.make_scan(11, 4, 32000, new_protocol=True, jitter=3)
     cases["full_32768_unsorted"] = synth.make_scan(11, 5, 32768, kind="uniform", jitter=2000,
                                                    rotate=True, invalid_p=0.3)
+    cases.update(random_scans())
     return cases
 
+
+def random_scans():
+    """Seeded random scans small enough for the golden fixtures: unique angle words (so the
+    reference's unstable sorts leave no choice), in sorted / rotated / shuffled order, with
+    distances from several awkward families."""
+    out = {}
+    rng = np.random.default_rng(20260923)
+    for k in range(16):
+        n = int(rng.choice([1, 5, 33, 64, 65, 129, 200, 300]))
+        m = np.zeros(n, NODE_DTYPE)
+        q = rng.choice(65536, size=n, replace=False)
+        if k % 3 == 0:
+            q = np.sort(q)
+        elif k % 3 == 1:
+            q = np.roll(np.sort(q), int(rng.integers(0, n)))
+        m["angle_z_q14"] = q
+        fam = k % 4
+        if fam == 0:
+            d = rng.integers(0, 2**32, n, dtype=np.uint64)
+        elif fam == 1:
+            d = rng.integers(600, 160001, n)
+        elif fam == 2:
+            d = rng.choice([1, 599, 600, 601, 47999, 48000, 48001, 159999, 160000, 160001], n)
+        else:
+            d = (rng.uniform(0.2, 30.0) * 4000 + rng.normal(0, 40, n)).clip(1, 2**32 - 1)
+        d = np.asarray(d, np.uint64)
+        d[rng.random(n) < [0.0, 0.1, 0.5, 0.9][k % 4]] = 0
+        m["dist_mm_q2"] = d.astype(np.uint32)
+        m["quality"] = rng.integers(0, 256, n)
+        m["flag"] = rng.integers(0, 4, n)
+        out[f"random_{k:02d}"] = m
+    return out
 
 
 CASES = gen_cases()
