@@ -29,7 +29,8 @@ struct Tables {
   const float2 *cs;        // (float)cos((double)angle), (float)sin((double)angle)
   const float2 *cs_inv;    // same for the inverted angle
   const double *rcp;       // rcp[c] = RN(1.0 / c), c = 1..32768 (voxel centroids), rcp[0] = 0
-  uint32_t *work_ctr;      // 2 words, zero between launches: dynamic scan queue of k_cloud_voxel
+  uint32_t *work_ctr;      // dynamic scan queue of k_cloud_voxel (one word, cleared by every launch)
+  uint32_t n_cu;           // compute units of the handle's device (persistent-workgroup grids)
 };
 
 struct KParams {

@@ -688,14 +688,6 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
   b = L.tmp[31];
   __syncthreads();
   }
-  // the last workgroup to leave rearms the queue for the next launch on this stream
-  if (threadIdx.x == 0) {
-    __threadfence();
-    if (atomicAdd(&T.work_ctr[1], 1u) == gridDim.x - 1u) {
-      T.work_ctr[0] = 0u;
-      T.work_ctr[1] = 0u;
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------
@@ -744,16 +736,14 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   ar.cursor = arena_cursor;
   ar.capacity = arena_capacity;
   ar.scan_start = scan_start;
-  static int n_cu = 0;  // one persistent workgroup per CU
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
+  // one persistent workgroup per CU of the handle's device; the scan queue is cleared by a
+  // memset ahead of every launch (an aborted launch can therefore not poison the next one)
+  uint32_t grid = std::min<uint32_t>(B, T.n_cu ? T.n_cu : 256u);
+  if (const char *e = std::getenv("RPLGPU_VOXEL_GRID")) {  // developer aid
+    const long g = std::atol(e);
+    if (g > 0) grid = std::min<uint32_t>(B, (uint32_t)g);
   }
-  uint32_t grid = std::min<uint32_t>(B, (uint32_t)n_cu);
-  if (const char *e = std::getenv("RPLGPU_VOXEL_GRID")) grid = std::min<uint32_t>(B, (uint32_t)std::atoi(e));
+  if (hipError_t e = hipMemsetAsync(T.work_ctr, 0, 4, s); e != hipSuccess) return e;
 #define RPL_LAUNCH_VOXEL(FD, SF)                                                              \
   hipLaunchKernelGGL((k_cloud_voxel<FD, SF>), dim3(grid), dim3(kBlock), 0, s, (const uint2 *)nodes, \
                      n_stride, n_per_scan, p, T, keepmask, mask_stride, (float4 *)xyzi, out_stride, \

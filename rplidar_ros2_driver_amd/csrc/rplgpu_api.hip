@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -42,6 +43,10 @@ struct rplgpu_ctx {
   bool leaf_ok = false;
   bool idx_checked = false, idx_ok = false;  // Mode A bin-index divide, see k_validate_idx
   unsigned long long *dbg = nullptr;  // developer aid: per-block phase cycle counters
+  uint32_t n_cu = 0;                  // compute units of `device`
+  unsigned char *d_dec = nullptr;     // rplgpu_decode_stream staging (grown on demand, kept)
+  size_t dec_cap = 0;
+  bool check_ptrs = true;             // batch entry points verify that buffers are device memory
   std::string err;
 };
 
@@ -138,7 +143,8 @@ rpl::Tables tables_of(const rplgpu_ctx *c) {
   t.cs = c->d_cs;
   t.cs_inv = c->d_cs_inv;
   t.rcp = c->d_rcp;
-  t.work_ctr = c->d_small + 16;  // [16] next scan, [17] finished workgroups (self-resetting)
+  t.work_ctr = c->d_small + 16;  // [16] next scan of k_cloud_voxel's queue (cleared per launch)
+  t.n_cu = c->n_cu;
   return t;
 }
 
@@ -198,9 +204,39 @@ void free_ctx(rplgpu_ctx *c) {
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->d_rormask) (void)hipFree(c->d_rormask);
   if (c->d_need_sort) (void)hipFree(c->d_need_sort);
+  if (c->d_dec) (void)hipFree(c->d_dec);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+}
+
+// A wrong pointer handed to a kernel is a GPU memory fault, and on this platform a fault ends
+// the whole process (the node would die instead of falling back to its CPU loop, cf.
+// src/rplidar_node.cpp:453-474).  So the batch entry points ask the runtime what a pointer is
+// before launching: it has to be device (or managed / mapped host) memory reachable from the
+// handle's device.  ~1 us per pointer against launches of >= tens of us.
+bool device_readable(rplgpu_ctx *c, const void *ptr, const char *what) {
+  if (!c->check_ptrs) return true;
+  hipPointerAttribute_t a;
+  std::memset(&a, 0, sizeof(a));
+  const hipError_t e = hipPointerGetAttributes(&a, ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // unregistered host memory: not an error state worth keeping
+    c->err = std::string(what) + " is not device-accessible memory";
+    return false;
+  }
+  if (a.type == hipMemoryTypeDevice && a.device != c->device) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, c->device, a.device) != hipSuccess || !can) {
+      c->err = std::string(what) + " lives on another device without peer access";
+      return false;
+    }
+  }
+  if (a.type == hipMemoryTypeUnregistered) {
+    c->err = std::string(what) + " is plain host memory";
+    return false;
+  }
+  return true;
 }
 
 int32_t check_batch(rplgpu_ctx *c, const void *nodes, uint32_t n_stride, const void *n_per_scan,
@@ -215,6 +251,8 @@ int32_t check_batch(rplgpu_ctx *c, const void *nodes, uint32_t n_stride, const v
     c->err = "batch larger than max_batch given to rplgpu_create";
     return RPLGPU_ERR_CAPACITY;
   }
+  if (!device_readable(c, nodes, "d_nodes") || !device_readable(c, n_per_scan, "d_n_per_scan"))
+    return RPLGPU_ERR_INVALID_ARG;
   return RPLGPU_OK;
 }
 
@@ -232,7 +270,7 @@ int32_t validate_divisor(rplgpu_ctx *c, float d, uint32_t e_lo, uint32_t e_hi, b
 
 // publish_scan on the handle's stream: Mode A (rpl_laserscan.hip) or Mode B.  The cheap
 // bin-index divide of Mode A is used only after it was compared with the IEEE divide for
-// every (beam count <= max_n, angle word, inverted or not) on this device, once per handle.
+// every (beam count <= 32768, angle word, inverted or not) on this device, once per handle.
 int32_t run_laserscan(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride,
                       const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t &p,
                       float *d_ranges, float *d_intens, uint32_t *d_beam_count) {
@@ -245,7 +283,9 @@ int32_t run_laserscan(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride,
   if (!c->idx_checked) {
     uint32_t zero = 0, bad = 1;
     RPL_HIP(c, hipMemcpyAsync(c->d_small + 8, &zero, 4, hipMemcpyHostToDevice, c->stream));
-    RPL_HIP(c, rpl::launch_validate_idx(c->stream, tables_of(c), c->d_inc, c->d_rinc, c->max_n,
+    // every beam count a kernel can meet (n_stride may exceed max_samples_per_scan of the handle;
+    // the kernels clamp to kMaxN), not just those up to max_n
+    RPL_HIP(c, rpl::launch_validate_idx(c->stream, tables_of(c), c->d_inc, c->d_rinc, rpl::kMaxN,
                                         c->d_small + 8));
     RPL_HIP(c, hipMemcpyAsync(&bad, c->d_small + 8, 4, hipMemcpyDeviceToHost, c->stream));
     RPL_HIP(c, hipStreamSynchronize(c->stream));
@@ -290,8 +330,9 @@ void rplgpu_default_params(rplgpu_params_t *p) {
 
 void rplgpu_fill_meta(const rplgpu_params_t *p, uint32_t count, double scan_duration,
                       rplgpu_scan_meta_t *meta) {
+  if (!meta) return;
   std::memset(meta, 0, sizeof(*meta));
-  if (count == 0) return;  // :611-613
+  if (count == 0 || !p) return;  // :611-613 (and: no parameters, nothing to publish)
   meta->published = 1;
   meta->count = count;
   meta->angle_min = 0.0f;          // :623
@@ -331,6 +372,8 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   c->device = device_id;
   c->max_n = max_samples_per_scan;
   c->max_b = max_batch;
+  c->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+  if (const char *e = std::getenv("RPLGPU_CHECK_POINTERS")) c->check_ptrs = std::atoi(e) != 0;
   auto fail = [&](int32_t code) {
     g_create_err = c->err;
     free_ctx(c);
@@ -366,16 +409,25 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   if (hipHostMalloc((void **)&c->h_pin, n * 8 + n * 16 + 2 * kTail, hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void **)&c->d_nodes, n * 8 + kTail) != hipSuccess ||
       hipMalloc((void **)&c->d_out, n * 16 + kTail) != hipSuccess ||
-      hipMalloc((void **)&c->d_small, 128) != hipSuccess) {
+      hipMalloc((void **)&c->d_small, 128) != hipSuccess ||
+      // per-call scratch of the batch entry points, sized once for max_batch (no allocation on
+      // the per-call paths): ascend's "needs the sorting kernel" list and the E5 keep bits
+      hipMalloc((void **)&c->d_need_sort, (size_t)c->max_b * 4u) != hipSuccess ||
+      hipMalloc((void **)&c->d_rormask, (size_t)c->max_b * kMaskStride * 4u) != hipSuccess) {
     c->err = "staging allocation failed";
     return fail(RPLGPU_ERR_HIP);
   }
+  c->need_sort_cap = c->max_b;
   if (hipMemset(c->d_small, 0, 128) != hipSuccess) {  // incl. the voxel kernel's scan queue
     c->err = "staging clear failed";
     return fail(RPLGPU_ERR_HIP);
   }
   // dist_mm_q2 / 4000.0f: operands are the integer-valued floats 1 .. 2^32
   if (validate_divisor(c, 4000.0f, 127, 159, &c->div4000_ok) != RPLGPU_OK) return fail(RPLGPU_ERR_HIP);
+  // the default leaf is validated here, so that the first cloud call does not have to stop the
+  // stream for it (any other leaf is validated, once, by the first call that uses it)
+  if (validate_divisor(c, 0.05f, 27, 167, &c->leaf_ok) != RPLGPU_OK) return fail(RPLGPU_ERR_HIP);
+  c->leaf_checked = 0.05f;
   *out = c;
   return RPLGPU_OK;
 }
@@ -395,7 +447,14 @@ const char *rplgpu_last_error(rplgpu_handle_t h) {
 
 int32_t rplgpu_set_stream(rplgpu_handle_t h, void *hip_stream) {
   if (!h) return RPLGPU_ERR_INVALID_ARG;
-  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  hipStream_t next = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  if (next != h->stream) {
+    // work queued on the old stream shares the handle's scratch (scan queue, staging, masks)
+    // with whatever is launched next: drain it before switching
+    RPL_HIP(h, hipSetDevice(h->device));
+    RPL_HIP(h, hipStreamSynchronize(h->stream));
+  }
+  h->stream = next;
   return RPLGPU_OK;
 }
 
@@ -426,13 +485,6 @@ int32_t rplgpu_ascend_batch_dev(rplgpu_handle_t h, rplgpu_node_t *d_nodes, uint3
   int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
   if (rc) return rc;
   RPL_HIP(h, hipSetDevice(h->device));
-  if (h->need_sort_cap < B) {
-    if (h->d_need_sort) (void)hipFree(h->d_need_sort);
-    h->d_need_sort = nullptr;
-    h->need_sort_cap = 0;
-    RPL_HIP(h, hipMalloc((void **)&h->d_need_sort, (size_t)B * 4u));
-    h->need_sort_cap = B;
-  }
   RPL_HIP(h, rpl::launch_ascend(h->stream, d_nodes, n_stride, d_n_per_scan, B, d_status,
                                 h->d_need_sort));
   return RPLGPU_OK;
@@ -476,8 +528,6 @@ static int32_t prepare_cloud(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, ui
   kp.dbg = h->dbg;
   *mask_out = nullptr;
   if (p->ror_enable) {  // E5 before E4: per-sample keep bits, then the cloud kernels apply them
-    if (!h->d_rormask)
-      RPL_HIP(h, hipMalloc((void **)&h->d_rormask, (size_t)h->max_b * kMaskStride * 4u));
     RPL_HIP(h, rpl::launch_ror_mask(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
                                     tables_of(h), h->d_rormask, kMaskStride));
     *mask_out = h->d_rormask;
@@ -769,12 +819,22 @@ int32_t rplgpu_decode_stream(rplgpu_handle_t h, uint8_t ans_type, uint32_t sampl
   RPL_HIP(h, hipSetDevice(h->device));
   const bool caps = ans_type != RPLGPU_ANS_MEASUREMENT && ans_type != RPLGPU_ANS_HQ;
   const size_t piece = std::min<size_t>(nf, rpl::decode_max_frames(ans_type));
-  // one-off device staging (this entry point is the convenience path; batches use *_batch_dev)
+  // device staging kept in the handle (grown when a longer recording arrives, never shrunk):
+  // every sub-buffer starts on a 16-byte boundary (the decoder stores nodes as 8-byte words)
+  auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
   const size_t node_cap = piece * npf, rcap = piece + 1;
-  const size_t sz_bytes = (nbytes + 15) & ~size_t(15), sz_off = piece * 4, sz_gap = (piece + 15) & ~size_t(15);
-  const size_t sz_nodes = node_cap * 8, sz_rst = rcap * 4, sz_small = 128;
-  unsigned char *d = nullptr;
-  RPL_HIP(h, hipMalloc(&d, sz_bytes + sz_off + sz_gap + sz_nodes + sz_rst + sz_small));
+  const size_t sz_bytes = up16(nbytes), sz_off = up16(piece * 4), sz_gap = up16(piece);
+  const size_t sz_nodes = up16(node_cap * 8), sz_rst = up16(rcap * 4), sz_small = 128;
+  const size_t need = sz_bytes + sz_off + sz_gap + sz_nodes + sz_rst + sz_small;
+  if (h->dec_cap < need) {
+    RPL_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->d_dec) (void)hipFree(h->d_dec);
+    h->d_dec = nullptr;
+    h->dec_cap = 0;
+    RPL_HIP(h, hipMalloc((void **)&h->d_dec, need));
+    h->dec_cap = need;
+  }
+  unsigned char *d = h->d_dec;
   unsigned char *d_b = d, *d_off = d_b + sz_bytes, *d_gap = d_off + sz_off;
   unsigned char *d_nodes = d_gap + sz_gap, *d_rst = d_nodes + sz_nodes, *d_small = d_rst + sz_rst;
   // d_small (u32): [0] n_frames [1] n_nodes [2] n_reset [3] n_err [4] status
@@ -831,7 +891,6 @@ int32_t rplgpu_decode_stream(rplgpu_handle_t h, uint8_t ans_type, uint32_t sampl
     done_nodes += got;
     first = lo + cnt;
   }
-  (void)hipFree(d);
   if (rc) return rc;
   *n_nodes = done_nodes;
   if (n_reset) *n_reset = done_resets;

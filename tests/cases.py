@@ -107,3 +107,7 @@ CASES = gen_cases()
 
 # cases small enough to ship as golden fixtures (inputs + genuine-reference outputs)
 GOLDEN_CASES = [k for k, v in CASES.items() if len(v) <= 1000]
+# the large cases (8192 ... 32768 samples, config 2's 32 000 among them) ship as SHA-256 digests
+# of the genuine reference's outputs (tests/golden/large_golden.npz, canonical forms of
+# tests/canon.py where the reference's order is introsort's): bit-exact work needs no more
+LARGE_GOLDEN_CASES = [k for k, v in CASES.items() if len(v) > 1000]

@@ -20,7 +20,8 @@ ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 
 from tests import oracle_lib  # noqa: E402
-from tests.cases import CASES, GOLDEN_CASES  # noqa: E402
+from tests import canon  # noqa: E402
+from tests.cases import CASES, GOLDEN_CASES, LARGE_GOLDEN_CASES  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
 
@@ -62,11 +63,54 @@ def main():
     np.savez_compressed(OUT / "publish_scan_golden.npz", **pub)
 
     dummy = {f"scan{k}": ref.dummy_grab() for k in range(3)}  # static phase: 0.1, 0.2, 0.3
+    for k in range(3):  # config 1 end to end: what the genuine node publishes for those scans
+        for inv in (0, 1):
+            for sp in (0, 1):
+                r, i, m = ref.publish_scan(dummy[f"scan{k}"], driver_kind=0, inverted=inv,
+                                           scan_processing=sp, range_max=40.0, scan_duration=0.1)
+                tag = f"scan{k}__i{inv}_s{sp}"
+                dummy[tag + "__ranges"] = r.copy()
+                dummy[tag + "__intens"] = i.copy()
+                dummy[tag + "__meta"] = np.frombuffer(bytes(m), np.uint8).copy()
     np.savez_compressed(OUT / "dummy_golden.npz", **dummy)
+    make_large_golden(ref)
     make_unpack_golden()
     for f in ("ascend_golden.npz", "publish_scan_golden.npz", "dummy_golden.npz",
-              "unpack_golden.npz"):
+              "large_golden.npz", "unpack_golden.npz"):
         print(f, (OUT / f).stat().st_size, "bytes")
+
+
+def make_large_golden(ref):
+    """The 8192 ... 32768-sample cases (BASELINE config 2's 32 000-sample scan among them) through
+    the genuine SDK ascendScanData and the genuine publish_scan: SHA-256 digests of the outputs
+    (canonical forms of tests/canon.py wherever the reference's order is introsort's).  The
+    inputs are regenerated from their seeds; their digest is stored to catch generator drift."""
+    g = {}
+    for name in LARGE_GOLDEN_CASES:
+        nodes = CASES[name]
+        g[f"{name}__in_sha"] = canon.digest(nodes)
+        out, res = ref.ascend(nodes)
+        g[f"{name}__asc_res"] = np.uint32(res)
+        g[f"{name}__asc_sha"] = canon.digest(canon.canon_ascend(out))
+        uniq = canon.valid_angles_unique(nodes)
+        g[f"{name}__unique"] = np.uint8(uniq)
+        for kind in (0, 1, 2):
+            for inv in (0, 1):
+                for sp in (0, 1):
+                    r, i, m = ref.publish_scan(nodes, driver_kind=kind, inverted=inv,
+                                               scan_processing=sp, range_max=40.0,
+                                               scan_duration=0.125)
+                    tag = f"{name}__k{kind}_i{inv}_s{sp}"
+                    g[tag + "__meta"] = np.frombuffer(bytes(m), np.uint8).copy()
+                    if sp:
+                        g[tag + "__ranges_sha"] = canon.digest(r)
+                        if not canon.has_intensity_tie(nodes, int(kind == 2)):
+                            g[tag + "__intens_sha"] = canon.digest(i)
+                    else:
+                        cr, ci = canon.canon_mode_b(nodes, r, i, inv)
+                        g[tag + "__ranges_sha"] = canon.digest(cr)
+                        g[tag + "__intens_sha"] = canon.digest(ci)
+    np.savez_compressed(OUT / "large_golden.npz", **g)
 
 
 UNPACK_CASES = [  # (answer type, frames, seed, corrupt, payload, frames_per_rev, sample_us, chunk)

@@ -13,7 +13,8 @@ import numpy as np
 import pytest
 
 from tests import oracle_lib
-from tests.cases import CASES, GOLDEN_CASES
+from tests import canon
+from tests.cases import CASES, GOLDEN_CASES, LARGE_GOLDEN_CASES
 
 GOLD = Path(__file__).resolve().parent / "golden"
 
@@ -72,6 +73,36 @@ def test_dummy_generator_golden(oracle):
     g = np.load(GOLD / "dummy_golden.npz")
     for k in range(3):
         assert oracle.gen_dummy(k).tobytes() == g[f"scan{k}"].tobytes()
+
+
+def test_dummy_publish_golden(oracle):
+    """Config 1 end to end: the genuine node's LaserScan for the genuine Dummy scans."""
+    g = np.load(GOLD / "dummy_golden.npz")
+    for k in range(3):
+        nodes = g[f"scan{k}"]
+        for inv in (0, 1):
+            for sp in (0, 1):
+                p = oracle_lib.params(inverted=inv, scan_processing=sp, range_max=40.0)
+                r, i, m = oracle.publish_scan(nodes, p, 0.1)
+                tag = f"scan{k}__i{inv}_s{sp}"
+                assert bytes(m) == g[tag + "__meta"].tobytes(), tag
+                assert r.tobytes() == g[tag + "__ranges"].tobytes(), tag
+                assert i.tobytes() == g[tag + "__intens"].tobytes(), tag
+
+
+@pytest.mark.parametrize("name", LARGE_GOLDEN_CASES)
+def test_large_golden(oracle, name):
+    """8192 ... 32768-sample scans (config 2's 32 000 among them) against digests of the genuine
+    SDK's / the genuine node's outputs."""
+    g = np.load(GOLD / "large_golden.npz")
+
+    def ls(nodes, kind, inv, sp):
+        p = oracle_lib.params(is_new_protocol=int(kind == 2), inverted=inv, scan_processing=sp,
+                              range_max=40.0)
+        r, i, m = oracle.publish_scan(nodes, p, 0.125)
+        return r, i, bytes(m)
+
+    assert canon.check_large_golden(g, name, CASES[name], oracle.ascend, ls) == 12
 
 
 def test_effective_max_range(oracle):
