@@ -129,6 +129,28 @@ int32_t rplgpu_cloud_msgs_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t o
                               uint8_t *d_msgs, uint32_t msg_stride, uint32_t *d_msg_len,
                               uint32_t *d_status);
 
+/* ---- LaserScan -> PointCloud2 projection (E7; row 3's `laser_geometry`-style cloud source) ---
+ * Input: what publish_scan produces (src/rplidar_node.cpp:618-662 Mode A, :663-680 Mode B) —
+ * the outputs of rplgpu_laserscan_batch_dev, still in HBM.  For scan b with count =
+ * d_beam_count[b] and angle_increment as the reference computes it (Mode A :635, Mode B
+ * :666-668; p->scan_processing selects), beam i is kept iff ranges[i] is finite (Mode A's empty
+ * bins are +inf, :640) and, with p->clip_enable, range_min <= ranges[i] <= range_max; then
+ *   theta = angle_min + float(i) * angle_increment            (float32; angle_min = 0, :623)
+ *   x = ranges[i] * (float)cos((double)theta);  y = ranges[i] * (float)sin((double)theta);  z = 0
+ *   intensity = intensities[i]
+ * in beam order, E3 layout (16-byte points), d_n_points[b] points at d_xyzi + b*out_stride.
+ * The serialised message of such a cloud is rplgpu_cloud_msgs_dev on the result. */
+int32_t rplgpu_laserscan_to_cloud_batch_dev(rplgpu_handle_t h, const float *d_ranges,
+                                            const float *d_intensities, uint32_t n_stride,
+                                            const uint32_t *d_beam_count, uint32_t B,
+                                            const rplgpu_params_t *p, float *d_xyzi,
+                                            uint32_t out_stride, uint32_t *d_n_points,
+                                            uint32_t *d_status);
+/* One scan, HOST buffers: ranges / intensities as a published LaserScan holds them (count
+ * beams, count <= max_samples_per_scan); xyzi: count * 4 floats. */
+int32_t rplgpu_laserscan_to_cloud(rplgpu_handle_t h, const float *ranges,
+                                  const float *intensities, uint32_t count,
+                                  const rplgpu_params_t *p, float *xyzi, uint32_t *n_points);
 
 /* ---- several sensors -> one fused cloud (first step) ------------------ */
 /* Rigid transform of the clouds of B scans, in place: d_pose holds B row-major 3x4 matrices

@@ -297,6 +297,35 @@ extern "C" size_t orc_scan_to_cloud(const orc_node_t *nodes, size_t n,
   return m;
 }
 
+/* E7 (spec, parity unpinned): a published LaserScan as a cloud, `laser_geometry`-style.
+ * Input = what publish_scan fills (src/rplidar_node.cpp:618-662 Mode A, :663-680 Mode B):
+ * count beams, angle_min = 0 (:623), angle_increment per :635 / :666-668. */
+extern "C" size_t orc_laserscan_to_cloud(const float *ranges, const float *intensities,
+                                         uint32_t count, const orc_params_t *p, float *xyzi) {
+  if (count == 0) return 0;
+  const float angle_min = 0.0f;
+  float angle_increment;
+  if (p->scan_processing) {
+    angle_increment = static_cast<float>((2.0 * M_PI) / static_cast<double>(count)); /* :635 */
+  } else {
+    double denom = static_cast<double>(count > 1 ? count - 1 : 1);                   /* :666 */
+    angle_increment = static_cast<float>((2.0 * M_PI) / denom);
+  }
+  size_t m = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    const float r = ranges[i];
+    if (!std::isfinite(r)) continue; /* +inf = bin never hit (:640) */
+    if (p->clip_enable && !(r >= p->range_min && r <= p->range_max)) continue;
+    const float theta = angle_min + static_cast<float>(i) * angle_increment;
+    xyzi[4 * m + 0] = r * (float)std::cos((double)theta);
+    xyzi[4 * m + 1] = r * (float)std::sin((double)theta);
+    xyzi[4 * m + 2] = 0.0f;
+    xyzi[4 * m + 3] = intensities[i];
+    ++m;
+  }
+  return m;
+}
+
 extern "C" size_t orc_voxel_grid(const float *xyzi, size_t n, float leaf, float *out,
                                  int32_t *cells, uint32_t *counts) {
   struct Tag {

@@ -91,6 +91,13 @@ void orc_gen_dummy(uint32_t scan_index, orc_node_t *nodes /*[360]*/);
 size_t orc_scan_to_cloud(const orc_node_t *nodes, size_t n, const orc_params_t *p,
                          float *xyzi);
 
+/* ---- E7 ("laser_geometry-style LaserScan -> cloud"; not in the
+ * reference, parity unpinned): beam i of a published LaserScan (angle_min = 0, angle_increment
+ * per src/rplidar_node.cpp:635 / :666-668) -> (r cos, r sin, 0, intensity); non-finite ranges
+ * dropped, clip_enable applies range_min/max.  xyzi must hold 4*count floats. */
+size_t orc_laserscan_to_cloud(const float *ranges, const float *intensities, uint32_t count,
+                              const orc_params_t *p, float *xyzi);
+
 /* ---- a-ext E5 alone on an xyzi array (O(n^2)). keep[] receives 0/1. */
 void orc_ror_mask(const float *xyzi, size_t n, float radius, uint32_t k,
                   uint8_t *keep);

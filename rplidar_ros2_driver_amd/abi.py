@@ -76,6 +76,8 @@ ABI_SYMBOLS = [
     "rplgpu_transform_clouds_dev",
     "rplgpu_fused_cloud_msg_dev",
     "rplgpu_cloud_deskew_batch_dev",
+    "rplgpu_laserscan_to_cloud_batch_dev",
+    "rplgpu_laserscan_to_cloud",
 ]
 
 
@@ -231,6 +233,10 @@ def load_library() -> C.CDLL:
     lib.rplgpu_fused_cloud_msg_dev.argtypes = [vp, vp, vp, u64, cs, Stamp, vp, u64, vp, vp]
     lib.rplgpu_cloud_deskew_batch_dev.argtypes = [
         vp, vp, u32, vp, u32, C.POINTER(Params), vp, vp, u32, vp, vp]
+    lib.rplgpu_laserscan_to_cloud_batch_dev.argtypes = [vp, vp, vp, u32, vp, u32, C.POINTER(Params),
+                                                        vp, u32, vp, vp]
+    lib.rplgpu_laserscan_to_cloud.argtypes = [vp, vp, vp, u32, C.POINTER(Params), vp,
+                                              C.POINTER(u32)]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default
@@ -429,6 +435,26 @@ class RplGpu:
         self._check(self._lib.rplgpu_cloud_deskew_batch_dev(
             self._h, d_nodes, n_stride, d_n_per_scan, B, C.byref(params), d_motion, d_xyzi,
             out_stride, d_n_points, d_status))
+
+    def laserscan_to_cloud_batch_dev(self, d_ranges: int, d_intens: int, n_stride: int,
+                                     d_beam_count: int, B: int, params: Params, d_xyzi: int,
+                                     out_stride: int, d_n_points: int, d_status: int = 0):
+        """E7: the LaserScans of a batch projected to clouds (laser_geometry-style)."""
+        self._check(self._lib.rplgpu_laserscan_to_cloud_batch_dev(
+            self._h, d_ranges, d_intens, n_stride, d_beam_count, B, C.byref(params), d_xyzi,
+            out_stride, d_n_points, d_status))
+
+    def laserscan_to_cloud(self, ranges: np.ndarray, intens: np.ndarray, params: Params):
+        """E7, one scan, host buffers: (count,) float32 ranges / intensities -> (m, 4) cloud."""
+        ranges = np.ascontiguousarray(ranges, np.float32)
+        intens = np.ascontiguousarray(intens, np.float32)
+        count = len(ranges)
+        xyzi = np.empty((max(count, 1), 4), np.float32)
+        npts = C.c_uint32(0)
+        self._check(self._lib.rplgpu_laserscan_to_cloud(
+            self._h, ranges.ctypes.data, intens.ctypes.data, count, C.byref(params),
+            xyzi.ctypes.data, C.byref(npts)))
+        return xyzi[: npts.value]
 
     def fused_cloud_msg_dev(self, d_arena: int, d_total_points: int, arena_capacity: int,
                             frame_id: str, sec: int, nanosec: int, d_msg: int, msg_capacity: int,

@@ -14,9 +14,12 @@
 
 namespace rpl {
 
-constexpr int kBlock = 1024;
+#ifndef RPL_KBLOCK
+#define RPL_KBLOCK 1024
+#endif
+constexpr int kBlock = RPL_KBLOCK;  // (developer builds of single translation units may override it)
 constexpr int kWaves = kBlock / 64;
-constexpr int kIters = 32;                       // 32768 samples / 1024 threads
+constexpr int kIters = 32768 / kBlock;           // 32768 samples / 1024 threads = 32
 constexpr uint32_t kMaxN = 32768;                // == RPLGPU_MAX_SAMPLES_PER_SCAN
 constexpr int kChunks = kIters * kWaves;         // 512 chunks of 64 samples
 constexpr double kTwoPi = 6.283185307179586476925286766559;  // 2.0 * M_PI

@@ -50,6 +50,12 @@ hipError_t launch_validate_div(hipStream_t s, float d, float rd, uint32_t e_lo, 
 hipError_t launch_pack(hipStream_t s, const float *xyzi, uint32_t out_stride,
                        const uint32_t *n_points, uint32_t B, float *packed, uint64_t *offsets);
 
+// E7: the binned LaserScan as a cloud (rpl_project.hip)
+hipError_t launch_laserscan_to_cloud(hipStream_t s, const float *ranges, const float *intens,
+                                     uint32_t n_stride, const uint32_t *beam_count, uint32_t B,
+                                     const KParams &p, float *xyzi, uint32_t out_stride,
+                                     uint32_t *n_points, uint32_t *status);
+
 // decode stage (rpl_decode.hip)
 hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
                          const uint32_t *frame_off, const uint8_t *gap, const uint32_t *n_frames,

@@ -46,14 +46,21 @@
 
 namespace rpl {
 
-constexpr uint32_t kRecCap = 7168;                    // run records per scan (112 KiB)
+#ifndef RPL_RECCAP
+#define RPL_RECCAP 7168
+#endif
+#ifndef RPL_ROWCAP
+#define RPL_ROWCAP 2048
+#endif
+constexpr uint32_t kRecCap = RPL_RECCAP;              // run records per scan (112 KiB)
 constexpr uint32_t kRecPerThread = kRecCap / kBlock;  // 7
-constexpr uint32_t kRowCap = 2048;                    // rows the counting sort handles
+constexpr uint32_t kRowCap = RPL_ROWCAP;              // rows the counting sort handles
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
 constexpr float kKeyMagic = 8421376.0f;               // 2^23 + 32768
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
@@ -176,6 +183,10 @@ __device__ __forceinline__ bool voxel_pair_pass(VoxelLds &L, uint32_t tag, bool 
                                                 uint32_t xA, uint32_t yA, uint32_t cA, bool okB,
                                                 uint32_t keyB, uint32_t xB, uint32_t yB,
                                                 uint32_t cB) {
+#ifdef RPL_ABL_NOAPPEND
+  asm volatile("" ::"v"(keyA), "v"(xA), "v"(yA), "v"(cA), "v"(keyB), "v"(xB), "v"(yB), "v"(cB));
+  return true;
+#endif
   // lane l+1's first key; lane 63 sees a value no key can take (its run always ends)
   const uint32_t nextA = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)keyA, 0x130,
                                                                0xF, 0xF, false);  // wave_shl:1
@@ -195,15 +206,21 @@ __device__ __forceinline__ bool voxel_pair_pass(VoxelLds &L, uint32_t tag, bool 
   // reserve queue slots: one LDS atomic by lane 0, its round trip overlaps the scans below
   // (hand-placed so that the compiler's atomic optimiser does not wait for it right away)
   uint32_t base = 0u;
+#ifndef RPL_ABL_NOATOMIC
   if (lane_id() == 0) {
     asm volatile("ds_add_rtn_u32 %0, %1, %2"
                  : "=v"(base)
                  : "v"((uint32_t)(uintptr_t)&L.misc[0]), "v"(total)
                  : "memory");
   }
+#endif
   uint32_t Px = xA + xB, Py = yA + yB, Pc = cA + cB;
+#ifndef RPL_ABL_NOSCAN
   wave_incl_scan3_dpp(Px, Py, Pc);
+#endif
+#ifndef RPL_ABL_NOATOMIC
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(base)::"memory");
+#endif
   base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
   if (base + total > kRecCap) return false;  // wave-uniform: queue full -> bisect the band
   const uint32_t mb1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32),
@@ -250,7 +267,11 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
   auto flush_dbg = [&]() {
     if (p.dbg && threadIdx.x == 0) {
 #pragma unroll
+#if defined(RPL_ABL_WAITT) || defined(RPL_ABL_LAT)
+      for (int i = 3; i < 8; ++i) atomicAdd(&p.dbg[8 * b + i], tacc[i]);
+#else
       for (int i = 1; i < 8; ++i) atomicAdd(&p.dbg[8 * b + i], tacc[i]);
+#endif
     }
   };
   const int vbias = p.vox_bias;
@@ -483,6 +504,9 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
   __shared__ VoxelLds L;
 
   if (threadIdx.x < 256) L.rcp[threadIdx.x] = T.rcp[threadIdx.x];  // (first barrier below publishes it)
+#ifdef RPL_ABL_CLK
+  const unsigned long long clk_c0 = clock64(), clk_w0 = wall_clock64();
+#endif
   // persistent workgroups: one per CU (a workgroup needs the whole LDS of a CU, so launching
   // one per scan only adds 4096 dispatches); the first scan is blockIdx.x, the next ones come
   // from a shared counter, so a workgroup that drew cheap scans simply takes more of them
@@ -525,9 +549,27 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
   const __amdgpu_buffer_rsrc_t scan_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
   auto load_pair = [&](uint32_t i) -> uint4 {
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)(i * 16u), 0, 2);
+#ifdef RPL_ABL_NORAW
+    return make_uint4((i * 4u) & 0xFFFFu | ((i * 40000u) << 16), (i * 40000u) >> 16 | 0x00400000u,
+                      (i * 4u + 2u) & 0xFFFFu | ((i * 40000u + 7u) << 16), (i * 40000u) >> 16 | 0x00800000u);
+#else
+#ifdef RPL_ABL_GLOBAL
+    const uint32_t ii = min(i, (n >> 1) - 1u);
+    return reinterpret_cast<const uint4 *>(scan)[ii];
+#else
+#ifndef RPL_RAW_AUX
+#define RPL_RAW_AUX 2
+#endif
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)(i * 16u), 0, RPL_RAW_AUX);
     return make_uint4(t.x, t.y, t.z, t.w);
+#endif
+#endif
   };
+#ifdef RPL_ABL_NOGATHER
+  struct FakeCs { __device__ float2 operator[](uint32_t q) const { return make_float2(0.6f + (float)q * 1e-6f, 0.8f); } };
+  const FakeCs cs_fake;
+#define cs cs_fake
+#endif
 
   const uint32_t *ror_bits = keepmask ? keepmask + (size_t)b * mask_stride : nullptr;
   bool first_band = true;
@@ -555,36 +597,178 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
       constexpr bool BAND = decltype(band_tag)::value;
       constexpr bool HASQ = decltype(hasq_tag)::value;
       constexpr bool HASMASK = decltype(mask_tag)::value;
-      uint4 w1 = load_pair(threadIdx.x);
-      uint4 w2 = load_pair(kBlock + threadIdx.x);
-      float2 cA1 = cs[w1.x & 0xFFFFu], cB1 = cs[w1.z & 0xFFFFu];
-      uint32_t round = 0;
+#ifdef RPL_ASM_RING
+      // ---- streaming loop with hand-managed vector-memory counters -------------------------
+      // Four raw-pair buffers W[r & 3] and two table buffers C[r & 1], addressed by name in a
+      // four-round body, so nothing is ever copied.  Round r issues, in this order, the table
+      // gathers of round r + 1 (their angle words came with raw buffer r + 1), [the E5 mask word
+      // of round r + 1] and the raw pairs of round r + 3.  A wave's loads retire in order, so
+      //   vmcnt(NB)     at the top    : raw r + 1 has arrived  (gathers r, raw r + 2 still fly)
+      //   vmcnt(NB + 1) before the use: gathers r have arrived (raw r + 2, gathers r + 1, raw r + 3 fly)
+      // with NB = 3 loads per round (4 with the mask).  A raw load has two rounds, a gather one
+      // round to arrive.  The loads and waits are inline assembly because the compiler's own
+      // counter tracking drains vmcnt to 0 at the loop header of any such ring (seen in the ISA
+      // of the plain-HIP version), which costs more than the prefetch distance buys.  The waits
+      // carry the loaded registers as operands, so no use can be scheduled above them, and
+      // nothing but these statements touches the ring registers while a load is in flight
+      // (checked in the ISA: no copy, no spill of W / C inside the loop).
+      const uint32_t nrounds = (npairs + kBlock - 1u) / kBlock;
+      const i32x4 rs = {__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)scan),
+                        __builtin_amdgcn_readfirstlane((int)((uint32_t)((uintptr_t)scan >> 32) & 0xFFFFu)),
+                        __builtin_amdgcn_readfirstlane((int)(n * 8u)), 0x00020000};
+      const uint64_t cs_base = (uint64_t)(uintptr_t)cs;
+      uint64_t mk_base = 0;
+      if (HASMASK) {
+        const uintptr_t mp = (uintptr_t)ror_bits;
+        mk_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mp >> 32)) << 32) |
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mp);
+      }
+      auto ld_raw = [&](u32x4 &w, uint32_t round_idx) {
+        const uint32_t off = (round_idx * kBlock + threadIdx.x) * 16u;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(w) : "v"(off), "s"(rs) : "memory");
+      };
+      auto ld_cs = [&](f2 &c, uint32_t word) {
+        const uint32_t off = (word & 0xFFFFu) << 3;
+        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(c) : "v"(off), "s"(cs_base) : "memory");
+      };
+      auto ld_mask = [&](uint32_t &m, uint32_t round_idx) {
+        const uint32_t pi = round_idx * kBlock + threadIdx.x;  // pair index -> bits 2*pi, 2*pi + 1
+        const uint32_t off = min(pi >> 4, mask_stride - 1u) << 2;  // (past the scan: dist 0 anyway)
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(m) : "v"(off), "s"(mk_base) : "memory");
+      };
+      constexpr int NB = HASMASK ? 4 : 3;
       bool fits = true;  // wave-uniform: this wave has not seen the queue overflow
-      for (uint32_t base = 0; base < npairs && fits; base += kBlock, ++round) {
-        const uint4 w0 = w1;
-        const float2 cA = cA1, cB = cB1;
-        w1 = w2;
-        cA1 = cs[w1.x & 0xFFFFu];
-        cB1 = cs[w1.z & 0xFFFFu];
-        w2 = load_pair(base + 2u * kBlock + threadIdx.x);
-        uint4 w = w0;
-        if (HASMASK) {  // E5 mask (one bit per sample): a dropped sample gets dist 0
-          const uint32_t pi = base + threadIdx.x;  // pair index -> bits 2*pi, 2*pi + 1
-          const uint32_t word = pi >> 4;
-          const uint32_t bits = (word < mask_stride) ? ror_bits[word] : 0u;
-          const uint32_t two = (bits >> ((pi & 15u) * 2u)) & 3u;
+      auto round = [&](u32x4 &Wc, u32x4 &Wn, u32x4 &Wl, f2 &cA, f2 &cB, f2 &cAn, f2 &cBn,
+                       uint32_t &mc, uint32_t &mn, uint32_t r) {
+        if (NB == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(Wn)::"memory");
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(Wn)::"memory");
+        ld_cs(cAn, Wn.x);
+        ld_cs(cBn, Wn.z);
+        if (HASMASK) ld_mask(mn, r + 1u);
+        ld_raw(Wl, r + 3u);
+        if (NB == 3) asm volatile("s_waitcnt vmcnt(4)" : "+v"(cA), "+v"(cB), "+v"(Wc)::"memory");
+        else asm volatile("s_waitcnt vmcnt(5)" : "+v"(cA), "+v"(cB), "+v"(mc), "+v"(Wc)::"memory");
+        uint4 w = make_uint4(Wc.x, Wc.y, Wc.z, Wc.w);
+        if (HASMASK) {  // a sample the E5 mask drops gets dist 0
+          const uint32_t pi = r * kBlock + threadIdx.x;
+          const uint32_t two = ((pi >> 4) < mask_stride) ? (mc >> ((pi & 15u) * 2u)) & 3u : 0u;
           if (!(two & 1u)) { w.x &= 0x0000FFFFu; w.y &= 0xFFFF0000u; }
           if (!(two & 2u)) { w.z &= 0x0000FFFFu; w.w &= 0xFFFF0000u; }
         }
         uint32_t keyA, xA, yA, ciA, keyB, xB, yB, ciB;
         const bool okA = voxel_sample<FAST_DIV, BAND, SAFE, HASQ>(
-            w.x, w.y, cA, p, q_min16, ibfe_off, ibfe_w, klo, khi, keyA, xA, yA, ciA, flags);
+            w.x, w.y, make_float2(cA.x, cA.y), p, q_min16, ibfe_off, ibfe_w, klo, khi, keyA, xA, yA, ciA, flags);
         const bool okB = voxel_sample<FAST_DIV, BAND, SAFE, HASQ>(
-            w.z, w.w, cB, p, q_min16, ibfe_off, ibfe_w, klo, khi, keyB, xB, yB, ciB, flags);
+            w.z, w.w, make_float2(cB.x, cB.y), p, q_min16, ibfe_off, ibfe_w, klo, khi, keyB, xB, yB, ciB, flags);
         // tag: (round, wave) — two neighbouring queue reservations never share it
-        const uint32_t tag = (((round & 15u) << 4) | wave_id()) << 24;
-        fits = voxel_pair_pass(L, tag, okA, keyA, xA, yA, ciA, okB, keyB, xB, yB, ciB);
+        const uint32_t tag = (((r & 15u) << 4) | wave_id()) << 24;
+        if (fits) fits = voxel_pair_pass(L, tag, okA, keyA, xA, yA, ciA, okB, keyB, xB, yB, ciB);
+      };
+      u32x4 W0, W1, W2, W3;
+      f2 cA0, cB0, cA1, cB1;
+      uint32_t m0 = 0xFFFFFFFFu, m1 = 0xFFFFFFFFu;
+      ld_raw(W0, 0u);
+      ld_raw(W1, 1u);
+      asm volatile("s_waitcnt vmcnt(1)" : "+v"(W0)::"memory");
+      ld_cs(cA0, W0.x);
+      ld_cs(cB0, W0.z);
+      if (HASMASK) ld_mask(m0, 0u);
+      ld_raw(W2, 2u);
+      for (uint32_t r = 0; r < nrounds && fits; r += 4u) {
+        round(W0, W1, W3, cA0, cB0, cA1, cB1, m0, m1, r);
+        if (r + 1u < nrounds) round(W1, W2, W0, cA1, cB1, cA0, cB0, m1, m0, r + 1u);
+        if (r + 2u < nrounds) round(W2, W3, W1, cA0, cB0, cA1, cB1, m0, m1, r + 2u);
+        if (r + 3u < nrounds) round(W3, W0, W2, cA1, cB1, cA0, cB0, m1, m0, r + 3u);
       }
+      // loads requested past the last round are still in flight: their registers must not be
+      // reused before they have landed
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(W0), "+v"(W1), "+v"(W2), "+v"(W3), "+v"(cA0), "+v"(cB0),
+                   "+v"(cA1), "+v"(cB1), "+v"(m0), "+v"(m1)::"memory");
+#else
+#ifndef RPL_PASSES
+#define RPL_PASSES 1
+#endif
+      // One loop trip = RPL_PASSES wave-passes (rounds).  All loads of the NEXT trip are issued at
+      // the top of a trip — the table entries of trip t + 1 (their angle words arrived with the
+      // raw pairs requested a trip earlier) and the raw pairs of trip t + 2 — so a load has a
+      // whole trip of compute to arrive.  With one pass per trip that is ~900 cycles against a
+      // measured ~1000 (raw) ... 1500 (raw behind the two gathers: a wave's loads return in
+      // order) cycles of latency, and since the 16 waves of the workgroup run in lockstep nobody
+      // computes while they all wait: 38 % of phase S was spent in that wait
+      // (profiles/r02/voxel_wait_cycles.txt).  Two passes per trip hide it.
+      constexpr int NP = RPL_PASSES;
+#ifdef RPL_STAGGER_MASK
+      // the 16 waves leave the barrier together and would issue their loads in one burst and
+      // wait for them together; start them a fraction of a round apart instead
+      for (uint32_t z = 0; z < (wave_id() & RPL_STAGGER_MASK); ++z) __builtin_amdgcn_s_sleep(RPL_STAGGER_SLEEP);
+#endif
+      uint4 w1[NP], w2[NP];
+      float2 cA1[NP], cB1[NP];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) w1[j] = load_pair((uint32_t)j * kBlock + threadIdx.x);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) w2[j] = load_pair((uint32_t)(NP + j) * kBlock + threadIdx.x);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        cA1[j] = cs[w1[j].x & 0xFFFFu];
+        cB1[j] = cs[w1[j].z & 0xFFFFu];
+      }
+      uint32_t round = 0;
+#if defined(RPL_ABL_WAITT) || defined(RPL_ABL_LAT)
+      unsigned long long wt_latch = 0;
+#endif
+      bool fits = true;  // wave-uniform: this wave has not seen the queue overflow
+      for (uint32_t base = 0; base < npairs && fits; base += NP * kBlock) {
+        uint4 w0[NP];
+        float2 cA[NP], cB[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          w0[j] = w1[j];
+          cA[j] = cA1[j];
+          cB[j] = cB1[j];
+          w1[j] = w2[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          cA1[j] = cs[w1[j].x & 0xFFFFu];
+          cB1[j] = cs[w1[j].z & 0xFFFFu];
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+          w2[j] = load_pair(base + (uint32_t)(2 * NP + j) * kBlock + threadIdx.x);
+#pragma unroll
+        for (int j = 0; j < NP; ++j, ++round) {
+          uint4 w = w0[j];
+          if (HASMASK) {  // E5 mask (one bit per sample): a dropped sample gets dist 0
+            const uint32_t pi = base + (uint32_t)j * kBlock + threadIdx.x;  // pair -> bits 2*pi, 2*pi+1
+            const uint32_t word = pi >> 4;
+            const uint32_t bits = (word < mask_stride) ? ror_bits[word] : 0u;
+            const uint32_t two = (bits >> ((pi & 15u) * 2u)) & 3u;
+            if (!(two & 1u)) { w.x &= 0x0000FFFFu; w.y &= 0xFFFF0000u; }
+            if (!(two & 2u)) { w.z &= 0x0000FFFFu; w.w &= 0xFFFF0000u; }
+          }
+          uint32_t keyA, xA, yA, ciA, keyB, xB, yB, ciB;
+          const bool okA = voxel_sample<FAST_DIV, BAND, SAFE, HASQ>(
+              w.x, w.y, cA[j], p, q_min16, ibfe_off, ibfe_w, klo, khi, keyA, xA, yA, ciA, flags);
+          const bool okB = voxel_sample<FAST_DIV, BAND, SAFE, HASQ>(
+              w.z, w.w, cB[j], p, q_min16, ibfe_off, ibfe_w, klo, khi, keyB, xB, yB, ciB, flags);
+          // tag: (round, wave) — two neighbouring queue reservations never share it
+          const uint32_t tag = (((round & 15u) << 4) | wave_id()) << 24;
+          if (fits) fits = voxel_pair_pass(L, tag, okA, keyA, xA, yA, ciA, okB, keyB, xB, yB, ciB);
+        }
+#ifdef RPL_ABL_WAITT
+        {
+          const unsigned long long t0 = clock64();
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          wt_latch += clock64() - t0;
+        }
+#endif
+      }
+#if defined(RPL_ABL_WAITT) || defined(RPL_ABL_LAT)
+      if (p.dbg && threadIdx.x == 0) atomicAdd(&p.dbg[8 * b + 1], wt_latch);
+      if (p.dbg && threadIdx.x == 64 * 7) atomicAdd(&p.dbg[8 * b + 2], wt_latch);
+#endif
+#endif  // RPL_ASM_RING
       if (!fits && lane_id() == 0) L.misc[2] = 1u;  // band does not fit
     };
     {
@@ -688,6 +872,16 @@ __global__ __launch_bounds__(kBlock) void k_cloud_voxel(
   b = L.tmp[31];
   __syncthreads();
   }
+#ifdef RPL_ABL_CLK
+  if (p.dbg && threadIdx.x == 0) {  // developer aid: core clocks vs 100 MHz wall clock of this workgroup
+    p.dbg[8 * blockIdx.x + 5] = clock64() - clk_c0;
+    p.dbg[8 * blockIdx.x + 6] = wall_clock64() - clk_w0;
+    p.dbg[8 * blockIdx.x + 7] = clk_w0;
+    unsigned int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    p.dbg[8 * blockIdx.x + 4] = ((unsigned long long)xcc << 32) | __smid();
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------
@@ -758,3 +952,6 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
 }
 
 }  // namespace rpl
+#ifdef RPL_ABL_NOGATHER
+#undef cs
+#endif

@@ -1163,6 +1163,60 @@ int32_t rplgpu_fused_cloud_msg_dev(rplgpu_handle_t h, const float *d_arena,
   return RPLGPU_OK;
 }
 
+int32_t rplgpu_laserscan_to_cloud_batch_dev(rplgpu_handle_t h, const float *d_ranges,
+                                            const float *d_intensities, uint32_t n_stride,
+                                            const uint32_t *d_beam_count, uint32_t B,
+                                            const rplgpu_params_t *p, float *d_xyzi,
+                                            uint32_t out_stride, uint32_t *d_n_points,
+                                            uint32_t *d_status) {
+  if (!h || !p) return RPLGPU_ERR_INVALID_ARG;
+  if (B == 0) return RPLGPU_OK;
+  if (!d_ranges || !d_intensities || !d_beam_count || !d_xyzi || !d_n_points || n_stride == 0 ||
+      out_stride == 0)
+    return RPLGPU_ERR_INVALID_ARG;
+  if (B > h->max_b) return RPLGPU_ERR_CAPACITY;
+  if (!device_readable(h, d_ranges, "d_ranges") || !device_readable(h, d_intensities, "d_intensities") ||
+      !device_readable(h, d_beam_count, "d_beam_count") || !device_readable(h, d_xyzi, "d_xyzi"))
+    return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_laserscan_to_cloud(h->stream, d_ranges, d_intensities, n_stride,
+                                            d_beam_count, B, to_kparams(*p), d_xyzi, out_stride,
+                                            d_n_points, d_status));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_laserscan_to_cloud(rplgpu_handle_t h, const float *ranges,
+                                  const float *intensities, uint32_t count,
+                                  const rplgpu_params_t *p, float *xyzi, uint32_t *n_points) {
+  if (!h || !p || !n_points || (count && (!ranges || !intensities || !xyzi)))
+    return RPLGPU_ERR_INVALID_ARG;
+  if (count > h->max_n) return RPLGPU_ERR_CAPACITY;
+  *n_points = 0;
+  if (count == 0) return RPLGPU_OK;
+  RPL_HIP(h, hipSetDevice(h->device));
+  // staging: ranges | intensities | count word go in with one copy (d_nodes holds 8 B per sample)
+  const size_t n = count;
+  std::memcpy(h->h_pin, ranges, n * 4);
+  std::memcpy(h->h_pin + n * 4, intensities, n * 4);
+  const uint32_t words[2] = {count, 0u};
+  std::memcpy(h->h_pin + n * 8, words, 8);
+  RPL_HIP(h, hipMemcpyAsync(h->d_nodes, h->h_pin, n * 8 + 8, hipMemcpyHostToDevice, h->stream));
+  const float *d_r = reinterpret_cast<const float *>(h->d_nodes);
+  const uint32_t *d_cnt = reinterpret_cast<const uint32_t *>(h->d_nodes + n * 8);
+  uint32_t *d_np = reinterpret_cast<uint32_t *>(h->d_out + n * 16);  // travels back with the points
+  RPL_HIP(h, rpl::launch_laserscan_to_cloud(h->stream, d_r, d_r + n, count, d_cnt, 1,
+                                            to_kparams(*p), reinterpret_cast<float *>(h->d_out),
+                                            count, d_np, nullptr));
+  unsigned char *h_out = stage_out(h);
+  RPL_HIP(h, hipMemcpyAsync(h_out, h->d_out, n * 16 + 4, hipMemcpyDeviceToHost, h->stream));
+  RPL_HIP(h, hipStreamSynchronize(h->stream));
+  uint32_t np;
+  std::memcpy(&np, h_out + n * 16, 4);
+  *n_points = np;
+  std::memcpy(xyzi, h_out, (size_t)np * 16);
+  return RPLGPU_OK;
+}
+
 int32_t rplgpu_cloud_deskew_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
                                       uint32_t n_stride, const uint32_t *d_n_per_scan, uint32_t B,
                                       const rplgpu_params_t *p, const float *d_motion,

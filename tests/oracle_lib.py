@@ -67,6 +67,8 @@ class Oracle:
         lib.orc_voxel_grid.restype = sz
         lib.orc_cloud_pipeline.argtypes = [vp, sz, C.POINTER(OParams), vp, vp, vp]
         lib.orc_cloud_pipeline.restype = sz
+        lib.orc_laserscan_to_cloud.argtypes = [vp, vp, C.c_uint32, C.POINTER(OParams), vp]
+        lib.orc_laserscan_to_cloud.restype = sz
         for name in ("orc_batch_ascend",):
             getattr(lib, name).argtypes = [vp, sz, vp, sz, C.c_int]
             getattr(lib, name).restype = C.c_uint64
@@ -170,6 +172,14 @@ class Oracle:
         nodes = np.ascontiguousarray(nodes)
         out = np.zeros((max(len(nodes), 1), 4), np.float32)
         m = self.lib.orc_scan_to_cloud(nodes.ctypes.data, len(nodes), C.byref(p), out.ctypes.data)
+        return out[:m]
+
+    def laserscan_to_cloud(self, ranges: np.ndarray, intens: np.ndarray, p: OParams) -> np.ndarray:
+        ranges = np.ascontiguousarray(ranges, np.float32)
+        intens = np.ascontiguousarray(intens, np.float32)
+        out = np.zeros((max(len(ranges), 1), 4), np.float32)
+        m = self.lib.orc_laserscan_to_cloud(ranges.ctypes.data, intens.ctypes.data, len(ranges),
+                                            C.byref(p), out.ctypes.data)
         return out[:m]
 
     def voxel_grid(self, xyzi: np.ndarray, leaf: float):

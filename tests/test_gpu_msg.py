@@ -375,3 +375,66 @@ def test_deskewed_cloud_matches_oracle(gpu, oracle):
         gpu.cloud_deskew_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B,
                                    Params.defaults(voxel_enable=1), d_motion.data_ptr(),
                                    d_xyzi.data_ptr(), n, d_np.data_ptr(), d_st.data_ptr())
+
+
+# ------------------------------------------------ E7: LaserScan -> PointCloud2 projection (f3)
+def test_laserscan_to_cloud_matches_oracle(gpu, oracle):
+    """The `laser_geometry`-style cloud source of SURVEY.md §8(f) row 3: the binned LaserScan
+    (what publish_scan fills, /root/reference src/rplidar_node.cpp:618-662) projected to E3
+    points.  Keep mask / order exact; XYZ <= 1e-6 m (in fact bit-exact: fp64 sincos rounded once);
+    intensity bit-exact."""
+    import torch
+    from tests.cases import CASES
+    dev = torch.device("cuda:0")
+    for name in ("c1_like_360", "ring_8192_rot_jit", "c2_32000", "kat2", "single_valid",
+                 "all_invalid", "full_32768_unsorted"):
+        nodes = CASES[name]
+        for sp, inv, clip in ((1, 0, 0), (1, 1, 1), (0, 0, 0), (0, 1, 1)):
+            p = Params.defaults(scan_processing=sp, inverted=inv, range_max=40.0)
+            r, i, m = gpu.scan_to_laserscan(nodes, p, 0.1)
+            pc = Params.defaults(scan_processing=sp, clip_enable=clip, range_min=0.3, range_max=9.0)
+            want = oracle.laserscan_to_cloud(r, i, oracle_lib.copy_params(pc))
+            got = gpu.laserscan_to_cloud(r, i, pc)
+            assert got.shape == want.shape, (name, sp, inv, clip)
+            if len(want):
+                assert np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2])) <= 1e-6
+                assert got[:, 2:].tobytes() == want[:, 2:].tobytes()
+    # batch, device resident: LaserScans straight from rplgpu_laserscan_batch_dev, then the clouds
+    # as serialised PointCloud2 messages (rplgpu_cloud_msgs_dev) — the whole row-3 chain in HBM
+    B, n = 12, 6000
+    batch = synth.make_batch(77, B, n, jitter=2)
+    lens = np.array([n - 401 * b for b in range(B)], np.int32)
+    lens[5] = 0
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+    d_len = torch.from_numpy(lens).to(dev)
+    d_r = torch.empty(B, n, dtype=torch.float32, device=dev)
+    d_i = torch.empty(B, n, dtype=torch.float32, device=dev)
+    d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    p = Params.defaults(range_max=40.0)
+    gpu.laserscan_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_r.data_ptr(),
+                            d_i.data_ptr(), d_cnt.data_ptr())
+    d_xyzi = torch.zeros(B, n, 4, dtype=torch.float32, device=dev)
+    d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    gpu.laserscan_to_cloud_batch_dev(d_r.data_ptr(), d_i.data_ptr(), n, d_cnt.data_ptr(), B, p,
+                                     d_xyzi.data_ptr(), n, d_np.data_ptr(), d_st.data_ptr())
+    fid = "laser_frame"
+    mstride = abi.msg_cloud_layout(len(fid), n).total_len
+    mstride = (mstride + 3) & ~3
+    d_msgs = torch.zeros(B, mstride, dtype=torch.uint8, device=dev)
+    d_ml = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_stamps = torch.tensor([[100 + b, 7 * b] for b in range(B)], dtype=torch.int32, device=dev)
+    gpu.cloud_msgs_dev(d_xyzi.data_ptr(), n, 0, d_np.data_ptr(), B, fid, d_stamps.data_ptr(),
+                       d_msgs.data_ptr(), mstride, d_ml.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    r, i, cnt = d_r.cpu().numpy(), d_i.cpu().numpy(), d_cnt.cpu().numpy()
+    xyzi, npts = d_xyzi.cpu().numpy(), d_np.cpu().numpy()
+    msgs, ml = d_msgs.cpu().numpy(), d_ml.cpu().numpy()
+    for b in range(B):
+        want = oracle.laserscan_to_cloud(r[b, : cnt[b]], i[b, : cnt[b]], oracle_lib.copy_params(p))
+        assert npts[b] == len(want)
+        got = xyzi[b, : npts[b]]
+        if len(want):
+            assert np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2])) <= 1e-6
+            assert got[:, 2:].tobytes() == want[:, 2:].tobytes()
+        assert msgs[b, : ml[b]].tobytes() == cdr.cloud_msg(fid, 100 + b, 7 * b, got)

@@ -563,11 +563,13 @@ def test_full_size_properties(gpu):
         starts = np.r_[0, np.flatnonzero(np.diff(ks)) + 1]
         counts = np.diff(np.r_[starts, len(ks)])
         assert npv[b] == len(starts) and counts.sum() == npc[b]
-        mean = lambda col: np.add.reduceat(pb[order, col].astype(np.float64), starts) / counts
+        # the spec's centroid: fp64 sum in sample order / count, rounded to float32
+        mean = lambda col: (np.add.reduceat(pb[order, col].astype(np.float64), starts)
+                            / counts).astype(np.float32)
         vb = vox[b, : npv[b]]
-        assert np.max(np.abs(vb[:, 0] - mean(0))) <= XYZ_TOL
-        assert np.max(np.abs(vb[:, 1] - mean(1))) <= XYZ_TOL
-        assert np.array_equal(vb[:, 3], mean(3).astype(np.float32))
+        assert np.max(np.abs(vb[:, 0].astype(np.float64) - mean(0))) <= XYZ_TOL
+        assert np.max(np.abs(vb[:, 1].astype(np.float64) - mean(1))) <= XYZ_TOL
+        assert np.array_equal(vb[:, 3], mean(3))
 
 
 # ------------------------------------------------------------ directly against the reference

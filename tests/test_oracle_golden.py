@@ -214,3 +214,44 @@ def test_ror_mask_small(oracle):
     pts[:, 0] = [0.0, 0.05, 0.09, 1.0, 1.05]
     keep = oracle.ror_mask(pts, 0.10, 2)
     assert keep.tolist() == [True, True, True, False, False]
+
+
+def numpy_laserscan_to_cloud(ranges, intens, scan_processing, clip=None):
+    """Numpy restatement of E7 (second, independent writer of the spec)."""
+    count = len(ranges)
+    den = np.float64(count) if scan_processing else np.float64(max(count - 1, 1))
+    inc = np.float32((2.0 * np.pi) / den)
+    keep = np.isfinite(ranges)
+    if clip is not None:
+        keep &= (ranges >= np.float32(clip[0])) & (ranges <= np.float32(clip[1]))
+    theta = (np.arange(count, dtype=np.float32) * inc).astype(np.float32)
+    c = np.cos(theta.astype(np.float64)).astype(np.float32)
+    s_ = np.sin(theta.astype(np.float64)).astype(np.float32)
+    out = np.zeros((int(keep.sum()), 4), np.float32)
+    out[:, 0] = (ranges * c)[keep]
+    out[:, 1] = (ranges * s_)[keep]
+    out[:, 3] = intens[keep]
+    return out
+
+
+@pytest.mark.parametrize("name", ["c1_like_360", "ring_8192", "c2_32000", "kat2", "single_valid"])
+def test_laserscan_to_cloud_oracle_vs_numpy(oracle, name):
+    nodes = CASES[name]
+    for sp in (1, 0):
+        p = oracle_lib.params(scan_processing=sp, range_max=40.0)
+        r, i, m = oracle.publish_scan(nodes, p, 0.1)
+        got = oracle.laserscan_to_cloud(r, i, p)
+        want = numpy_laserscan_to_cloud(r, i, sp)
+        assert got.shape == want.shape
+        # libm vs numpy cos/sin of the same double: both correctly rounded in practice; allow 1 ulp
+        assert np.max(np.abs(got.astype(np.float64) - want), initial=0.0) <= 4e-6
+        assert np.mean(got.tobytes() == want.tobytes()) == 1 or np.mean(got == want) > 0.999
+        pc = oracle_lib.params(scan_processing=sp, range_max=8.0, range_min=0.5, clip_enable=1)
+        gotc = oracle.laserscan_to_cloud(r, i, pc)
+        assert gotc.shape == numpy_laserscan_to_cloud(r, i, sp, (0.5, 8.0)).shape
+    # the projection of a Mode A scan puts every point back on its ring: |p| == range
+    p = oracle_lib.params(scan_processing=1, range_max=40.0)
+    r, i, m = oracle.publish_scan(CASES["ring_8192"], p, 0.1)
+    pts = oracle.laserscan_to_cloud(r, i, p)
+    rr = r[np.isfinite(r)]
+    assert np.max(np.abs(np.hypot(pts[:, 0].astype(np.float64), pts[:, 1]) - rr)) < 1e-5

@@ -8,7 +8,9 @@ from rplidar_ros2_driver_amd import Params, RplGpu, synth, abi
 
 B, n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 32000
 NOISE = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
-batch = synth.make_batch(2026, B, n, noise_m=NOISE)
+import os
+R0MAX = float(os.environ.get('RPL_VOXDBG_R0MAX', '30'))
+batch = synth.make_batch(2026, B, n, noise_m=NOISE, r0_range=(1.0, R0MAX))
 dev = torch.device("cuda:0")
 d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
 d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
@@ -40,3 +42,16 @@ for i, nm in enumerate(names):
 print("  total mean %.0f" % dbg.sum(1).mean())
 npts = d_np.cpu().numpy()
 print("cells mean", npts.mean(), "status", int(d_st.max()))
+
+if os.environ.get('RPL_VOXDBG_CLK'):
+    g = int(os.environ.get('RPLGPU_VOXEL_GRID', '256'))
+    c, w = dbg[:g, 5].astype(float), dbg[:g, 6].astype(float)
+    print("core clock MHz per workgroup: mean %.0f min %.0f max %.0f (wall us mean %.1f)" % ((c / w * 100).mean(), (c / w * 100).min(), (c / w * 100).max(), w.mean() / 100))
+    st = dbg[:g, 7].astype(float); st -= st.min(); en = st + w
+    print("  start us: p50 %.1f p90 %.1f max %.1f | end us: p50 %.1f max %.1f | life us: p10 %.1f p50 %.1f p90 %.1f" % (
+        np.median(st) / 100, np.percentile(st, 90) / 100, st.max() / 100, np.median(en) / 100, en.max() / 100,
+        np.percentile(w, 10) / 100, np.median(w) / 100, np.percentile(w, 90) / 100))
+    ids = dbg[:g, 4]
+    import collections
+    cnt = collections.Counter(ids.tolist())
+    print("  distinct (xcc, smid) slots: %d, workgroups per slot max %d" % (len(cnt), max(cnt.values())))
