@@ -7,12 +7,17 @@ input samples, 1 048 576 000 B of packed 8-byte nodes) -> E1 quality/range clip 
 -> 5 cm voxel grid (kernel ``k_cloud_voxel``), the clouds of all scans written to one
 contiguous arena (every scan reserves exactly its cells; no packing pass).
 With --gpus N > 1 (config 4) the SAME batch is sharded by scan index (strong scaling), each
-rank processes its block and the packed clouds are all-gathered with RCCL over xGMI inside
-the timed region.
+rank processes its block in chunks and the voxelised clouds are all-gathered with RCCL over
+xGMI through the library's own C entry points (rplgpu_comm_*), the gather of chunk k
+overlapping the compute of chunk k + 1 on a second stream.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-``roofline`` (dominant kernel vs the HBM roofline) and ``cpu_baseline`` (the CPU oracle
-timed on this box's host cores on a bounded sample of the same buffers).
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+``roofline`` (dominant kernel vs the HBM roofline), ``cpu_baseline`` (the CPU oracle timed on
+this box's host cores on a bounded sample of the same buffers), ``variants`` (the same
+4096 x 32 000 shape on the other data regimes of SURVEY.md §8(d): 1 cm range noise, uniformly
+random ranges, quality filter on), ``c5`` (8 sensors x 512 frames, E5 + E4, fused arena),
+``single_scan_us`` (the node's per-scan entry points at the scan sizes the reference produces)
+and ``decode`` (the step before the path, per answer type).
 """
 from __future__ import annotations
 
@@ -29,15 +34,17 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
+HBM_COPY_GBS = 6290.0   # achievable streaming rate (same guide; tools/ubench/cu_stream: 6.2-6.3 TB/s)
 TRAFFIC_JSON = ROOT / "profiles" / "traffic.json"  # PMC-derived HBM bytes per launch (tools/prof.sh)
 
 
-def measured_traffic(kernel: str, B: int, n: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+def static_traffic(kernel: str, B: int, n: int):
+    """HBM bytes per launch of `kernel` from the COMMITTED rocprofv3 PMC passes
     (profiles/traffic.json, written by tools/prof_summary.py from separate --pmc runs of this
-    very command, with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md), or None when
-    no profile of this workload shape is on record."""
+    very command, with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md).  Static:
+    counters cannot be read from inside this process; None when no profile of this workload
+    shape is on record."""
     try:
         rec = json.loads(TRAFFIC_JSON.read_text())
     except Exception:
@@ -45,7 +52,7 @@ def measured_traffic(kernel: str, B: int, n: int):
     ent = rec.get(kernel)
     if not ent or ent.get("scans") != B or ent.get("samples_per_scan") != n:
         return None, None
-    return int(ent["hbm_bytes_per_launch"]), ent.get("source")
+    return int(ent["hbm_bytes_per_launch"]), "static: " + str(ent.get("source"))
 
 
 def parse_args():
@@ -57,22 +64,27 @@ def parse_args():
     ap.add_argument("--samples", type=int, default=32000, help="samples per scan")
     ap.add_argument("--out-stride", type=int, default=8192, help="cloud slots per scan")
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="N > 1: pieces a rank's block is cut into (gather of piece k overlaps "
+                         "compute of piece k + 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target wall time of the CPU baseline sample (0 disables)")
     ap.add_argument("--no-laserscan", action="store_true",
                     help="skip the secondary ascend+LaserScan measurement")
-    ap.add_argument("--no-c5", action="store_true",
-                    help="skip the secondary config-5 measurement (it launches the headline kernel "
-                         "on a small noisy batch; profiles of the headline launch use this flag)")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the data-regime variants and the config-5 leg (they launch the "
+                         "headline kernel on other batches; profiles of the headline launch use this)")
+    ap.add_argument("--no-c5", action="store_true", help="alias of --no-variants (round-1 flag)")
     ap.add_argument("--no-decode", action="store_true",
                     help="skip the secondary decode-stage measurement (capsules -> nodes -> scans)")
+    ap.add_argument("--no-single", action="store_true", help="skip the per-scan latency table")
     return ap.parse_args()
 
 
 def cpu_baseline(batch_np, lens_np, params, target_s):
     """Time the CPU oracle (a port of the spec; the reference has no cloud path) on this
-    host, all cores, on a bounded prefix of the same scans.  Only this function touches
-    oracle/."""
+    host, all cores, on a bounded prefix of the same scans.  Only this function (and
+    `cpu_single_scan`) touch oracle/."""
     from tests import oracle_lib
 
     orc = oracle_lib.load_oracle()
@@ -104,7 +116,8 @@ def cpu_baseline(batch_np, lens_np, params, target_s):
         passes += 1
     t_one_scans = min(nscans, 32)
     t_one, _ = run(t_one_scans, 1)
-    # the reference's own per-scan loop (ascendScanData + publish_scan Mode A), same threads
+    # the reference's own per-scan loop (ascendScanData + publish_scan Mode A), same threads:
+    # the oracle's restatement (pinned bit for bit against the genuine code, tests/golden/)
     pl = oracle_lib.copy_params(params)
     pl.clip_enable = 0
     nodes = np.ascontiguousarray(batch_np[:nscans]).copy()
@@ -115,7 +128,7 @@ def cpu_baseline(batch_np, lens_np, params, target_s):
     t0 = time.perf_counter()
     orc.lib.orc_batch_laserscan(nodes.ctypes.data, n, lens.ctypes.data, nscans, C.byref(pl), cores)
     t_ls = time.perf_counter() - t0
-    return {
+    out = {
         "value": round(nscans * n / t_all / 1e6, 3),
         "unit": "Mpoints/s",
         "cores": cores,
@@ -125,80 +138,188 @@ def cpu_baseline(batch_np, lens_np, params, target_s):
                   f"{cores} threads over scans (g++ -O2 oracle, clip + polar->XYZ + voxel)",
         "single_thread_value": round(t_one_scans * n / t_one / 1e6, 3),
         "cells_out": tot,
-        "reference_path_ascend_mpts": round(nscans * n / t_asc / 1e6, 1),
-        "reference_path_laserscan_mpts": round(nscans * n / t_ls / 1e6, 1),
+        "reference_path": {
+            "kind": "port (restatement of ascendScanData / publish_scan, pinned bit for bit against "
+                    "the genuine SDK and node: tests/golden/, tests/test_oracle_golden.py)",
+            "ascend_mpts": round(nscans * n / t_asc / 1e6, 1),
+            "laserscan_mpts": round(nscans * n / t_ls / 1e6, 1),
+            "threads": cores,
+        },
     }
+    # the GENUINE reference code (oracle/_ref/, built from /root/reference where it exists and
+    # shipped as binaries): one thread, a few scans
+    ref = oracle_lib.load_ref()
+    if ref is not None:
+        k = min(nscans, 16)
+        t0 = time.perf_counter()
+        for s in range(k):
+            ref.ascend(batch_np[s])
+        t_ra = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for s in range(k):
+            ref.publish_scan(batch_np[s], driver_kind=1, inverted=0, scan_processing=1,
+                             range_max=40.0, scan_duration=0.1)
+        t_rp = time.perf_counter() - t0
+        out["reference_path_genuine"] = {
+            "kind": "reference (oracle/_ref: the SDK's ascendScanData and the node's publish_scan "
+                    "compiled from /root/reference), 1 thread",
+            "ascend_mpts": round(k * n / t_ra / 1e6, 1),
+            "laserscan_mpts": round(k * n / t_rp / 1e6, 1),
+            "scans": k,
+        }
+    return out
+
+
+def timed(fn, stream, reps, sync):
+    """Back-to-back launches between two events on the launch stream: ms per call."""
+    import torch
+    fn()
+    sync()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(reps):
+        fn()
+    b.record(stream)
+    sync()
+    return a.elapsed_time(b) / reps
 
 
 def decode_stage(gpu, dev, stream, cpu_seconds):
     """Secondary measurement (not `value`): the step before the path, SURVEY.md §8(f) rows 1-2.
-    4096 recorded DenseBoost capsule streams (801 frames = 32 000 samples each, resident in HBM)
-    -> k_decode -> k_segment, plus the CPU oracle restatement of the SDK unpacker on one core."""
+    4096 recorded streams per answer type (resident in HBM) -> k_decode (sync list + scans
+    written straight into the batch layout where the type allows), plus the CPU oracle
+    restatement of the SDK unpacker on one core for DenseBoost."""
     import torch
 
     from rplidar_ros2_driver_amd import capsules as cp
 
-    ans, nf, B = cp.ANS_DENSE_CAPSULED, 801, 4096
-    S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
-    uniq = 32  # distinct streams (host generation time); the batch repeats them
-    # two revolutions per stream so that scan assembly has one complete scan to cut out
-    base = np.stack([cp.make_stream(ans, nf, 10 + s, payload="ring", frames_per_rev=nf / 2.0 + 0.3)
-                     for s in range(uniq)])
-    buf = torch.from_numpy(base).to(dev).repeat(B // uniq, 1).contiguous()
-    d_nf = torch.full((B,), nf, dtype=torch.int32, device=dev)
-    node_stride = nf * npf
-    d_nodes = torch.empty(B, node_stride * 8, dtype=torch.uint8, device=dev)
-    d_seg = torch.empty_like(d_nodes)
-    d_nn = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_rst = torch.zeros(B, 8, dtype=torch.int32, device=dev)
-    d_nr = torch.zeros(B, dtype=torch.int32, device=dev)
-    scan_cap = 8
-    d_off = torch.zeros(B, scan_cap + 1, dtype=torch.int32, device=dev)
-    d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
+    B = 4096
+    out = {}
+    sync = lambda: torch.cuda.synchronize(dev)
+    for name, ans, nf in (("dense", cp.ANS_DENSE_CAPSULED, 801), ("express", cp.ANS_CAPSULED, 1001),
+                          ("ultra", cp.ANS_CAPSULED_ULTRA, 334),
+                          ("ultra_dense", cp.ANS_ULTRA_DENSE_CAPSULED, 501), ("hq", cp.ANS_HQ, 334),
+                          ("normal", cp.ANS_MEASUREMENT, 4000)):
+        S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
+        uniq = 16  # distinct streams (host generation time); the batch repeats them
+        # two revolutions per stream so that scan assembly has one complete scan to cut out
+        base = np.stack([cp.make_stream(ans, nf, 10 + s, payload="ring", frames_per_rev=nf / 2.0 + 0.3)
+                         for s in range(uniq)])
+        buf = torch.from_numpy(base).to(dev).repeat(B // uniq, 1).contiguous()
+        d_nf = torch.full((B,), nf, dtype=torch.int32, device=dev)
+        node_stride = nf * npf
+        d_nodes = torch.empty(B, node_stride * 8, dtype=torch.uint8, device=dev)
+        d_nn = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_rst = torch.zeros(B, 8, dtype=torch.int32, device=dev)
+        d_nr = torch.zeros(B, dtype=torch.int32, device=dev)
 
-    def dec():
-        gpu.decode_batch_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0,
-                             d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8,
-                             d_nr.data_ptr())
+        def dec():
+            gpu.decode_batch_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0,
+                                 d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8,
+                                 d_nr.data_ptr())
 
-    def seg():
-        gpu.segment_batch_dev(d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(),
-                              8, d_nr.data_ptr(), B, 32768, d_seg.data_ptr(), node_stride,
-                              d_off.data_ptr(), scan_cap, d_ns.data_ptr())
+        ms = timed(dec, stream, 5, sync)
+        nodes = int(d_nn.sum().item())
+        gbs = (B * nf * S + 8 * nodes) / ms / 1e6
+        out[name] = {"ms": round(ms, 4), "gnodes_s": round(nodes / ms / 1e6, 1), "gbs": round(gbs, 1),
+                     "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        if ans == cp.ANS_DENSE_CAPSULED:
+            d_seg = torch.empty_like(d_nodes)
+            scan_cap = 8
+            d_off = torch.zeros(B, scan_cap + 1, dtype=torch.int32, device=dev)
+            d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
 
-    res = {}
-    for name, fn in (("decode", dec), ("segment", seg)):
-        fn()
-        torch.cuda.synchronize(dev)
-        ts = []
-        for _ in range(5):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            fn()
-            b.record(stream)
-            torch.cuda.synchronize(dev)
-            ts.append(a.elapsed_time(b))
-        res[name] = min(ts)
-    nodes = int(d_nn.sum().item())
-    out = {
-        "decode_dense_ms": round(res["decode"], 4),
-        "decode_dense_mnodes": round(nodes / res["decode"] / 1e3, 1),
-        "decode_dense_gbs": round((B * nf * S + 8 * nodes) / res["decode"] / 1e6, 1),
-        "segment_ms": round(res["segment"], 4),
-        "segment_scans": int(d_ns.sum().item()),
-    }
-    if cpu_seconds > 0:  # the oracle restatement of the SDK unpacker, one core, one stream
-        from tests import oracle_lib
+            def seg():
+                gpu.segment_batch_dev(d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(),
+                                      8, d_nr.data_ptr(), B, 32768, d_seg.data_ptr(), node_stride,
+                                      d_off.data_ptr(), scan_cap, d_ns.data_ptr())
 
-        orc = oracle_lib.load_oracle()
-        orc.unpack(ans, base[0], 125)
-        t0 = time.perf_counter()
-        reps = 0
-        while time.perf_counter() - t0 < min(cpu_seconds, 2.0):
-            orc.unpack(ans, base[reps % uniq], 125)
-            reps += 1
-        out["decode_dense_cpu1_mnodes"] = round(reps * (nf - 1) * npf / (time.perf_counter() - t0) / 1e6, 1)
+            out["segment_ms"] = round(timed(seg, stream, 5, sync), 4)
+            out["segment_scans"] = int(d_ns.sum().item())
+            if cpu_seconds > 0:  # the oracle restatement of the SDK unpacker, one core, one stream
+                from tests import oracle_lib
+
+                orc = oracle_lib.load_oracle()
+                orc.unpack(ans, base[0], 125)
+                t0 = time.perf_counter()
+                reps = 0
+                while time.perf_counter() - t0 < min(cpu_seconds, 2.0):
+                    orc.unpack(ans, base[reps % uniq], 125)
+                    reps += 1
+                out["dense_cpu1_mnodes"] = round(reps * (nf - 1) * npf / (time.perf_counter() - t0) / 1e6, 1)
+            del d_seg
+        del buf, d_nodes
     return out
+
+
+def regime(gpu, dev, stream, name, batch_np, params, arena, cursor, start, npts, stat, reps):
+    """One data regime at the full batch shape: k_cloud_voxel (+ k_ror_mask when E5 is on) into the
+    arena; ms per launch, Gpts/s, roofline fractions.  Returns (dict, cells)."""
+    import torch
+
+    B, n = batch_np.shape
+    d_nodes = torch.from_numpy(batch_np.view(np.uint8).reshape(B, n * 8)).to(dev)
+    d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
+    cap = arena.shape[0]
+
+    def fn():
+        gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params, arena.data_ptr(),
+                            cap, cursor.data_ptr(), start.data_ptr(), npts.data_ptr(), stat.data_ptr())
+
+    ms = timed(fn, stream, reps, lambda: torch.cuda.synchronize(dev))
+    cells = int(cursor.item())
+    st = int(stat.max().item())
+    algo = 8 * B * n + 16 * cells
+    res = {"ms": round(ms, 4), "gpts_s": round(B * n / ms / 1e6, 1),
+           "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "frac_read": round(8 * B * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "cells": cells, "status_bits": st}
+    del d_nodes
+    return res
+
+
+def single_scan_table(gpu, params_voxel, seed, cpu_seconds):
+    """The drop-in seam, one scan at a time through the host-buffer entry points the node calls
+    (wall clock per call: copies, kernels, synchronisation), at the scan sizes the reference
+    produces (360 Standard / ~3 200 DenseBoost S2 / 8 192 = the SDK's buffer,
+    src/lidar_driver_wrapper.cpp:316-318 / 32 000 config 2), next to the CPU loop it replaces."""
+    from rplidar_ros2_driver_amd import Params, synth
+
+    table = {}
+    pl1 = Params.defaults(range_max=40.0)
+    pin = gpu.host_alloc(1 << 20)
+    for n in (360, 3200, 8192, 32000):
+        one = synth.make_scan(seed, 9000 + n, n)
+        row = {}
+        for name, fn in (
+            ("laserscan", lambda: gpu.scan_to_laserscan(one, pl1, 0.1)),
+            ("laserscan_msg_pinned", lambda: gpu.scan_to_laserscan_msg(one, pl1, 0.1, "laser_frame",
+                                                                       1, 2, out=pin)),
+            ("ascend", lambda: gpu.ascend(one.copy())),
+            ("voxel_cloud", lambda: gpu.scan_to_cloud(one, params_voxel)),
+        ):
+            for _ in range(20):
+                fn()
+            reps = 200
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            row[name] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+        if cpu_seconds > 0:  # the CPU loops the node runs today, same scan, one core
+            from tests import oracle_lib
+            orc = oracle_lib.load_oracle()
+            op = oracle_lib.copy_params(pl1)
+            for name, fn in (("cpu_publish_scan", lambda: orc.publish_scan(one, op, 0.1)),
+                             ("cpu_ascend", lambda: orc.ascend(one))):
+                t0 = time.perf_counter()
+                reps = 0
+                while time.perf_counter() - t0 < 0.25:
+                    fn()
+                    reps += 1
+                row[name] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+        table[str(n)] = row
+    gpu.host_free(pin)
+    return table
 
 
 def main():
@@ -207,7 +328,7 @@ def main():
     import torch.distributed as dist
 
     from rplidar_ros2_driver_amd import Params, RplGpu, synth
-    from rplidar_ros2_driver_amd.sharding import allgather_clouds, shard_range
+    from rplidar_ros2_driver_amd.sharding import CloudExchange, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -230,6 +351,7 @@ def main():
     lo, hi = shard_range(B_total, world, rank)
     B = hi - lo
     out_stride = args.out_stride
+    no_variants = args.no_variants or args.no_c5
 
     # ---- synthetic input, generated on the host then made resident in HBM --------------
     t0 = time.perf_counter()
@@ -257,13 +379,22 @@ def main():
     torch.cuda.set_stream(stream)
     gpu.set_stream(stream.cuda_stream)
 
-    def step():
+    def compute_only_step():
         gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
                             d_arena.data_ptr(), arena_cap, d_cursor.data_ptr(),
                             d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
-        if use_dist:  # the cursor stays on the device: one host sync (the sizes) per exchange
-            return allgather_clouds(d_arena, d_cursor, d_np, scan_starts=d_start)
-        return None
+
+    exch = None
+    if use_dist:
+        # N > 1: the library's own exchange (RCCL behind the C ABI): the rank's block is cut into
+        # chunks; chunk k is voxelised into arena half (k & 1) while chunk k - 1 is gathered
+        exch = CloudExchange(gpu, dist, dev, world, rank, B, n, out_stride, args.chunks)
+
+    def step():
+        if exch is None:
+            compute_only_step()
+        else:
+            exch.step(d_nodes, d_len, params)
 
     def fence():
         if use_dist:
@@ -283,23 +414,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # N > 1: the same K steps without the exchange (SURVEY.md §8e asks for both curves)
+    # N > 1: the same K steps without the exchange, and the exchange alone
     compute_only = None
     if use_dist:
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
-                                d_arena.data_ptr(), arena_cap, d_cursor.data_ptr(),
-                                d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
-        fence()
-        el2 = time.perf_counter() - t0
-        t = torch.tensor([el2], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el2 = float(t.item())
-        compute_only = {"value": round(B_total * n / (el2 / args.steps) / 1e6, 1),
-                        "ms_per_step": round(el2 / args.steps * 1e3, 4),
-                        "note": "same steps without the all-gather of the clouds"}
+        def timed_loop(fn):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            fence()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item()) / args.steps * 1e3
+        ms_c = timed_loop(compute_only_step)
+        ms_x = timed_loop(exch.exchange_only)
+        compute_only = {"value": round(B_total * n / ms_c / 1e3, 1), "ms_per_step": round(ms_c, 4),
+                        "exchange_only_ms": round(ms_x, 4),
+                        "overlapped_ms": round(elapsed / args.steps * 1e3, 4),
+                        "gathered_bytes_per_rank": exch.last_bytes(),
+                        "note": "compute = the rank's whole block in one launch, no exchange; "
+                                "exchange_only = RCCL all-gather of the last step's clouds; "
+                                "overlapped = the timed step (chunked, two streams)"}
+        compute_only_step()  # (status / cells below refer to the plain launch)
+        torch.cuda.synchronize(dev)
 
     status = int(d_st.max().item())
     cells_local = int(d_cursor.item())
@@ -322,23 +459,24 @@ def main():
         except Exception:
             h2d_ms = None
 
-    # ---- dominant kernel alone: HIP events on the launch stream, per launch -------------
+    # ---- dominant kernel alone: HIP events on the launch stream ---------------------------
+    # back to back (the figure the roofline uses: one event pair around `reps` launches, so the
+    # gaps between an event and a launch are not counted reps times) and per launch (min)
     reps = max(args.steps, 5)
+    k_ms_b2b = timed(compute_only_step, stream, reps, lambda: torch.cuda.synchronize(dev))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(reps)]
     for a, b in ev:
-        a.record(stream)  # the same launch as in the step (k_cloud_voxel + an 8-byte memset)
-        gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, params,
-                            d_arena.data_ptr(), arena_cap, d_cursor.data_ptr(),
-                            d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+        a.record(stream)  # the same launch as in the step (k_cloud_voxel + two tiny memsets)
+        compute_only_step()
         b.record(stream)
     torch.cuda.synchronize(dev)
     k_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    k_ms_avg = sum(k_ms) / len(k_ms)
     algo_bytes = 8 * B * n + 16 * cells_local  # 8 B read/sample + 16 B/cell out
-    achieved = algo_bytes / (k_ms_avg * 1e-3) / 1e9
+    achieved = algo_bytes / (k_ms_b2b * 1e-3) / 1e9
 
     extra = {}
+    sync = lambda: torch.cuda.synchronize(dev)
     if not args.no_laserscan:
         # secondary: the reference's own path (ascend + publish_scan Mode A) on a copy
         d_nodes2 = d_nodes.clone()
@@ -365,13 +503,16 @@ def main():
                 torch.cuda.synchronize(dev)
                 ts.append(a.elapsed_time(b))
             res[name] = min(ts[1:])
-        extra = {
+        valid = int(d_cnt.to(torch.int64).sum().item())
+        extra["reference_path_gpu"] = {
             "ascend_ms": round(res["ascend"], 4),
             "laserscan_ms": round(res["laserscan"], 4),
             "ascend_mpts": round(B * n / res["ascend"] / 1e3, 1),
             "laserscan_mpts": round(B * n / res["laserscan"] / 1e3, 1),
+            "laserscan_frac": round((8 * B * n + 8 * valid) / (res["laserscan"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         }
-        # secondary: the LaserScans of the batch as serialised (CDR) messages in HBM
+        # secondary: the LaserScans of the batch as serialised (CDR) messages in HBM, and the
+        # LaserScans projected to clouds (E7, laser_geometry-style)
         from rplidar_ros2_driver_amd import abi as _abi
         fid = "laser_frame"
         mstride = _abi.msg_laserscan_layout(len(fid), n).total_len
@@ -379,86 +520,65 @@ def main():
         d_ml = torch.zeros(B, dtype=torch.int32, device=dev)
         d_stamps = torch.zeros(B, 2, dtype=torch.int32, device=dev)
         d_dur = torch.full((B,), 0.1, dtype=torch.float64, device=dev)
-        ts = []
-        for it in range(4):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            gpu.laserscan_msgs_dev(d_r.data_ptr(), d_i.data_ptr(), n, d_cnt.data_ptr(), B, pl, fid,
-                                   d_stamps.data_ptr(), d_dur.data_ptr(), d_msgs.data_ptr(),
-                                   mstride, d_ml.data_ptr(), 0)
-            b.record(stream)
-            torch.cuda.synchronize(dev)
-            ts.append(a.elapsed_time(b))
+        ms = timed(lambda: gpu.laserscan_msgs_dev(d_r.data_ptr(), d_i.data_ptr(), n, d_cnt.data_ptr(), B,
+                                                  pl, fid, d_stamps.data_ptr(), d_dur.data_ptr(),
+                                                  d_msgs.data_ptr(), mstride, d_ml.data_ptr(), 0),
+                   stream, 3, sync)
         msg_bytes = int(d_ml.to(torch.int64).sum().item())
-        extra["laserscan_msgs_ms"] = round(min(ts[1:]), 4)
-        extra["laserscan_msgs_gbps_rw"] = round(2 * msg_bytes / min(ts[1:]) / 1e6, 1)
-        del d_nodes2, d_r, d_i, d_msgs
+        extra["reference_path_gpu"]["laserscan_msgs_ms"] = round(ms, 4)
+        extra["reference_path_gpu"]["laserscan_msgs_gbps_rw"] = round(2 * msg_bytes / ms / 1e6, 1)
+        del d_msgs
+        d_pc = torch.empty(B, n, 4, dtype=torch.float32, device=dev)
+        ms = timed(lambda: gpu.laserscan_to_cloud_batch_dev(d_r.data_ptr(), d_i.data_ptr(), n,
+                                                            d_cnt.data_ptr(), B, pl, d_pc.data_ptr(), n,
+                                                            d_np.data_ptr(), d_st.data_ptr()),
+                   stream, 3, sync)
+        pts = int(d_np.to(torch.int64).sum().item())
+        extra["reference_path_gpu"]["laserscan_to_cloud_ms"] = round(ms, 4)
+        extra["reference_path_gpu"]["laserscan_to_cloud_frac"] = round(
+            (8 * valid + 16 * pts) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        del d_nodes2, d_r, d_i, d_pc
 
-    if not args.no_decode and rank == 0:
-        extra.update(decode_stage(gpu, dev, stream, args.cpu_seconds))
-    if not args.no_laserscan and not args.no_c5 and rank == 0:
-        # secondary: BASELINE config 5 shape — 8 sensors x 32 frames of 32 000 samples with 1 cm
-        # range noise, E5 radius-outlier removal + voxel grid into one fused cloud (arena)
-        Bc = min(256, B)
-        c5 = synth.make_batch(args.seed + 5, Bc, n, noise_m=0.01)
-        d_c5 = torch.from_numpy(c5.view(np.uint8).reshape(Bc, n * 8)).to(dev)
-        d_len5 = torch.full((Bc,), n, dtype=torch.int32, device=dev)
+    variants = None
+    c5 = None
+    if not no_variants and rank == 0 and world == 1:
+        # the other data regimes of SURVEY.md §8(d) at the SAME shape (4096 x 32 000), same kernel
+        vreps = max(3, min(args.steps, 10))
+        variants = {"ring_clean": {"ms": round(k_ms_b2b, 4), "gpts_s": round(B * n / k_ms_b2b / 1e6, 1),
+                                   "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                   "frac_read": round(8 * B * n / (k_ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "cells": cells_local, "status_bits": status}}
+        pq = Params.defaults(clip_enable=1, q_min=48, range_min=0.15, range_max=40.0, voxel_enable=1,
+                             voxel_leaf=0.05)
+        variants["ring_clean_q_min48"] = regime(gpu, dev, stream, "q", batch_np, pq, d_arena, d_cursor,
+                                                d_start, d_np, d_st, vreps)
+        big_arena = torch.empty(B * n, 4, dtype=torch.float32, device=dev) if B * n * 16 < 8e9 else d_arena
+        for name, kw in (("ring_noise_1cm", dict(noise_m=0.01)), ("uniform", dict(kind="uniform"))):
+            vb = synth.make_batch(args.seed, B, n, **kw)
+            variants[name] = regime(gpu, dev, stream, name, vb, params, big_arena, d_cursor, d_start,
+                                    d_np, d_st, vreps if name != "uniform" else 3)
+            del vb
+        # BASELINE config 5 at throughput scale: 8 sensors x 512 frames of 32 000 samples with 1 cm
+        # range noise, E5 radius-outlier removal + E4 voxel grid into one fused arena
+        c5b = synth.make_batch(args.seed + 5, B, n, noise_m=0.01)
         p5 = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1,
                              voxel_leaf=0.05, ror_enable=1, ror_radius=0.10, ror_min_neighbors=2)
-        ts = []
-        for it in range(4):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            gpu.cloud_arena_dev(d_c5.data_ptr(), n, d_len5.data_ptr(), Bc, p5, d_arena.data_ptr(),
-                                arena_cap, d_cursor.data_ptr(), d_start.data_ptr(),
-                                d_np.data_ptr(), d_st.data_ptr())
-            b.record(stream)
-            torch.cuda.synchronize(dev)
-            ts.append(a.elapsed_time(b))
-        extra["c5_ror_voxel_ms"] = round(min(ts[1:]), 4)
-        extra["c5_scans"] = Bc
-        extra["c5_ror_voxel_mpts"] = round(Bc * n / min(ts[1:]) / 1e3, 1)
-        del d_c5
+        c5 = regime(gpu, dev, stream, "c5", c5b, p5, big_arena, d_cursor, d_start, d_np, d_st, vreps)
+        c5["workload"] = f"8 sensors x {B // 8} frames x {n} samples, 1 cm range noise, ROR(0.10 m, >= 2) + voxel 5 cm"
+        del c5b, big_arena
+
+    if not args.no_decode and rank == 0:
+        extra["decode"] = decode_stage(gpu, dev, stream, args.cpu_seconds)
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         cpu = cpu_baseline(batch_np, lens_np, params, args.cpu_seconds)
 
-    if rank == 0 and not args.no_laserscan and not args.no_c5:
-        # secondary: BASELINE config 2 — ONE 32 000-sample scan through the host-buffer entry
-        # points the node calls per scan (H2D + kernels + D2H + sync), wall clock per call
-        one = np.ascontiguousarray(batch_np[0])
-        pl1 = Params.defaults(range_max=40.0)
-        pin = gpu.host_alloc(1 << 20)
-        lat = {}
-        for name, fn in (
-            ("laserscan", lambda: gpu.scan_to_laserscan(one, pl1, 0.1)),
-            ("laserscan_msg_pinned", lambda: gpu.scan_to_laserscan_msg(one, pl1, 0.1, "laser_frame",
-                                                                       1, 2, out=pin)),
-            ("voxel_cloud", lambda: gpu.scan_to_cloud(one, params)),
-        ):
-            for _ in range(20):
-                fn()
-            t0 = time.perf_counter()
-            for _ in range(200):
-                fn()
-            lat[name] = (time.perf_counter() - t0) / 200 * 1e6
-        gpu.host_free(pin)
-        extra["single_scan_us"] = {k: round(v, 1) for k, v in lat.items()}
-        if args.cpu_seconds > 0:  # the CPU loop the node runs today, same scan, one core
-            from tests import oracle_lib
-            orc = oracle_lib.load_oracle()
-            op = oracle_lib.copy_params(pl1)
-            t0 = time.perf_counter()
-            reps = 0
-            while time.perf_counter() - t0 < 0.5:
-                orc.publish_scan(one, op, 0.1)
-                reps += 1
-            extra["single_scan_us"]["cpu_publish_scan_oracle"] = round(
-                (time.perf_counter() - t0) / reps * 1e6, 1)
+    if rank == 0 and not args.no_single:
+        extra["single_scan_us"] = single_scan_table(gpu, params, args.seed, args.cpu_seconds)
 
     if rank == 0:
-        traffic, traffic_src = measured_traffic("k_cloud_voxel", B, n)
+        traffic, traffic_src = static_traffic("k_cloud_voxel", B, n)
         ms_per_step = elapsed / args.steps * 1e3
         value = B_total * n / (elapsed / args.steps) / 1e6
         line = {
@@ -476,9 +596,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"config3: {B_total} scans x {n} samples (ring, 10% invalid runs), "
-                            f"clip [0.15,40] m + polar->XYZ + 5 cm voxel grid into one contiguous cloud"
+                            f"clip [0.15,40] m, q_min 0 (BASELINE config 3's filter at its SURVEY 8(a-ext) "
+                            f"default; the q_min 48 leg is in `variants`) + polar->XYZ + 5 cm voxel grid "
+                            f"into one contiguous cloud"
                             + ("" if world == 1 else f", sharded by scan over {world} GPUs + "
-                               "RCCL all-gather of voxelised clouds"),
+                               "RCCL all-gather of voxelised clouds (chunked, overlapped)"),
                 "scans": B_total, "samples_per_scan": n, "voxel_leaf_m": 0.05,
                 "input_bytes": 8 * B_total * n,
             },
@@ -489,20 +611,22 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_read": round(8 * B * n / (k_ms_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_of_copy_rate": round(achieved / HBM_COPY_GBS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel_ms_avg": round(k_ms_avg, 4),
+                "kernel_ms_avg": round(k_ms_b2b, 4),
                 "kernel_ms_min": round(k_ms[0], 4),
+                "kernel_ms_note": "avg = back-to-back launches between one event pair (this rank's "
+                                  "block); min = best single launch bracketed by its own events",
                 "algorithmic_bytes": algo_bytes,
-                "note": "priced against HBM as SURVEY 8(d) asks; the binding resource is vector "
-                        "issue: SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 4 waves per SIMD) = 0.69 "
-                        "in profiles/r01/rocprof_summary_v9.txt (DESIGN.md section 8)",
-                # SQ_INSTS_VALU of that profile: 167.6 M wave-instructions per 131.072 M samples
-                "valu": {"lane_ops_per_sample": 81.9,
-                         "peak_lane_ops_per_s": 256 * 4 * 16 * 2.4e9,
-                         "frac": round(B * n / (k_ms_avg * 1e-3) * 81.9 / (256 * 4 * 16 * 2.4e9), 4)},
+                "note": "priced against HBM as SURVEY 8(d) asks; phase S of the kernel is bound by the "
+                        "CU's own memory pipeline (~33 k cycles per scan whatever the prefetch depth), "
+                        "phase R by vector issue + LDS latency: profiles/r02/voxel_phaseS_study.txt",
             },
             "cpu_baseline": cpu,
+            "variants": variants,
+            "c5": c5,
             "compute_only": compute_only,
             "status_bits": status,
             "cells_out_rank0": cells_local,
@@ -514,6 +638,8 @@ def main():
         line.update(extra)
         print(json.dumps(line), flush=True)
 
+    if exch is not None:
+        exch.close()
     gpu.close()
     if use_dist:
         dist.destroy_process_group()

@@ -14,12 +14,9 @@
 
 namespace rpl {
 
-#ifndef RPL_KBLOCK
-#define RPL_KBLOCK 1024
-#endif
-constexpr int kBlock = RPL_KBLOCK;  // (developer builds of single translation units may override it)
+constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
-constexpr int kIters = 32768 / kBlock;           // 32768 samples / 1024 threads = 32
+constexpr int kIters = 32;                       // 32768 samples / 1024 threads
 constexpr uint32_t kMaxN = 32768;                // == RPLGPU_MAX_SAMPLES_PER_SCAN
 constexpr int kChunks = kIters * kWaves;         // 512 chunks of 64 samples
 constexpr double kTwoPi = 6.283185307179586476925286766559;  // 2.0 * M_PI
@@ -34,6 +31,8 @@ struct Tables {
   const double *rcp;       // rcp[c] = RN(1.0 / c), c = 1..32768 (voxel centroids), rcp[0] = 0
   uint32_t *work_ctr;      // dynamic scan queue of k_cloud_voxel (one word, cleared by every launch)
   uint32_t n_cu;           // compute units of the handle's device (persistent-workgroup grids)
+  void *voxel_store;       // k_cloud_voxel's record stores: voxel_store_wgs x 32768 x 16 B
+  uint32_t voxel_store_wgs;
 };
 
 struct KParams {

@@ -42,6 +42,9 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               unsigned long long arena_capacity = 0,
                               unsigned long long *arena_cursor = nullptr,
                               unsigned long long *scan_start = nullptr);
+// record stores k_cloud_voxel needs: one per resident workgroup (two per CU), this many bytes each
+uint32_t voxel_max_workgroups(uint32_t n_cu);
+size_t voxel_store_bytes_per_workgroup();
 hipError_t launch_ror_mask(hipStream_t s, const void *nodes, uint32_t n_stride,
                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                            const Tables &T, uint32_t *mask, uint32_t mask_stride);

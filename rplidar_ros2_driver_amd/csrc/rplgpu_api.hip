@@ -44,6 +44,8 @@ struct rplgpu_ctx {
   bool idx_checked = false, idx_ok = false;  // Mode A bin-index divide, see k_validate_idx
   unsigned long long *dbg = nullptr;  // developer aid: per-block phase cycle counters
   uint32_t n_cu = 0;                  // compute units of `device`
+  void *d_vstore = nullptr;           // k_cloud_voxel record stores (one per resident workgroup)
+  uint32_t vstore_wgs = 0;
   unsigned char *d_dec = nullptr;     // rplgpu_decode_stream staging (grown on demand, kept)
   size_t dec_cap = 0;
   bool check_ptrs = true;             // batch entry points verify that buffers are device memory
@@ -145,6 +147,8 @@ rpl::Tables tables_of(const rplgpu_ctx *c) {
   t.rcp = c->d_rcp;
   t.work_ctr = c->d_small + 16;  // [16] next scan of k_cloud_voxel's queue (cleared per launch)
   t.n_cu = c->n_cu;
+  t.voxel_store = c->d_vstore;
+  t.voxel_store_wgs = c->vstore_wgs;
   return t;
 }
 
@@ -205,6 +209,7 @@ void free_ctx(rplgpu_ctx *c) {
   if (c->d_rormask) (void)hipFree(c->d_rormask);
   if (c->d_need_sort) (void)hipFree(c->d_need_sort);
   if (c->d_dec) (void)hipFree(c->d_dec);
+  if (c->d_vstore) (void)hipFree(c->d_vstore);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -418,6 +423,13 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
     return fail(RPLGPU_ERR_HIP);
   }
   c->need_sort_cap = c->max_b;
+  // the voxel kernel's record stores (overflow of its LDS queue; 512 KiB per resident workgroup,
+  // at most two workgroups per CU and never more than scans in a batch)
+  c->vstore_wgs = std::min<uint32_t>(c->max_b, rpl::voxel_max_workgroups(c->n_cu));
+  if (hipMalloc(&c->d_vstore, (size_t)c->vstore_wgs * rpl::voxel_store_bytes_per_workgroup()) != hipSuccess) {
+    c->err = "record store allocation failed";
+    return fail(RPLGPU_ERR_HIP);
+  }
   if (hipMemset(c->d_small, 0, 128) != hipSuccess) {  // incl. the voxel kernel's scan queue
     c->err = "staging clear failed";
     return fail(RPLGPU_ERR_HIP);

@@ -36,22 +36,10 @@ dbg = d_dbg.cpu().numpy()
 nrec = dbg[:, 7] >> 40
 dbg[:, 7] &= (1 << 40) - 1
 print("records/scan mean %.0f p50 %.0f p90 %.0f p99 %.0f max %d" % (nrec.mean(), np.median(nrec), np.percentile(nrec, 90), np.percentile(nrec, 99), nrec.max()))
-names = ["stream", "load+rowminmax", "rowhist", "rowscan", "scatter", "rank+permute", "heads+scan", "emit"]
+names = ["stream", "load+rowminmax", "select(store)", "rowscan", "scatter", "rank+permute", "heads+scan", "emit"]
 for i, nm in enumerate(names):
     print("  %-16s mean %8.0f  p50 %8.0f  p99 %8.0f" % (nm, dbg[:, i].mean(), np.median(dbg[:, i]), np.percentile(dbg[:, i], 99)))
 print("  total mean %.0f" % dbg.sum(1).mean())
 npts = d_np.cpu().numpy()
 print("cells mean", npts.mean(), "status", int(d_st.max()))
 
-if os.environ.get('RPL_VOXDBG_CLK'):
-    g = int(os.environ.get('RPLGPU_VOXEL_GRID', '256'))
-    c, w = dbg[:g, 5].astype(float), dbg[:g, 6].astype(float)
-    print("core clock MHz per workgroup: mean %.0f min %.0f max %.0f (wall us mean %.1f)" % ((c / w * 100).mean(), (c / w * 100).min(), (c / w * 100).max(), w.mean() / 100))
-    st = dbg[:g, 7].astype(float); st -= st.min(); en = st + w
-    print("  start us: p50 %.1f p90 %.1f max %.1f | end us: p50 %.1f max %.1f | life us: p10 %.1f p50 %.1f p90 %.1f" % (
-        np.median(st) / 100, np.percentile(st, 90) / 100, st.max() / 100, np.median(en) / 100, en.max() / 100,
-        np.percentile(w, 10) / 100, np.median(w) / 100, np.percentile(w, 90) / 100))
-    ids = dbg[:g, 4]
-    import collections
-    cnt = collections.Counter(ids.tolist())
-    print("  distinct (xcc, smid) slots: %d, workgroups per slot max %d" % (len(cnt), max(cnt.values())))
