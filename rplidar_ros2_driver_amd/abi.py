@@ -78,6 +78,16 @@ ABI_SYMBOLS = [
     "rplgpu_cloud_deskew_batch_dev",
     "rplgpu_laserscan_to_cloud_batch_dev",
     "rplgpu_laserscan_to_cloud",
+    # include/rplgpu_comm.h
+    "rplgpu_comm_unique_id",
+    "rplgpu_comm_init",
+    "rplgpu_comm_destroy",
+    "rplgpu_cloud_meta_words",
+    "rplgpu_pack_cloud_meta_dev",
+    "rplgpu_allgather_clouds_dev",
+    "rplgpu_comm_fence",
+    "rplgpu_comm_fence_lag",
+    "rplgpu_unpack_gathered_dev",
 ]
 
 
@@ -237,6 +247,16 @@ def load_library() -> C.CDLL:
                                                         vp, u32, vp, vp]
     lib.rplgpu_laserscan_to_cloud.argtypes = [vp, vp, vp, u32, C.POINTER(Params), vp,
                                               C.POINTER(u32)]
+    lib.rplgpu_comm_unique_id.argtypes = [vp]
+    lib.rplgpu_comm_init.argtypes = [vp, i32, i32, vp]
+    lib.rplgpu_comm_destroy.argtypes = [vp]
+    lib.rplgpu_cloud_meta_words.argtypes = [u32]
+    lib.rplgpu_cloud_meta_words.restype = u32
+    lib.rplgpu_pack_cloud_meta_dev.argtypes = [vp, vp, vp, vp, u32, u64, u32, vp]
+    lib.rplgpu_allgather_clouds_dev.argtypes = [vp, vp, u64, vp, u32, vp, vp]
+    lib.rplgpu_comm_fence.argtypes = [vp]
+    lib.rplgpu_comm_fence_lag.argtypes = [vp, u32]
+    lib.rplgpu_unpack_gathered_dev.argtypes = [vp, vp, u64, vp, u32, u32, u32, vp, vp, vp, vp, vp]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default
@@ -456,6 +476,45 @@ class RplGpu:
             xyzi.ctypes.data, C.byref(npts)))
         return xyzi[: npts.value]
 
+    # -- multi-GPU exchange (include/rplgpu_comm.h) ------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> np.ndarray:
+        """A fresh RCCL unique id (rank 0 makes it, the caller carries it to the other ranks)."""
+        uid = np.zeros(128, np.uint8)
+        rc = load_library().rplgpu_comm_unique_id(uid.ctypes.data)
+        if rc:
+            raise RplGpuError(rc, "rplgpu_comm_unique_id (is librccl.so loadable?)")
+        return uid
+
+    def comm_init(self, rank: int, world: int, uid: np.ndarray):
+        uid = np.ascontiguousarray(uid, np.uint8)
+        assert uid.nbytes == 128
+        self._check(self._lib.rplgpu_comm_init(self._h, rank, world, uid.ctypes.data))
+
+    def comm_destroy(self):
+        self._check(self._lib.rplgpu_comm_destroy(self._h))
+
+    def pack_cloud_meta_dev(self, d_cursor: int, d_scan_start: int, d_n_points: int, B: int,
+                            slot_points: int, max_scans: int, d_meta: int):
+        self._check(self._lib.rplgpu_pack_cloud_meta_dev(
+            self._h, d_cursor, d_scan_start, d_n_points, B, slot_points, max_scans, d_meta))
+
+    def allgather_clouds_dev(self, d_points_local: int, slot_points: int, d_meta_local: int,
+                             meta_words: int, d_points_all: int, d_meta_all: int):
+        self._check(self._lib.rplgpu_allgather_clouds_dev(
+            self._h, d_points_local, slot_points, d_meta_local, meta_words, d_points_all, d_meta_all))
+
+    def comm_fence(self, lag: int = 0):
+        self._check(self._lib.rplgpu_comm_fence_lag(self._h, lag))
+
+    def unpack_gathered_dev(self, d_points_all: int, slot_points: int, d_meta_all: int,
+                            meta_words: int, world: int, max_scans: int, d_packed: int,
+                            d_total: int, d_scan_start_all: int, d_n_points_all: int,
+                            d_status: int = 0):
+        self._check(self._lib.rplgpu_unpack_gathered_dev(
+            self._h, d_points_all, slot_points, d_meta_all, meta_words, world, max_scans, d_packed,
+            d_total, d_scan_start_all, d_n_points_all, d_status))
+
     def fused_cloud_msg_dev(self, d_arena: int, d_total_points: int, arena_capacity: int,
                             frame_id: str, sec: int, nanosec: int, d_msg: int, msg_capacity: int,
                             d_msg_len: int, d_status: int = 0):
@@ -509,6 +568,10 @@ class RplGpu:
         self._check(self._lib.rplgpu_scans_to_batch_dev(
             self._h, d_seg_nodes, seg_stride, d_scan_off, scan_cap, d_n_scans, B, d_scan_base,
             d_batch, n_stride, max_scans, d_n_per_scan))
+
+
+def cloud_meta_words(max_scans: int) -> int:
+    return int(load_library().rplgpu_cloud_meta_words(max_scans))
 
 
 def msg_laserscan_layout(frame_id_len: int, count: int) -> LaserScanLayout:

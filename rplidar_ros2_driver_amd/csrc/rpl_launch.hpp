@@ -5,6 +5,7 @@
 
 #include "rplgpu.h"
 #include "rplgpu_msg.h"
+#include "rplgpu_comm.h"
 #include "rpl_device.hpp"
 
 namespace rplmsg {
@@ -58,6 +59,18 @@ hipError_t launch_laserscan_to_cloud(hipStream_t s, const float *ranges, const f
                                      uint32_t n_stride, const uint32_t *beam_count, uint32_t B,
                                      const KParams &p, float *xyzi, uint32_t out_stride,
                                      uint32_t *n_points, uint32_t *status);
+
+// multi-GPU exchange, device side (rpl_comm.hip)
+hipError_t launch_pack_meta(hipStream_t s, const unsigned long long *cursor,
+                            const unsigned long long *scan_start, const uint32_t *n_points,
+                            uint32_t B, unsigned long long slot_points, uint32_t max_scans,
+                            uint32_t *meta);
+hipError_t launch_unpack_gathered(hipStream_t s, const float *points_all,
+                                  unsigned long long slot_points, const uint32_t *meta_all,
+                                  uint32_t meta_words, uint32_t world, uint32_t max_scans,
+                                  float *packed, unsigned long long *total,
+                                  unsigned long long *scan_start_all, uint32_t *n_points_all,
+                                  uint32_t *status, uint32_t n_cu);
 
 // decode stage (rpl_decode.hip)
 hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,

@@ -5,6 +5,7 @@
 // checking.  All arithmetic on samples happens in rpl_kernels.hip.  There is no CPU
 // fallback: if no gfx950 device is usable, rplgpu_create fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -49,7 +50,17 @@ struct rplgpu_ctx {
   unsigned char *d_dec = nullptr;     // rplgpu_decode_stream staging (grown on demand, kept)
   size_t dec_cap = 0;
   bool check_ptrs = true;             // batch entry points verify that buffers are device memory
+  // multi-GPU exchange (include/rplgpu_comm.h)
+  void *comm = nullptr;               // ncclComm_t
+  int32_t comm_rank = 0, comm_world = 0;
+  hipStream_t xstream = nullptr;      // exchange stream
+  hipEvent_t ev_main = nullptr, ev_x[4] = {nullptr, nullptr, nullptr, nullptr};  // ring of exchange-done events
+  uint32_t n_exchanges = 0;
   std::string err;
+};
+
+struct rplgpu_nccl_id_t {
+  char internal[128];  // == ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
 };
 
 namespace {
@@ -193,9 +204,12 @@ int32_t upload(rplgpu_ctx *c, T **dst, const std::vector<T> &src) {
   return RPLGPU_OK;
 }
 
+void comm_teardown(rplgpu_ctx *c);
+
 void free_ctx(rplgpu_ctx *c) {
   if (!c) return;
   if (c->device >= 0) (void)hipSetDevice(c->device);
+  comm_teardown(c);
   if (c->d_angle) (void)hipFree(c->d_angle);
   if (c->d_angle_inv) (void)hipFree(c->d_angle_inv);
   if (c->d_inc) (void)hipFree(c->d_inc);
@@ -487,6 +501,7 @@ int32_t rplgpu_synchronize(rplgpu_handle_t h) {
   if (!h) return RPLGPU_ERR_INVALID_ARG;
   RPL_HIP(h, hipSetDevice(h->device));
   RPL_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->xstream) RPL_HIP(h, hipStreamSynchronize(h->xstream));
   return RPLGPU_OK;
 }
 
@@ -1247,6 +1262,199 @@ int32_t rplgpu_cloud_deskew_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_
   RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(h),
                                false, mask, kMaskStride, d_xyzi, out_stride, d_n_points, d_status,
                                d_motion));
+  return RPLGPU_OK;
+}
+
+}  // extern "C"
+
+// ---- multi-GPU exchange (include/rplgpu_comm.h) ------------------------------------------
+// RCCL is loaded at run time: a node that never exchanges clouds does not need it, and a host
+// process that already has an RCCL mapped (PyTorch ships its own) keeps exactly that one.
+namespace {
+
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;
+  int (*CommInitRank)(void **, int, rplgpu_nccl_id_t, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+
+RcclApi &rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *n : names) {
+      a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (a.lib) break;
+    }
+    if (!a.lib) return a;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.lib, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.GroupStart &&
+           a.GroupEnd;
+    return a;
+  }();
+  return api;
+}
+
+constexpr int kNcclUint32 = 3, kNcclFloat32 = 7;  // ncclDataType_t (rccl.h)
+
+#define RPL_NCCL(ctx, call)                                                                     \
+  do {                                                                                          \
+    int r_ = (call);                                                                            \
+    if (r_ != 0) {                                                                              \
+      (ctx)->err = std::string(#call) + ": " +                                                 \
+                   (rccl().GetErrorString ? rccl().GetErrorString(r_) : "RCCL error");          \
+      return RPLGPU_ERR_HIP;                                                                    \
+    }                                                                                           \
+  } while (0)
+
+void comm_teardown(rplgpu_ctx *c) {
+  if (c->comm && rccl().ok) {
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+    (void)rccl().CommDestroy(c->comm);
+  }
+  c->comm = nullptr;
+  c->comm_world = 0;
+  if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+  for (auto &e : c->ev_x) {
+    if (e) (void)hipEventDestroy(e);
+    e = nullptr;
+  }
+  if (c->xstream) (void)hipStreamDestroy(c->xstream);
+  c->ev_main = nullptr;
+  c->xstream = nullptr;
+  c->n_exchanges = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rplgpu_comm_unique_id(uint8_t id[RPLGPU_COMM_ID_BYTES]) {
+  if (!id) return RPLGPU_ERR_INVALID_ARG;
+  if (!rccl().ok) return RPLGPU_ERR_NO_DEVICE;
+  static_assert(sizeof(rplgpu_nccl_id_t) == RPLGPU_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  return rccl().GetUniqueId(id) == 0 ? RPLGPU_OK : RPLGPU_ERR_HIP;
+}
+
+int32_t rplgpu_comm_init(rplgpu_handle_t h, int32_t rank, int32_t world,
+                         const uint8_t id[RPLGPU_COMM_ID_BYTES]) {
+  if (!h || !id || world < 1 || rank < 0 || rank >= world) return RPLGPU_ERR_INVALID_ARG;
+  if (!rccl().ok) {
+    h->err = "RCCL (librccl.so) could not be loaded";
+    return RPLGPU_ERR_NO_DEVICE;
+  }
+  if (h->comm) {
+    h->err = "communicator already initialised (rplgpu_comm_destroy first)";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, hipStreamCreateWithFlags(&h->xstream, hipStreamNonBlocking));
+  RPL_HIP(h, hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+  for (auto &e : h->ev_x) RPL_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  rplgpu_nccl_id_t uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  RPL_NCCL(h, rccl().CommInitRank(&h->comm, world, uid, rank));
+  h->comm_rank = rank;
+  h->comm_world = world;
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_comm_destroy(rplgpu_handle_t h) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  (void)hipSetDevice(h->device);
+  comm_teardown(h);
+  return RPLGPU_OK;
+}
+
+uint32_t rplgpu_cloud_meta_words(uint32_t max_scans) { return 4u + 3u * max_scans; }
+
+int32_t rplgpu_pack_cloud_meta_dev(rplgpu_handle_t h, const uint64_t *d_cursor,
+                                   const uint64_t *d_scan_start, const uint32_t *d_n_points,
+                                   uint32_t B, uint64_t slot_points, uint32_t max_scans,
+                                   uint32_t *d_meta) {
+  if (!h || !d_cursor || !d_meta || (B && (!d_scan_start || !d_n_points)) || B > max_scans)
+    return RPLGPU_ERR_INVALID_ARG;
+  if (!device_readable(h, d_cursor, "d_cursor") || !device_readable(h, d_meta, "d_meta"))
+    return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_pack_meta(h->stream, reinterpret_cast<const unsigned long long *>(d_cursor),
+                                   reinterpret_cast<const unsigned long long *>(d_scan_start),
+                                   d_n_points, B, slot_points, max_scans, d_meta));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_allgather_clouds_dev(rplgpu_handle_t h, const float *d_points_local,
+                                    uint64_t slot_points, const uint32_t *d_meta_local,
+                                    uint32_t meta_words, float *d_points_all,
+                                    uint32_t *d_meta_all) {
+  if (!h || !d_points_local || !d_meta_local || !d_points_all || !d_meta_all || meta_words == 0)
+    return RPLGPU_ERR_INVALID_ARG;
+  if (!h->comm) {
+    h->err = "rplgpu_comm_init has not been called";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  if (!device_readable(h, d_points_local, "d_points_local") ||
+      !device_readable(h, d_points_all, "d_points_all") ||
+      !device_readable(h, d_meta_local, "d_meta_local") ||
+      !device_readable(h, d_meta_all, "d_meta_all"))
+    return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  // the exchange stream picks up after everything queued on the main stream so far
+  RPL_HIP(h, hipEventRecord(h->ev_main, h->stream));
+  RPL_HIP(h, hipStreamWaitEvent(h->xstream, h->ev_main, 0));
+  RPL_NCCL(h, rccl().GroupStart());
+  int r1 = rccl().AllGather(d_meta_local, d_meta_all, meta_words, kNcclUint32, h->comm, h->xstream);
+  int r2 = slot_points ? rccl().AllGather(d_points_local, d_points_all, (size_t)slot_points * 4u,
+                                          kNcclFloat32, h->comm, h->xstream)
+                       : 0;
+  RPL_NCCL(h, rccl().GroupEnd());
+  RPL_NCCL(h, r1);
+  RPL_NCCL(h, r2);
+  RPL_HIP(h, hipEventRecord(h->ev_x[h->n_exchanges & 3u], h->xstream));
+  ++h->n_exchanges;
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_comm_fence_lag(rplgpu_handle_t h, uint32_t lag) {
+  if (!h || lag > 3u) return RPLGPU_ERR_INVALID_ARG;
+  if (!h->comm || h->n_exchanges <= lag) return RPLGPU_OK;  // no such exchange: nothing to wait for
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, hipStreamWaitEvent(h->stream, h->ev_x[(h->n_exchanges - 1u - lag) & 3u], 0));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_comm_fence(rplgpu_handle_t h) { return rplgpu_comm_fence_lag(h, 0u); }
+
+int32_t rplgpu_unpack_gathered_dev(rplgpu_handle_t h, const float *d_points_all,
+                                   uint64_t slot_points, const uint32_t *d_meta_all,
+                                   uint32_t meta_words, uint32_t world, uint32_t max_scans,
+                                   float *d_packed, uint64_t *d_total,
+                                   uint64_t *d_scan_start_all, uint32_t *d_n_points_all,
+                                   uint32_t *d_status) {
+  if (!h || !d_points_all || !d_meta_all || !d_packed || !d_total || !d_scan_start_all ||
+      !d_n_points_all || world == 0 || world > 4096 || meta_words < rplgpu_cloud_meta_words(max_scans))
+    return RPLGPU_ERR_INVALID_ARG;
+  if (!device_readable(h, d_points_all, "d_points_all") || !device_readable(h, d_meta_all, "d_meta_all") ||
+      !device_readable(h, d_packed, "d_packed"))
+    return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_unpack_gathered(
+                 h->stream, d_points_all, slot_points, d_meta_all, meta_words, world, max_scans, d_packed,
+                 reinterpret_cast<unsigned long long *>(d_total),
+                 reinterpret_cast<unsigned long long *>(d_scan_start_all), d_n_points_all, d_status,
+                 h->n_cu));
   return RPLGPU_OK;
 }
 

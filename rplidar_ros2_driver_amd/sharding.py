@@ -119,3 +119,140 @@ def split_by_scan(cloud: torch.Tensor, counts: torch.Tensor,
     if starts is None:
         return list(torch.split(cloud[: sum(sizes)], sizes)) if sizes else []
     return [cloud[int(a): int(a) + n] for a, n in zip(starts.cpu().tolist(), sizes)]
+
+
+# ---------------------------------------------------------------------------------------------
+# The exchange behind the C ABI (include/rplgpu_comm.h): layout twins + the chunked, overlapped
+# driver bench.py uses.  The twins restate, in torch, what k_pack_meta / k_unpack_gathered do, so
+# that the N > 1 layout is testable on CPU (gloo, world_size 2) and the kernels are checked
+# against them on the GPU.
+# ---------------------------------------------------------------------------------------------
+def meta_words(max_scans: int) -> int:
+    return 4 + 3 * max_scans
+
+
+def pack_cloud_meta(cursor: int, scan_start, n_points, slot_points: int, max_scans: int) -> torch.Tensor:
+    """Twin of ``rplgpu_pack_cloud_meta_dev``: int64 inputs -> (meta_words,) int32 tensor holding
+    the u32 words [count lo, count hi, B, flags, B x {start lo, start hi, n_points}]."""
+    B = int(len(n_points))
+    assert B <= max_scans
+    m = torch.zeros(meta_words(max_scans), dtype=torch.int64)
+    k = min(int(cursor), int(slot_points))
+    m[0], m[1], m[2], m[3] = k & 0xFFFFFFFF, k >> 32, B, int(int(cursor) > int(slot_points))
+    for s in range(B):
+        st, n = int(scan_start[s]), int(n_points[s])
+        if st >= slot_points:
+            st, n = 0, 0
+        elif st + n > slot_points:
+            n = int(slot_points) - st
+        m[4 + 3 * s], m[5 + 3 * s], m[6 + 3 * s] = st & 0xFFFFFFFF, st >> 32, n
+    return m.to(torch.int32) if int(m.max()) < 2**31 else (m - (m >= 2**31) * 2**32).to(torch.int32)
+
+
+def unpack_gathered(points_all: torch.Tensor, meta_all: torch.Tensor, slot_points: int,
+                    world: int, max_scans: int):
+    """Twin of ``rplgpu_unpack_gathered_dev``: (world*slot_points, 4) float32 slots and
+    (world, meta_words) int32 meta -> (packed (total, 4), scan_start_all (world, max_scans) int64,
+    n_points_all (world, max_scans) int64, status (world,))."""
+    meta = meta_all.view(world, -1).to(torch.int64) & 0xFFFFFFFF
+    counts = torch.clamp(meta[:, 0] | (meta[:, 1] << 32), max=slot_points)
+    offs = torch.cumsum(counts, 0) - counts
+    packed = torch.cat([points_all.view(world, slot_points, 4)[r, : int(counts[r])] for r in range(world)]) \
+        if world else points_all.new_zeros(0, 4)
+    starts = torch.zeros(world, max_scans, dtype=torch.int64)
+    npts = torch.zeros(world, max_scans, dtype=torch.int64)
+    for r in range(world):
+        B = min(int(meta[r, 2]), max_scans)
+        for s in range(B):
+            n = int(meta[r, 6 + 3 * s])
+            npts[r, s] = n
+            starts[r, s] = (int(meta[r, 4 + 3 * s]) | (int(meta[r, 5 + 3 * s]) << 32)) + int(offs[r]) if n else 0
+    status = (meta[:, 3] & 1) * 8  # RPLGPU_SCAN_OUT_TRUNCATED
+    return packed, starts, npts, status
+
+
+class CloudExchange:
+    """bench.py's N > 1 step through the library's own exchange: the rank's block of scans is cut
+    into `chunks`; chunk c is voxelised into arena (c & 1) on the handle's main stream and its
+    cloud all-gathered (RCCL, exchange stream) while chunk c + 1 is being voxelised.  Slot sizes
+    are fixed after one calibration pass (max cells per chunk over all ranks + 15 % head room), so
+    a timed step has no host synchronisation: counts travel in the META blocks on the device."""
+
+    def __init__(self, gpu, dist_mod, dev, world, rank, B, n, out_stride, chunks):
+        self.gpu, self.dist, self.dev, self.world, self.rank = gpu, dist_mod, dev, world, rank
+        self.B, self.n = B, n
+        self.chunks = max(1, min(chunks, max(B, 1)))
+        self.Bc = (B + self.chunks - 1) // self.chunks
+        self.mw = meta_words(self.Bc)
+        # communicator: rank 0's unique id travels through torch.distributed
+        import numpy as np
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.from_numpy(gpu.comm_unique_id()))
+        self.dist.broadcast(uid, src=0)
+        gpu.comm_init(rank, world, uid.cpu().numpy())
+        cap = self.Bc * out_stride
+        self.cap = cap
+        self.arena = [torch.empty(cap, 4, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.cursor = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.start = [torch.zeros(self.Bc, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.npts = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.stat = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.meta = [torch.zeros(self.mw, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.slot = None
+        self.recv_pts = None
+        self.recv_meta = torch.zeros(self.chunks, world, self.mw, dtype=torch.int32, device=dev)
+
+    def _chunk(self, c):
+        lo = c * self.Bc
+        return lo, min(self.Bc, self.B - lo)
+
+    def _calibrate(self, d_nodes, d_len, params):
+        worst = 0
+        for c in range(self.chunks):
+            lo, nb = self._chunk(c)
+            if nb <= 0:
+                continue
+            self.gpu.cloud_arena_dev(d_nodes.data_ptr() + lo * self.n * 8, self.n, d_len.data_ptr() + lo * 4,
+                                     nb, params, self.arena[0].data_ptr(), self.cap,
+                                     self.cursor[0].data_ptr(), self.start[0].data_ptr(),
+                                     self.npts[0].data_ptr(), self.stat[0].data_ptr())
+            self.gpu.synchronize()
+            worst = max(worst, int(self.cursor[0].item()))
+        t = torch.tensor([worst], dtype=torch.int64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        self.slot = min(self.cap, int(int(t.item()) * 1.15) + 1024)
+        self.recv_pts = torch.empty(self.chunks, self.world, self.slot, 4, dtype=torch.float32,
+                                    device=self.dev)
+
+    def step(self, d_nodes, d_len, params):
+        if self.slot is None:
+            self._calibrate(d_nodes, d_len, params)
+        g = self.gpu
+        for c in range(self.chunks):
+            lo, nb = self._chunk(c)
+            if nb <= 0:
+                continue
+            k = c & 1
+            g.comm_fence(1)  # arena k was last read by the gather of chunk c - 2
+            g.cloud_arena_dev(d_nodes.data_ptr() + lo * self.n * 8, self.n, d_len.data_ptr() + lo * 4, nb,
+                              params, self.arena[k].data_ptr(), self.cap, self.cursor[k].data_ptr(),
+                              self.start[k].data_ptr(), self.npts[k].data_ptr(), self.stat[k].data_ptr())
+            g.pack_cloud_meta_dev(self.cursor[k].data_ptr(), self.start[k].data_ptr(),
+                                  self.npts[k].data_ptr(), nb, self.slot, self.Bc, self.meta[k].data_ptr())
+            g.allgather_clouds_dev(self.arena[k].data_ptr(), self.slot, self.meta[k].data_ptr(), self.mw,
+                                   self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
+        g.comm_fence(0)
+
+    def exchange_only(self):
+        for c in range(self.chunks):
+            k = c & 1
+            self.gpu.allgather_clouds_dev(self.arena[k].data_ptr(), self.slot, self.meta[k].data_ptr(),
+                                          self.mw, self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
+        self.gpu.comm_fence(0)
+
+    def last_bytes(self):
+        return int(self.chunks * self.world * (self.slot or 0) * 16)
+
+    def close(self):
+        self.gpu.comm_destroy()

@@ -1,5 +1,5 @@
 """CPU tests of the product's host side: the C-ABI library loads and exports every symbol
-include/rplgpu.h and include/rplgpu_msg.h declare (no compute calls without a GPU), fails loudly without a device,
+include/rplgpu.h, include/rplgpu_msg.h and include/rplgpu_comm.h declare (no compute calls without a GPU), fails loudly without a device,
 and its host-side arithmetic (LaserScan metadata, src/rplidar_node.cpp:618-627,634-638,
 665-669) matches the oracle bit for bit."""
 import ctypes as C
@@ -24,7 +24,7 @@ def _gpu_present():
 
 
 def test_header_symbols_are_exported():
-    hdr = (ROOT / "include" / "rplgpu.h").read_text() + (ROOT / "include" / "rplgpu_msg.h").read_text()
+    hdr = "".join((ROOT / "include" / f).read_text() for f in ("rplgpu.h", "rplgpu_msg.h", "rplgpu_comm.h"))
     declared = set(re.findall(r"\b(rplgpu_[a-z_0-9]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(abi.ABI_SYMBOLS)

@@ -1,0 +1,204 @@
+"""GPU tests of the exchange behind the C ABI (include/rplgpu_comm.h).
+
+A 1-GPU box can only run world_size 1 (RCCL refuses two ranks on one device), so here:
+  * the device kernels (META block, unpack) against their torch twins in sharding.py — the twins
+    are what the world_size-2 gloo test (tests/test_sharding_gloo.py) runs;
+  * the whole chain through RCCL with one rank, the library loading librccl itself:
+    arena -> META -> all-gather (exchange stream) -> fence -> unpack -> per-sensor transform ->
+    ONE serialised PointCloud2, byte-identical to the chain without the exchange
+    (BASELINE config 5: one GPU per sensor -> fused PointCloud2);
+  * the chunked, double-buffered driver bench.py uses for N > 1 (CloudExchange), result equal to
+    the unchunked launch."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from rplidar_ros2_driver_amd import Params, RplGpu, abi, synth
+from rplidar_ros2_driver_amd import sharding as sh
+from tests import oracle_lib
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+
+pytestmark = pytest.mark.gpu
+FID = "base_link"
+
+
+def _arena(gpu, torch, dev, batch, p, cap):
+    S, n = batch.shape
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(S, n * 8)).to(dev)
+    d_len = torch.full((S,), n, dtype=torch.int32, device=dev)
+    t = dict(arena=torch.zeros(cap, 4, dtype=torch.float32, device=dev),
+             cur=torch.zeros(1, dtype=torch.int64, device=dev),
+             start=torch.zeros(S, dtype=torch.int64, device=dev),
+             npts=torch.zeros(S, dtype=torch.int32, device=dev),
+             st=torch.zeros(S, dtype=torch.int32, device=dev))
+    gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), S, p, t["arena"].data_ptr(), cap,
+                        t["cur"].data_ptr(), t["start"].data_ptr(), t["npts"].data_ptr(),
+                        t["st"].data_ptr())
+    return t
+
+
+def test_meta_and_unpack_kernels_match_their_twins(gpu):
+    import torch
+    dev = torch.device("cuda:0")
+    S, n = 6, 6000
+    batch = synth.make_batch(41, S, n)
+    p = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
+    t = _arena(gpu, torch, dev, batch, p, S * 4096)
+    gpu.synchronize()
+    total = int(t["cur"].item())
+    max_scans = 8
+    mw = abi.cloud_meta_words(max_scans)
+    assert mw == sh.meta_words(max_scans)
+    for slot in (total + 500, total, total // 2):  # roomy, exact, too small (truncation)
+        d_meta = torch.full((mw,), -1, dtype=torch.int32, device=dev)
+        gpu.pack_cloud_meta_dev(t["cur"].data_ptr(), t["start"].data_ptr(), t["npts"].data_ptr(), S,
+                                slot, max_scans, d_meta.data_ptr())
+        gpu.synchronize()
+        want = sh.pack_cloud_meta(total, t["start"].cpu().tolist(), t["npts"].cpu().tolist(), slot,
+                                  max_scans)
+        assert d_meta.cpu().tolist() == want.tolist()
+        # three "ranks" holding the same slot with different META (as if gathered): unpack
+        world = 3
+        metas = [want.clone() for _ in range(world)]
+        metas[1][0] = max(int(metas[1][0]) - 7, 0)  # a rank with a shorter cloud
+        meta_all = torch.stack(metas).to(dev)
+        pts_all = torch.zeros(world, slot, 4, dtype=torch.float32, device=dev)
+        for r in range(world):
+            pts_all[r, : min(slot, total)] = t["arena"][: min(slot, total)] + float(r)
+        d_packed = torch.full((world * slot + 8, 4), -3.0, dtype=torch.float32, device=dev)
+        d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_sa = torch.zeros(world, max_scans, dtype=torch.int64, device=dev)
+        d_na = torch.zeros(world, max_scans, dtype=torch.int32, device=dev)
+        d_stat = torch.zeros(world, dtype=torch.int32, device=dev)
+        gpu.unpack_gathered_dev(pts_all.data_ptr(), slot, meta_all.data_ptr(), mw, world, max_scans,
+                                d_packed.data_ptr(), d_total.data_ptr(), d_sa.data_ptr(),
+                                d_na.data_ptr(), d_stat.data_ptr())
+        gpu.synchronize()
+        w_packed, w_sa, w_na, w_stat = sh.unpack_gathered(pts_all.cpu().view(-1, 4), meta_all.cpu(),
+                                                          slot, world, max_scans)
+        assert int(d_total.item()) == len(w_packed)
+        assert d_packed.cpu()[: len(w_packed)].numpy().tobytes() == w_packed.numpy().tobytes()
+        assert np.all(d_packed.cpu().numpy()[len(w_packed):] == -3.0)
+        assert d_sa.cpu().tolist() == w_sa.tolist() and d_na.cpu().tolist() == w_na.tolist()
+        assert d_stat.cpu().tolist() == w_stat.tolist()
+        assert bool(w_stat.any()) == (slot < total)
+
+
+def test_c5_exchange_transform_fused_message_single_rank_rccl(oracle):
+    """arena -> META -> RCCL all-gather -> unpack -> transform -> fused message, against the same
+    chain without the exchange and against the oracle clouds."""
+    import torch
+    import cdr_oracle as cdr
+    import fusion_oracle as fo
+    dev = torch.device("cuda:0")
+    S, n = 8, 16000
+    batch = np.stack([synth.make_scan(800 + s, 0, n, noise_m=0.01) for s in range(S)])
+    p = Params.defaults(clip_enable=1, range_max=40.0, ror_enable=1, voxel_enable=1)
+    poses = np.stack([fo.planar_pose(0.7 * s - 1.0, 0.35 * s, -0.2 * s, 0.05 * s) for s in range(S)])
+    with RplGpu(device=0, max_samples_per_scan=32768, max_batch=S) as gpu:
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        gpu.set_stream(stream.cuda_stream)
+        gpu.comm_init(0, 1, RplGpu.comm_unique_id())
+        cap = S * 8192
+        t = _arena(gpu, torch, dev, batch, p, cap)
+        mw = abi.cloud_meta_words(S)
+        d_meta = torch.zeros(mw, dtype=torch.int32, device=dev)
+        slot = cap
+        gpu.pack_cloud_meta_dev(t["cur"].data_ptr(), t["start"].data_ptr(), t["npts"].data_ptr(), S,
+                                slot, S, d_meta.data_ptr())
+        d_pts_all = torch.full((slot, 4), -9.0, dtype=torch.float32, device=dev)
+        d_meta_all = torch.zeros(mw, dtype=torch.int32, device=dev)
+        gpu.allgather_clouds_dev(t["arena"].data_ptr(), slot, d_meta.data_ptr(), mw,
+                                 d_pts_all.data_ptr(), d_meta_all.data_ptr())
+        gpu.comm_fence()
+        d_packed = torch.zeros(slot, 4, dtype=torch.float32, device=dev)
+        d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_sa = torch.zeros(S, dtype=torch.int64, device=dev)
+        d_na = torch.zeros(S, dtype=torch.int32, device=dev)
+        d_stat = torch.zeros(1, dtype=torch.int32, device=dev)
+        gpu.unpack_gathered_dev(d_pts_all.data_ptr(), slot, d_meta_all.data_ptr(), mw, 1, S,
+                                d_packed.data_ptr(), d_total.data_ptr(), d_sa.data_ptr(),
+                                d_na.data_ptr(), d_stat.data_ptr())
+        d_pose = torch.from_numpy(poses.reshape(S, 12)).to(dev)
+        gpu.transform_clouds_dev(d_packed.data_ptr(), 0, d_sa.data_ptr(), d_na.data_ptr(), S,
+                                 d_pose.data_ptr())
+        msg_cap = abi.msg_cloud_layout(len(FID), slot).total_len
+        d_msg = torch.zeros(msg_cap, dtype=torch.uint8, device=dev)
+        d_ml = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_ms = torch.zeros(1, dtype=torch.int32, device=dev)
+        gpu.fused_cloud_msg_dev(d_packed.data_ptr(), d_total.data_ptr(), slot, FID, 5, 6,
+                                d_msg.data_ptr(), msg_cap, d_ml.data_ptr(), d_ms.data_ptr())
+        # the same without the exchange
+        gpu.transform_clouds_dev(t["arena"].data_ptr(), 0, t["start"].data_ptr(), t["npts"].data_ptr(),
+                                 S, d_pose.data_ptr())
+        d_msg2 = torch.zeros(msg_cap, dtype=torch.uint8, device=dev)
+        d_ml2 = torch.zeros(1, dtype=torch.int64, device=dev)
+        gpu.fused_cloud_msg_dev(t["arena"].data_ptr(), t["cur"].data_ptr(), cap, FID, 5, 6,
+                                d_msg2.data_ptr(), msg_cap, d_ml2.data_ptr(), d_ms.data_ptr())
+        gpu.synchronize()
+        assert int(t["st"].max()) == 0 and int(d_stat.item()) == 0 and int(d_ms.item()) == 0
+        ml = int(d_ml.item())
+        assert ml == int(d_ml2.item()) > 0
+        assert d_msg.cpu().numpy()[:ml].tobytes() == d_msg2.cpu().numpy()[:ml].tobytes()
+        # ... and against the oracle: every sensor's cloud, transformed, at its place
+        starts, npts = d_sa.cpu().numpy(), d_na.cpu().numpy()
+        fused = d_packed.cpu().numpy()
+        for s in range(S):
+            want, _, _ = oracle.cloud_pipeline(batch[s], oracle_lib.copy_params(p))
+            want = fo.transform_cloud(want, poses[s])
+            got = fused[starts[s]: starts[s] + npts[s]]
+            assert len(got) == len(want)
+            assert np.max(np.abs(got[:, :3].astype(np.float64) - want[:, :3]), initial=0.0) <= 2e-6
+        assert d_msg.cpu().numpy()[:ml].tobytes() == cdr.cloud_msg(FID, 5, 6, fused[: int(d_total.item())])
+        gpu.comm_destroy()
+
+
+def test_chunked_overlapped_exchange_equals_plain_launch():
+    """CloudExchange (bench.py --gpus N): chunks, two arenas, gathers overlapping compute.  With
+    one rank every gathered chunk must hold exactly the clouds a plain launch of that chunk gives."""
+    import os
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        B, n, out_stride, chunks = 96, 8000, 4096, 4
+        batch = synth.make_batch(5, B, n)
+        p = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
+        with RplGpu(device=0, max_samples_per_scan=32768, max_batch=B) as gpu:
+            stream = torch.cuda.Stream(device=dev)
+            torch.cuda.set_stream(stream)
+            gpu.set_stream(stream.cuda_stream)
+            d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+            d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
+            ex = sh.CloudExchange(gpu, dist, dev, 1, 0, B, n, out_stride, chunks)
+            for _ in range(3):
+                ex.step(d_nodes, d_len, p)
+            gpu.synchronize()
+            torch.cuda.synchronize()
+            Bc = ex.Bc
+            for c in range(chunks):
+                meta = ex.recv_meta[c, 0].cpu()
+                pk, st, npx, status = sh.unpack_gathered(ex.recv_pts[c, 0].cpu().view(-1, 4), meta, ex.slot,
+                                                         1, Bc)
+                assert int(status.sum()) == 0
+                t = _arena(gpu, torch, dev, batch[c * Bc: (c + 1) * Bc], p, Bc * out_stride)
+                gpu.synchronize()
+                ref_a, ref_s, ref_n = t["arena"].cpu().numpy(), t["start"].cpu().numpy(), t["npts"].cpu().numpy()
+                for j in range(Bc):
+                    assert int(npx[0, j]) == int(ref_n[j])
+                    a = pk[int(st[0, j]): int(st[0, j]) + int(npx[0, j])].numpy()
+                    assert a.tobytes() == ref_a[ref_s[j]: ref_s[j] + ref_n[j]].tobytes()
+            ex.exchange_only()
+            gpu.synchronize()
+            assert ex.last_bytes() == chunks * ex.slot * 16
+            ex.close()
+    finally:
+        dist.destroy_process_group()

@@ -122,3 +122,89 @@ def test_allgather_clouds_world2_gloo():
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res), res
+
+
+# ---- BASELINE config 5 across ranks: one sensor per rank -> gather -> transform -> fused message
+def _c5_worker(rank, world, port, per_rank, n, q):
+    """The layout of include/rplgpu_comm.h end to end on CPU: every rank voxelises ITS sensors
+    (oracle clouds stand in for the GPU kernels here), lays them out as rplgpu_cloud_arena_dev
+    does (completion order != scan order), builds the META block, all-gathers fixed-size slots
+    and META blocks (gloo), unpacks them into one cloud + per-scan tables, applies the per-sensor
+    poses and serialises ONE PointCloud2 — which must equal, byte for byte, what a single process
+    holding all sensors produces."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, str(ROOT / "oracle"))
+        import cdr_oracle
+        import fusion_oracle as fo
+        from rplidar_ros2_driver_amd import sharding as sh
+        from tests import oracle_lib
+        orc = oracle_lib.load_oracle()
+        p = oracle_lib.params(clip_enable=1, range_max=40.0, voxel_enable=1)
+        S = world * per_rank
+        poses = np.stack([fo.planar_pose(0.7 * s - 1.0, 0.35 * s, -0.2 * s, 0.05 * s) for s in range(S)])
+
+        def cloud_of(sensor):
+            return orc.cloud_pipeline(synth.make_scan(900 + sensor, 0, n, noise_m=0.01), p)[0]
+
+        # this rank's arena: its sensors in REVERSED completion order, a slot with head room
+        mine = [cloud_of(rank * per_rank + j) for j in range(per_rank)]
+        counts = [len(c) for c in mine]
+        slot = max(8000, sum(counts) + 100)
+        t = torch.tensor([slot], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        slot = int(t.item())
+        arena = torch.full((slot, 4), -7.0)
+        starts, at = [0] * per_rank, 0
+        for j in reversed(range(per_rank)):
+            starts[j] = at
+            arena[at: at + counts[j]] = torch.from_numpy(mine[j])
+            at += counts[j]
+        meta = sh.pack_cloud_meta(at, starts, counts, slot, per_rank)
+        pts_all = torch.empty(world * slot * 4)
+        dist.all_gather_into_tensor(pts_all, arena.view(-1))
+        meta_all = torch.empty(world * sh.meta_words(per_rank), dtype=torch.int32)
+        dist.all_gather_into_tensor(meta_all, meta)
+        packed, st_all, np_all, status = sh.unpack_gathered(pts_all.view(-1, 4), meta_all, slot, world,
+                                                            per_rank)
+        ok = int(status.sum()) == 0 and len(packed) == int(np_all.sum())
+        # per-sensor transform into the common frame, then one serialised PointCloud2
+        fused = packed.numpy().copy()
+        for r in range(world):
+            for j in range(per_rank):
+                a, k = int(st_all[r, j]), int(np_all[r, j])
+                fused[a: a + k] = fo.transform_cloud(fused[a: a + k], poses[r * per_rank + j])
+        msg = cdr_oracle.cloud_msg("base_link", 12, 34, fused)
+        # single process: all sensors, arena order = rank-major, each rank's reversed order
+        ref_parts = []
+        for r in range(world):
+            for j in reversed(range(per_rank)):
+                s = r * per_rank + j
+                ref_parts.append(fo.transform_cloud(cloud_of(s), poses[s]))
+        ref_msg = cdr_oracle.cloud_msg("base_link", 12, 34, np.concatenate(ref_parts))
+        ok = ok and msg == ref_msg
+        # a slot that is too small truncates and flags instead of overrunning
+        small = max(1, at // 2)
+        meta_s = sh.pack_cloud_meta(at, starts, counts, small, per_rank)
+        ok = ok and int(meta_s[3]) == 1 and int(meta_s[0]) == small
+        q.put((rank, bool(ok), len(packed)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c5_one_sensor_group_per_rank_fused_message_world2_gloo():
+    world, per_rank, n = 2, 2, 1200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c5_worker, args=(r, world, port, per_rank, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert res[0][2] == res[1][2] > 0
