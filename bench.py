@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--samples", type=int, default=32000, help="samples per scan")
     ap.add_argument("--out-stride", type=int, default=8192, help="cloud slots per scan")
     ap.add_argument("--seed", type=int, default=2026)
-    ap.add_argument("--chunks", type=int, default=4,
+    ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1: pieces a rank's block is cut into (gather of piece k overlaps "
                          "compute of piece k + 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
@@ -324,6 +324,10 @@ def single_scan_table(gpu, params_voxel, seed, cpu_seconds):
 
 def main():
     args = parse_args()
+    # stdout carries ONE JSON line: everything the libraries print there (RCCL's version banner
+    # ...) is sent to stderr while the bench runs
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -636,13 +640,24 @@ def main():
                 B_total * n / ((ms_per_step + h2d_ms) * 1e-3) / 1e6, 1),
         }
         line.update(extra)
-        print(json.dumps(line), flush=True)
+        result_line = json.dumps(line)
+    else:
+        result_line = None
 
     if exch is not None:
         exch.close()
     gpu.close()
     if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:  # the C libraries' own stdio buffers (RCCL's banner sits there until exit)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    os.dup2(real_stdout, 1)
+    if result_line is not None:
+        os.write(1, (result_line + "\n").encode())
 
 
 if __name__ == "__main__":

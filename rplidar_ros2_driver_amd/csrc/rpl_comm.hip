@@ -81,6 +81,16 @@ __global__ __launch_bounds__(256) void k_unpack_gathered(
     dst[i] = src[i];
 }
 
+// completion flag of a single-scan call (rplgpu_api.hip wait_scan): everything queued before this
+// kernel on the stream is complete when it runs; the store is a system-scope release
+__global__ void k_signal(uint32_t *flag, uint32_t seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_signal(hipStream_t s, uint32_t *flag, uint32_t seq) {
+  hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, s, flag, seq);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_meta(hipStream_t s, const unsigned long long *cursor,
                             const unsigned long long *scan_start, const uint32_t *n_points,
                             uint32_t B, unsigned long long slot_points, uint32_t max_scans,

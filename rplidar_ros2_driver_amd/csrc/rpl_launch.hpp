@@ -61,6 +61,7 @@ hipError_t launch_laserscan_to_cloud(hipStream_t s, const float *ranges, const f
                                      uint32_t *n_points, uint32_t *status);
 
 // multi-GPU exchange, device side (rpl_comm.hip)
+hipError_t launch_signal(hipStream_t s, uint32_t *flag, uint32_t seq);
 hipError_t launch_pack_meta(hipStream_t s, const unsigned long long *cursor,
                             const unsigned long long *scan_start, const uint32_t *n_points,
                             uint32_t B, unsigned long long slot_points, uint32_t max_scans,

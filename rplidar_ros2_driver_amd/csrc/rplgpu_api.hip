@@ -33,6 +33,13 @@ struct rplgpu_ctx {
   double *d_rcp = nullptr;
   // single-scan staging
   unsigned char *h_pin = nullptr;  // pinned: nodes | out (16 B / sample) | 2 x u32
+  unsigned char *d_pin = nullptr;  // the same memory as the device sees it (zero-copy single scans)
+  bool zero_copy = true;           // single-scan entry points: kernels read / write h_pin directly
+  bool spin_sync = true;           // ... and complete through a flag in pinned memory (wait_scan)
+  size_t flag_off = 0;             // offset of that flag in h_pin
+  uint32_t scan_seq = 0;
+  struct Pinned { unsigned char *host, *dev; size_t bytes; };
+  std::vector<Pinned> pinned;      // buffers handed out by rplgpu_host_alloc (device-addressable)
   unsigned char *d_nodes = nullptr, *d_out = nullptr;
   uint32_t *d_rormask = nullptr;  // E5 keep bits, max_b scans x kMaskStride words
   uint32_t *d_need_sort = nullptr;  // ascend: scans the sorting kernel must redo (B words)
@@ -330,6 +337,49 @@ int32_t upload_scan(rplgpu_ctx *c, const rplgpu_node_t *nodes, size_t n, const u
   return RPLGPU_OK;
 }
 
+// Zero-copy staging of one scan: the nodes and their count word are placed in the pinned buffer
+// (a CPU copy of n * 8 bytes) and the kernels address that buffer directly.
+// End of a zero-copy single-scan call: wait until the kernels queued on the stream are done and
+// their writes to the pinned staging are visible.  hipStreamSynchronize costs ~15 us of wake-up
+// latency on this stack; instead a one-lane kernel queued behind the work stores a sequence
+// number into pinned memory (system-scope release) and the calling thread — the node's scan
+// thread, which has nothing else to do until the scan is converted — polls it.  Falls back to
+// the runtime's synchronisation after ~2 ms (that is also where errors surface).
+int32_t wait_scan(rplgpu_ctx *c) {
+  if (!c->spin_sync) {
+    RPL_HIP(c, hipStreamSynchronize(c->stream));
+    return RPLGPU_OK;
+  }
+  volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(c->h_pin + c->flag_off);
+  const uint32_t seq = ++c->scan_seq;
+  RPL_HIP(c, rpl::launch_signal(c->stream, reinterpret_cast<uint32_t *>(c->d_pin + c->flag_off), seq));
+  for (uint32_t spins = 0; spins < 400000u; ++spins) {
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return RPLGPU_OK;
+    __builtin_ia32_pause();
+  }
+  RPL_HIP(c, hipStreamSynchronize(c->stream));
+  return RPLGPU_OK;
+}
+
+struct ScanStage {
+  const rplgpu_node_t *d_nodes;  // device view of the staged nodes
+  const uint32_t *d_n;           // ... of the count word (status word right behind it)
+  unsigned char *d_out;          // ... of the result area (16 B per sample + tail)
+  unsigned char *h_out;          // host view of the result area
+};
+inline ScanStage stage_scan(rplgpu_ctx *c, const rplgpu_node_t *nodes, size_t n) {
+  std::memcpy(c->h_pin, nodes, n * 8);
+  const uint32_t words[2] = {(uint32_t)n, 0u};
+  std::memcpy(c->h_pin + n * 8, words, 8);
+  ScanStage s;
+  s.d_nodes = reinterpret_cast<const rplgpu_node_t *>(c->d_pin);
+  s.d_n = reinterpret_cast<const uint32_t *>(c->d_pin + n * 8);
+  const size_t out_off = (size_t)c->max_n * 8 + kTail;
+  s.d_out = c->d_pin + out_off;
+  s.h_out = c->h_pin + out_off;
+  return s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -425,7 +475,8 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   const size_t n = c->max_n;
   // single-scan staging: the length word travels right behind the nodes and the result words
   // right behind the results, so that a call is one copy in and one copy out
-  if (hipHostMalloc((void **)&c->h_pin, n * 8 + n * 16 + 2 * kTail, hipHostMallocDefault) != hipSuccess ||
+  c->flag_off = n * 8 + n * 16 + 2 * kTail;  // (64-byte aligned: n * 24 + 128)
+  if (hipHostMalloc((void **)&c->h_pin, n * 8 + n * 16 + 3 * kTail, hipHostMallocDefault) != hipSuccess ||
       hipMalloc((void **)&c->d_nodes, n * 8 + kTail) != hipSuccess ||
       hipMalloc((void **)&c->d_out, n * 16 + kTail) != hipSuccess ||
       hipMalloc((void **)&c->d_small, 128) != hipSuccess ||
@@ -444,6 +495,15 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
     c->err = "record store allocation failed";
     return fail(RPLGPU_ERR_HIP);
   }
+  // Single scans go through host memory the device can address: the kernels read the nodes from
+  // the pinned staging and write their results into it over PCIe — one launch and one
+  // synchronisation per call instead of DMA in + kernel + DMA out (RPLGPU_ZERO_COPY=0: the DMA
+  // path of round 1, kept for comparison).
+  if (hipHostGetDevicePointer((void **)&c->d_pin, c->h_pin, 0) != hipSuccess) c->d_pin = nullptr;
+  if (const char *e = std::getenv("RPLGPU_ZERO_COPY")) c->zero_copy = std::atoi(e) != 0;
+  if (!c->d_pin) c->zero_copy = false;
+  if (const char *e = std::getenv("RPLGPU_SPIN_SYNC")) c->spin_sync = std::atoi(e) != 0;
+  std::memset(c->h_pin + c->flag_off, 0, kTail);
   if (hipMemset(c->d_small, 0, 128) != hipSuccess) {  // incl. the voxel kernel's scan queue
     c->err = "staging clear failed";
     return fail(RPLGPU_ERR_HIP);
@@ -623,6 +683,19 @@ int32_t rplgpu_ascend(rplgpu_handle_t h, rplgpu_node_t *nodes, size_t n, uint32_
     return RPLGPU_OK;
   }
   RPL_HIP(h, hipSetDevice(h->device));
+  if (h->zero_copy) {  // in place in the pinned staging: one launch pair, one synchronisation
+    const ScanStage st = stage_scan(h, nodes, n);
+    uint32_t *d_status = const_cast<uint32_t *>(st.d_n) + 1;
+    RPL_HIP(h, rpl::launch_ascend(h->stream, const_cast<rplgpu_node_t *>(st.d_nodes), (uint32_t)n,
+                                  st.d_n, 1, d_status, h->d_small + 20));
+    if (int32_t wrc = wait_scan(h)) return wrc;
+    uint32_t stw;
+    std::memcpy(&stw, h->h_pin + n * 8 + 4, 4);
+    const bool all_invalid = (stw & RPLGPU_SCAN_ALL_INVALID) != 0;
+    if (!all_invalid) std::memcpy(nodes, h->h_pin, n * 8);
+    if (sl_result) *sl_result = all_invalid ? 0x80008001u : 0u;
+    return RPLGPU_OK;
+  }
   const uint32_t *d_n;
   if (int32_t rc = upload_scan(h, nodes, n, &d_n)) return rc;
   uint32_t *d_status = const_cast<uint32_t *>(d_n) + 1;  // travels back with the nodes
@@ -646,6 +719,23 @@ int32_t rplgpu_scan_to_laserscan(rplgpu_handle_t h, const rplgpu_node_t *nodes, 
   std::memset(meta, 0, sizeof(*meta));
   if (n == 0) return RPLGPU_OK;  // :561-563
   RPL_HIP(h, hipSetDevice(h->device));
+  if (h->zero_copy) {
+    const ScanStage st = stage_scan(h, nodes, n);
+    float *d_r = reinterpret_cast<float *>(st.d_out);
+    float *d_i = d_r + n;
+    uint32_t *d_count = reinterpret_cast<uint32_t *>(d_i + n);
+    if (int32_t lrc = run_laserscan(h, st.d_nodes, (uint32_t)n, st.d_n, 1, *p, d_r, d_i, d_count))
+      return lrc;
+    if (int32_t wrc = wait_scan(h)) return wrc;
+    uint32_t count;
+    std::memcpy(&count, st.h_out + n * 8, 4);
+    rplgpu_fill_meta(p, count, scan_duration, meta);
+    if (count) {
+      std::memcpy(ranges, st.h_out, (size_t)count * 4);
+      std::memcpy(intensities, st.h_out + n * 4, (size_t)count * 4);
+    }
+    return RPLGPU_OK;
+  }
   unsigned char *h_out = stage_out(h);
   const uint32_t *d_n;
   if (int32_t rc = upload_scan(h, nodes, n, &d_n)) return rc;
@@ -676,6 +766,27 @@ int32_t rplgpu_scan_to_cloud(rplgpu_handle_t h, const rplgpu_node_t *nodes, size
   if (n == 0) return RPLGPU_OK;
   unsigned char *h_out = stage_out(h);
   RPL_HIP(h, hipSetDevice(h->device));
+  if (h->zero_copy && !p->ror_enable) {  // (E5 reads a scan many times: it wants it in HBM)
+    const ScanStage st = stage_scan(h, nodes, n);
+    uint32_t *d_words = reinterpret_cast<uint32_t *>(st.d_out + n * 16);  // n_points, status
+    // (the batch entry point's pointer check asks the runtime about each pointer: skip it for
+    // the handle's own staging)
+    const bool chk = h->check_ptrs;
+    h->check_ptrs = false;
+    const int32_t rc = rplgpu_cloud_batch_dev(h, st.d_nodes, (uint32_t)n, st.d_n, 1, p,
+                                              reinterpret_cast<float *>(st.d_out), (uint32_t)n,
+                                              d_words, d_words + 1);
+    h->check_ptrs = chk;
+    if (rc) return rc;
+    if (int32_t wrc = wait_scan(h)) return wrc;
+    uint32_t w[2];
+    std::memcpy(w, st.h_out + n * 16, 8);
+    *n_points = w[0];
+    if (status) *status = w[1];
+    std::memcpy(xyzi, st.h_out, (size_t)w[0] * 16);
+    return (w[1] & (RPLGPU_SCAN_CELL_RANGE | RPLGPU_SCAN_TABLE_FULL)) ? RPLGPU_ERR_SCAN_OVERFLOW
+                                                                     : RPLGPU_OK;
+  }
   const uint32_t *d_n;
   if (int32_t urc = upload_scan(h, nodes, n, &d_n)) return urc;
   uint32_t *d_words = reinterpret_cast<uint32_t *>(h->d_out + n * 16);  // n_points, status
@@ -985,6 +1096,9 @@ int32_t rplgpu_host_alloc(rplgpu_handle_t h, size_t bytes, void **out) {
   *out = nullptr;
   RPL_HIP(h, hipSetDevice(h->device));
   RPL_HIP(h, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  void *dev = nullptr;
+  if (hipHostGetDevicePointer(&dev, *out, 0) == hipSuccess && dev)
+    h->pinned.push_back({static_cast<unsigned char *>(*out), static_cast<unsigned char *>(dev), bytes});
   return RPLGPU_OK;
 }
 
@@ -992,8 +1106,24 @@ int32_t rplgpu_host_free(rplgpu_handle_t h, void *p) {
   if (!h) return RPLGPU_ERR_INVALID_ARG;
   if (!p) return RPLGPU_OK;
   RPL_HIP(h, hipSetDevice(h->device));
+  for (size_t i = 0; i < h->pinned.size(); ++i)
+    if (h->pinned[i].host == p) {
+      h->pinned.erase(h->pinned.begin() + (long)i);
+      break;
+    }
   RPL_HIP(h, hipHostFree(p));
   return RPLGPU_OK;
+}
+
+static int32_t make_prefix(rplgpu_handle_t h, const char *frame_id, bool cloud,
+                           const rplgpu_params_t *p, rplmsg::Prefix *P);
+
+// device view of [p, p + bytes) when it lies inside a buffer from rplgpu_host_alloc, else null
+static unsigned char *pinned_device_view(rplgpu_handle_t h, const void *p, size_t bytes) {
+  const unsigned char *q = static_cast<const unsigned char *>(p);
+  for (const auto &b : h->pinned)
+    if (q >= b.host && q + bytes <= b.host + b.bytes) return b.dev + (q - b.host);
+  return nullptr;
 }
 
 int32_t rplgpu_scan_to_laserscan_msg(rplgpu_handle_t h, const rplgpu_node_t *nodes, size_t n,
@@ -1013,6 +1143,40 @@ int32_t rplgpu_scan_to_laserscan_msg(rplgpu_handle_t h, const rplgpu_node_t *nod
     return RPLGPU_ERR_CAPACITY;
   }
   RPL_HIP(h, hipSetDevice(h->device));
+  if (unsigned char *d_msg = h->zero_copy ? pinned_device_view(h, msg, cap) : nullptr) {
+    // The message buffer is device-addressable (rplgpu_host_alloc): the kernels read the staged
+    // nodes and WRITE THE SERIALISED MESSAGE IN PLACE — prefix, scalars, both arrays — over
+    // PCIe: two launches, one synchronisation, no DMA, no host pass over the arrays.
+    rplmsg::Prefix P;
+    if (int32_t rc = make_prefix(h, frame_id, false, p, &P)) return rc;
+    const ScanStage st = stage_scan(h, nodes, n);
+    // per-scan inputs / outputs of the message kernel travel in the staging tail:
+    // [count][status] after the nodes (stage_scan), then stamp (8 B), duration (8 B), msg_len, status
+    unsigned char *tail_h = h->h_pin + n * 8 + 16, *tail_d = h->d_pin + n * 8 + 16;
+    std::memcpy(tail_h, &stamp, 8);
+    std::memcpy(tail_h + 8, &scan_duration, 8);
+    const uint32_t zeros[2] = {0u, 0u};
+    std::memcpy(tail_h + 16, zeros, 8);
+    float *d_r = reinterpret_cast<float *>(h->d_out);  // the arrays themselves stay in HBM
+    float *d_i = d_r + n;
+    uint32_t *d_count = reinterpret_cast<uint32_t *>(st.d_out);  // host-visible
+    if (int32_t lrc = run_laserscan(h, st.d_nodes, (uint32_t)n, st.d_n, 1, *p, d_r, d_i, d_count))
+      return lrc;
+    const uint32_t stride = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFCu) & ~3u;
+    RPL_HIP(h, rpl::launch_msg_laserscan(h->stream, d_r, d_i, (uint32_t)n, d_count, 1,
+                                         p->scan_processing != 0,
+                                         reinterpret_cast<const rplgpu_stamp_t *>(tail_d),
+                                         reinterpret_cast<const double *>(tail_d + 8), P, d_msg, stride,
+                                         reinterpret_cast<uint32_t *>(tail_d + 16),
+                                         reinterpret_cast<uint32_t *>(tail_d + 20)));
+    if (int32_t wrc = wait_scan(h)) return wrc;
+    uint32_t count, len;
+    std::memcpy(&count, st.h_out, 4);
+    std::memcpy(&len, tail_h + 16, 4);
+    rplgpu_fill_meta(p, count, scan_duration, meta);
+    *msg_len = count ? len : 0;
+    return RPLGPU_OK;
+  }
   uint32_t *h_small = reinterpret_cast<uint32_t *>(stage_out(h));  // pinned scratch word
   const uint32_t *d_n;
   if (int32_t rc = upload_scan(h, nodes, n, &d_n)) return rc;

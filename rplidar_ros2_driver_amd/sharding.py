@@ -173,32 +173,31 @@ def unpack_gathered(points_all: torch.Tensor, meta_all: torch.Tensor, slot_point
 
 class CloudExchange:
     """bench.py's N > 1 step through the library's own exchange: the rank's block of scans is cut
-    into `chunks`; chunk c is voxelised into arena (c & 1) on the handle's main stream and its
-    cloud all-gathered (RCCL, exchange stream) while chunk c + 1 is being voxelised.  Slot sizes
-    are fixed after one calibration pass (max cells per chunk over all ranks + 15 % head room), so
-    a timed step has no host synchronisation: counts travel in the META blocks on the device."""
+    into `chunks`; chunk c is voxelised STRAIGHT INTO this rank's slot of chunk c's receive buffer
+    (the arena is the slot: RCCL's in-place all-gather then moves no local bytes at all) on the
+    handle's main stream and all-gathered on the exchange stream while chunk c + 1 is being
+    voxelised.  Every chunk has its own receive buffer, so nothing is reused inside a step and the
+    step needs no fence but the last.  Slot sizes are fixed after one calibration pass (max cells
+    per chunk over all ranks + 15 % head room; a cloud that outgrows its slot is cut and flagged,
+    never overrun), so a timed step has no host synchronisation: counts travel in the META blocks
+    on the device."""
 
     def __init__(self, gpu, dist_mod, dev, world, rank, B, n, out_stride, chunks):
         self.gpu, self.dist, self.dev, self.world, self.rank = gpu, dist_mod, dev, world, rank
-        self.B, self.n = B, n
+        self.B, self.n, self.out_stride = B, n, out_stride
         self.chunks = max(1, min(chunks, max(B, 1)))
         self.Bc = (B + self.chunks - 1) // self.chunks
         self.mw = meta_words(self.Bc)
         # communicator: rank 0's unique id travels through torch.distributed
-        import numpy as np
         uid = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
             uid.copy_(torch.from_numpy(gpu.comm_unique_id()))
         self.dist.broadcast(uid, src=0)
         gpu.comm_init(rank, world, uid.cpu().numpy())
-        cap = self.Bc * out_stride
-        self.cap = cap
-        self.arena = [torch.empty(cap, 4, dtype=torch.float32, device=dev) for _ in range(2)]
-        self.cursor = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
-        self.start = [torch.zeros(self.Bc, dtype=torch.int64, device=dev) for _ in range(2)]
-        self.npts = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(2)]
-        self.stat = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(2)]
-        self.meta = [torch.zeros(self.mw, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.cursor = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.chunks)]
+        self.start = [torch.zeros(self.Bc, dtype=torch.int64, device=dev) for _ in range(self.chunks)]
+        self.npts = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(self.chunks)]
+        self.stat = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(self.chunks)]
         self.slot = None
         self.recv_pts = None
         self.recv_meta = torch.zeros(self.chunks, world, self.mw, dtype=torch.int32, device=dev)
@@ -208,51 +207,56 @@ class CloudExchange:
         return lo, min(self.Bc, self.B - lo)
 
     def _calibrate(self, d_nodes, d_len, params):
+        cap = self.Bc * self.out_stride
+        tmp = torch.empty(cap, 4, dtype=torch.float32, device=self.dev)
         worst = 0
         for c in range(self.chunks):
             lo, nb = self._chunk(c)
             if nb <= 0:
                 continue
             self.gpu.cloud_arena_dev(d_nodes.data_ptr() + lo * self.n * 8, self.n, d_len.data_ptr() + lo * 4,
-                                     nb, params, self.arena[0].data_ptr(), self.cap,
-                                     self.cursor[0].data_ptr(), self.start[0].data_ptr(),
-                                     self.npts[0].data_ptr(), self.stat[0].data_ptr())
+                                     nb, params, tmp.data_ptr(), cap, self.cursor[0].data_ptr(),
+                                     self.start[0].data_ptr(), self.npts[0].data_ptr(),
+                                     self.stat[0].data_ptr())
             self.gpu.synchronize()
             worst = max(worst, int(self.cursor[0].item()))
+        del tmp
         t = torch.tensor([worst], dtype=torch.int64, device=self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        self.slot = min(self.cap, int(int(t.item()) * 1.15) + 1024)
+        self.slot = min(cap, int(int(t.item()) * 1.15) + 1024)
         self.recv_pts = torch.empty(self.chunks, self.world, self.slot, 4, dtype=torch.float32,
                                     device=self.dev)
 
     def step(self, d_nodes, d_len, params):
         if self.slot is None:
             self._calibrate(d_nodes, d_len, params)
-        g = self.gpu
+        g, r = self.gpu, self.rank
         for c in range(self.chunks):
             lo, nb = self._chunk(c)
             if nb <= 0:
                 continue
-            k = c & 1
-            g.comm_fence(1)  # arena k was last read by the gather of chunk c - 2
+            mine = self.recv_pts[c, r]      # this rank's slot of chunk c: the arena
+            meta = self.recv_meta[c, r]
             g.cloud_arena_dev(d_nodes.data_ptr() + lo * self.n * 8, self.n, d_len.data_ptr() + lo * 4, nb,
-                              params, self.arena[k].data_ptr(), self.cap, self.cursor[k].data_ptr(),
-                              self.start[k].data_ptr(), self.npts[k].data_ptr(), self.stat[k].data_ptr())
-            g.pack_cloud_meta_dev(self.cursor[k].data_ptr(), self.start[k].data_ptr(),
-                                  self.npts[k].data_ptr(), nb, self.slot, self.Bc, self.meta[k].data_ptr())
-            g.allgather_clouds_dev(self.arena[k].data_ptr(), self.slot, self.meta[k].data_ptr(), self.mw,
+                              params, mine.data_ptr(), self.slot, self.cursor[c].data_ptr(),
+                              self.start[c].data_ptr(), self.npts[c].data_ptr(), self.stat[c].data_ptr())
+            g.pack_cloud_meta_dev(self.cursor[c].data_ptr(), self.start[c].data_ptr(),
+                                  self.npts[c].data_ptr(), nb, self.slot, self.Bc, meta.data_ptr())
+            g.allgather_clouds_dev(mine.data_ptr(), self.slot, meta.data_ptr(), self.mw,
                                    self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
         g.comm_fence(0)
 
     def exchange_only(self):
+        r = self.rank
         for c in range(self.chunks):
-            k = c & 1
-            self.gpu.allgather_clouds_dev(self.arena[k].data_ptr(), self.slot, self.meta[k].data_ptr(),
-                                          self.mw, self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
+            self.gpu.allgather_clouds_dev(self.recv_pts[c, r].data_ptr(), self.slot,
+                                          self.recv_meta[c, r].data_ptr(), self.mw,
+                                          self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
         self.gpu.comm_fence(0)
 
     def last_bytes(self):
-        return int(self.chunks * self.world * (self.slot or 0) * 16)
+        """bytes this rank RECEIVES from its peers per step"""
+        return int(self.chunks * (self.world - 1) * (self.slot or 0) * 16)
 
     def close(self):
         self.gpu.comm_destroy()

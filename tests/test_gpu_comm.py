@@ -198,7 +198,7 @@ def test_chunked_overlapped_exchange_equals_plain_launch():
                     assert a.tobytes() == ref_a[ref_s[j]: ref_s[j] + ref_n[j]].tobytes()
             ex.exchange_only()
             gpu.synchronize()
-            assert ex.last_bytes() == chunks * ex.slot * 16
+            assert ex.last_bytes() == 0  # one rank: nothing crosses a link (in-place slots)
             ex.close()
     finally:
         dist.destroy_process_group()
