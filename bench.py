@@ -569,7 +569,31 @@ def main():
                              voxel_leaf=0.05, ror_enable=1, ror_radius=0.10, ror_min_neighbors=2)
         c5 = regime(gpu, dev, stream, "c5", c5b, p5, big_arena, d_cursor, d_start, d_np, d_st, vreps)
         c5["workload"] = f"8 sensors x {B // 8} frames x {n} samples, 1 cm range noise, ROR(0.10 m, >= 2) + voxel 5 cm"
-        del c5b, big_arena
+        # ... and as ONE grid per time step (E8): per-sensor motion de-skew + planar pose, the 8
+        # sensors of a frame voxelised together (rplgpu_cloud_fused_voxel_dev, group = 8)
+        rng = np.random.default_rng(args.seed)
+        motion = np.stack([[rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.3, 0.3), 0.1 / n]
+                           for _ in range(B)]).astype(np.float32)
+        ang = rng.uniform(-3, 3, B)
+        pose2d = np.stack([np.cos(ang), -np.sin(ang), rng.uniform(-2, 2, B), np.sin(ang), np.cos(ang),
+                           rng.uniform(-2, 2, B)], 1).astype(np.float32)
+        d_c5 = torch.from_numpy(c5b.view(np.uint8).reshape(B, n * 8)).to(dev)
+        d_mo, d_po = torch.from_numpy(motion).to(dev), torch.from_numpy(pose2d).to(dev)
+        cap5 = big_arena.shape[0]
+
+        def fused():
+            gpu.cloud_fused_voxel_dev(d_c5.data_ptr(), n, d_len.data_ptr(), B, 8, p5, d_mo.data_ptr(),
+                                      d_po.data_ptr(), big_arena.data_ptr(), cap5, d_cursor.data_ptr(),
+                                      d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+
+        ms = timed(fused, stream, vreps, sync)
+        cells = int(d_cursor.item())
+        c5["fused_grid"] = {"ms": round(ms, 4), "gpts_s": round(B * n / ms / 1e6, 1),
+                            "frac": round((8 * B * n + 16 * cells) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "cells": cells, "status_bits": int(d_st[: B // 8].max().item()),
+                            "workload": "the same scans, de-skewed + posed, one voxel grid per time step "
+                                        "(8 sensors), E5 mask on"}
+        del c5b, big_arena, d_c5
 
     if not args.no_decode and rank == 0:
         extra["decode"] = decode_stage(gpu, dev, stream, args.cpu_seconds)

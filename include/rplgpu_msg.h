@@ -178,6 +178,29 @@ int32_t rplgpu_cloud_deskew_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_
                                       const rplgpu_params_t *p, const float *d_motion,
                                       float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,
                                       uint32_t *d_status);
+/* E8 — ONE voxel grid for a GROUP of scans (row 4: de-skew in front of the voxel grid, and the
+ * cross-sensor voxel grid).  Scans [g*group, (g+1)*group) of the batch — e.g. the 8 sensors of one
+ * time step, or a single scan (group = 1) — are voxelised together: every kept sample (E1 clip,
+ * E5 mask when ror_enable) gives (x, y) by E2; then, in float32, one rounding per operation:
+ *   E6 de-skew with the scan's (vx, vy, wz, time_increment) from d_motion (NULL: none) —
+ *     tau = float(i) * time_increment, formulas of rplgpu_cloud_deskew_batch_dev above;
+ *   the scan's planar pose from d_pose2d (NULL: identity), 6 floats per scan
+ *     (r00 r01 tx r10 r11 ty):  x'' = (r00*x' + r01*y') + tx;  y'' = (r10*x' + r11*y') + ty;
+ * and the E4 voxel grid (leaf p->voxel_leaf) runs over ALL points of the group: one output point
+ * per occupied cell = centroid (fp64 sum / count, rounded to float), mean intensity, z = 0, cells
+ * in (iy, ix) order.  Outputs as rplgpu_cloud_arena_dev, indexed by GROUP: d_group_start[g],
+ * d_n_points[g], d_status[g] for g < ceil(B / group); *d_cursor = all points.
+ * The raw scans are streamed once; a group's run records beyond the on-chip queue go through the
+ * handle's record store (L2).  The reference publishes time_increment / scan_time
+ * (src/rplidar_node.cpp:627,637-638) and an identity transform (:183-197); nothing there
+ * consumes them — this is the consumer. */
+int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
+                                     uint32_t n_stride, const uint32_t *d_n_per_scan, uint32_t B,
+                                     uint32_t group, const rplgpu_params_t *p,
+                                     const float *d_motion, const float *d_pose2d, float *d_arena,
+                                     uint64_t arena_capacity, uint64_t *d_cursor,
+                                     uint64_t *d_group_start, uint32_t *d_n_points,
+                                     uint32_t *d_status);
 /* The whole arena as ONE serialised PointCloud2 (the fused cloud of BASELINE config 5):
  * width = min(*d_total_points, arena_capacity) with d_total_points the arena cursor of
  * rplgpu_cloud_arena_dev — no host round trip.  *d_msg_len (device) = serialised size, or 0 +

@@ -78,6 +78,7 @@ ABI_SYMBOLS = [
     "rplgpu_cloud_deskew_batch_dev",
     "rplgpu_laserscan_to_cloud_batch_dev",
     "rplgpu_laserscan_to_cloud",
+    "rplgpu_cloud_fused_voxel_dev",
     # include/rplgpu_comm.h
     "rplgpu_comm_unique_id",
     "rplgpu_comm_init",
@@ -247,6 +248,8 @@ def load_library() -> C.CDLL:
                                                         vp, u32, vp, vp]
     lib.rplgpu_laserscan_to_cloud.argtypes = [vp, vp, vp, u32, C.POINTER(Params), vp,
                                               C.POINTER(u32)]
+    lib.rplgpu_cloud_fused_voxel_dev.argtypes = [vp, vp, u32, vp, u32, u32, C.POINTER(Params), vp, vp, vp,
+                                                 u64, vp, vp, vp, vp]
     lib.rplgpu_comm_unique_id.argtypes = [vp]
     lib.rplgpu_comm_init.argtypes = [vp, i32, i32, vp]
     lib.rplgpu_comm_destroy.argtypes = [vp]
@@ -475,6 +478,15 @@ class RplGpu:
             self._h, ranges.ctypes.data, intens.ctypes.data, count, C.byref(params),
             xyzi.ctypes.data, C.byref(npts)))
         return xyzi[: npts.value]
+
+    def cloud_fused_voxel_dev(self, d_nodes: int, n_stride: int, d_n_per_scan: int, B: int, group: int,
+                              params: Params, d_motion: int, d_pose2d: int, d_arena: int,
+                              arena_capacity: int, d_cursor: int, d_group_start: int, d_n_points: int,
+                              d_status: int = 0):
+        """E8: one voxel grid per group of `group` consecutive scans (de-skew + planar pose)."""
+        self._check(self._lib.rplgpu_cloud_fused_voxel_dev(
+            self._h, d_nodes, n_stride, d_n_per_scan, B, group, C.byref(params), d_motion, d_pose2d,
+            d_arena, arena_capacity, d_cursor, d_group_start, d_n_points, d_status))
 
     # -- multi-GPU exchange (include/rplgpu_comm.h) ------------------------------------------
     @staticmethod

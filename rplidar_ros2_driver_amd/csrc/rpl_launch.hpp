@@ -42,7 +42,11 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               uint32_t *status, float *arena = nullptr,
                               unsigned long long arena_capacity = 0,
                               unsigned long long *arena_cursor = nullptr,
-                              unsigned long long *scan_start = nullptr);
+                              unsigned long long *scan_start = nullptr,
+                              // E8: `group` consecutive scans share one grid; per-scan motion
+                              // (vx, vy, wz, dt) and planar pose (r00 r01 tx r10 r11 ty), optional
+                              uint32_t group = 1, const float *motion = nullptr,
+                              const float *pose2d = nullptr);
 // record stores k_cloud_voxel needs: one per resident workgroup (two per CU), this many bytes each
 uint32_t voxel_max_workgroups(uint32_t n_cu);
 size_t voxel_store_bytes_per_workgroup();

@@ -20,7 +20,7 @@
 //   * a smooth ring stays in a 5 cm cell for ~10-200 samples, so runs of equal keys are
 //     aggregated before anything is stored: A and B merge in the lane, lanes merge through
 //     three plain DPP prefix scans, and a lane whose run ends writes ONE 16-byte record
-//     {key, prefix_x, prefix_y, prefix_count|intensity|tag} to the record queue.  The record
+//     {key, prefix_x, prefix_y, prefix_count|intensity|first-of-pass flag} to the record queue.  The record
 //     holds the wave-pass PREFIX, not the run sum: the run sum is prefix(this record) -
 //     prefix(previous record of the same wave-pass), recovered when the record is read,
 //     which removes every cross-lane gather (ds_bpermute) from the hot loop.
@@ -89,7 +89,7 @@ __device__ __forceinline__ void wave_incl_scan3_dpp(uint32_t &a, uint32_t &b, ui
 }
 
 struct VoxelLds {
-  // S: {key, prefix_x, prefix_y, tag<<24 | prefix(count<<16 | intensity)}
+  // S: {key, prefix_x, prefix_y, first-of-pass flag (bit 24) | prefix(count<<16 | intensity)}
   // R: first the (ix << 16 | record index) lists of the rows (the records sit in registers
   //    then), afterwards the records in (iy, ix) order {key, sum_x, sum_y, count<<16 | isum}
   uint4 rec[kRecCap];
@@ -141,11 +141,43 @@ __device__ __forceinline__ f2 div_by2(f2 a, float d, float rd) {
 // Per-sample arithmetic of phase S for one 8-byte node (lo, hi) and its table entry `c`.
 // Outputs the sort key (kEmptyKey when the sample is dropped) and the three quantities
 // that are summed per cell.  `flags` collects RPLGPU_SCAN_CELL_RANGE.
-template <bool FAST_DIV, bool SAFE, bool HASQ>
+// E8 (include/rplgpu_msg.h): what happens to a point between polar->XY and the grid when a GROUP
+// of scans shares one grid — the scan's motion during its acquisition (E6 de-skew, same
+// operations in the same order as k_cloud) and its sensor's planar pose.  All zeros / identity
+// reproduce x, y bit for bit.
+struct ScanXf {
+  float vx, vy, wz, dt;             // planar twist of the sensor and time between samples
+  float r00, r01, tx, r10, r11, ty;  // [R | t] of the sensor in the common frame (2-D)
+};
+__device__ __forceinline__ f2 apply_xf(f2 xy, uint32_t sample_index, const ScanXf &m) {
+  const float tau = (float)sample_index * m.dt;
+  const float a = m.wz * tau, a2 = a * a;
+  float ts = a2 * (1.0f / 120.0f);
+  ts = ts + (-1.0f / 6.0f);
+  ts = a2 * ts;
+  ts = ts + 1.0f;
+  const float sn = a * ts;
+  float tc = a2 * (-1.0f / 720.0f);
+  tc = tc + (1.0f / 24.0f);
+  tc = a2 * tc;
+  tc = tc + (-0.5f);
+  tc = a2 * tc;
+  const float cn = tc + 1.0f;
+  const float x1 = (cn * xy.x - sn * xy.y) + m.vx * tau;
+  const float y1 = (sn * xy.x + cn * xy.y) + m.vy * tau;
+  f2 o;
+  o.x = (m.r00 * x1 + m.r01 * y1) + m.tx;
+  o.y = (m.r10 * x1 + m.r11 * y1) + m.ty;
+  return o;
+}
+
+template <bool FAST_DIV, bool SAFE, bool HASQ, bool XF = false>
 __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c, const KParams &p,
                                              uint32_t q_min16, uint32_t ibfe_off,
                                              uint32_t ibfe_w, uint32_t &key, uint32_t &qx,
-                                             uint32_t &qy, uint32_t &ci, uint32_t &flags) {
+                                             uint32_t &qy, uint32_t &ci, uint32_t &flags,
+                                             uint32_t sample_index = 0u,
+                                             const ScanXf *xf = nullptr) {
   // Straight-line: a dropped sample runs the same arithmetic on harmless operands (dist 0 or an
   // out-of-range distance give finite values) and is masked at the end.  A wave issues in
   // order, so the exec-mask regions and branches of an `if (kept)` cost it more than the few
@@ -156,7 +188,8 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
   const float df = __uint2float_rn(d);
   const float dm = FAST_DIV ? div_by(df, 4000.0f, 0.00025f) : df / 4000.0f;  // :590
   const f2 cv = {c.x, c.y};
-  const f2 xy = cv * dm;                                                       // E2
+  f2 xy = cv * dm;                                                             // E2
+  if (XF) xy = apply_xf(xy, sample_index, *xf);                                // E6 + pose (E8)
   f2 t;
   if (FAST_DIV) {
     t = div_by2(xy, p.voxel_leaf, p.inv_leaf);                                 // E4 cell
@@ -165,7 +198,7 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
     t.y = xy.y / p.voxel_leaf;
   }
   const f2 f = {__builtin_floorf(t.x), __builtin_floorf(t.y)};
-  if (!SAFE) {
+  if (!SAFE || XF) {
     const bool inr = (fabsf(f.x) < 32767.0f) && (fabsf(f.y) < 32767.0f);
     if (kept && !inr) flags |= RPLGPU_SCAN_CELL_RANGE;
     kept = kept & inr;
@@ -189,7 +222,8 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
 // (okA / okB: the sample survived the keep mask and carries a real key).  The run records go
 // to the LDS queue while it has room and to the record store `G` (global) after that; either
 // way record i of the scan sits at position i.
-__device__ __forceinline__ void voxel_pair_pass(VoxelLds &L, uint4 *__restrict__ G, uint32_t tag,
+constexpr uint32_t kFirstOfPass = 1u << 24;  // record flag: no record of the same wave-pass before it
+__device__ __forceinline__ void voxel_pair_pass(VoxelLds &L, uint4 *__restrict__ G,
                                                 bool okA, uint32_t keyA, uint32_t xA, uint32_t yA,
                                                 uint32_t cA, bool okB, uint32_t keyB, uint32_t xB,
                                                 uint32_t yB, uint32_t cB) {
@@ -230,12 +264,15 @@ __device__ __forceinline__ void voxel_pair_pass(VoxelLds &L, uint4 *__restrict__
   uint32_t pos2;                           // pos1 + (e1 ? 1 : 0): the ballot is the carry-in
   uint64_t carry_out;
   asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(pos2), "=s"(carry_out) : "v"(pos1), "s"(m1));
+  // the first record of the pass is flagged: its prefix is a run sum already (the reader subtracts
+  // the previous record's prefix from every other one)
+  const uint32_t f1 = pos1 == base ? kFirstOfPass : 0u, f2 = pos2 == base ? kFirstOfPass : 0u;
   if (base + total <= kRecCap) {  // wave-uniform: the usual case, everything goes to LDS
-    if (e1) L.rec[pos1] = make_uint4(keyA, Px - xB, Py - yB, (Pc - cB) | tag);
-    if (e2) L.rec[pos2] = make_uint4(keyB, Px, Py, Pc | tag);
+    if (e1) L.rec[pos1] = make_uint4(keyA, Px - xB, Py - yB, (Pc - cB) | f1);
+    if (e2) L.rec[pos2] = make_uint4(keyB, Px, Py, Pc | f2);
   } else {  // past (or across) the end of the LDS queue: the record store takes the rest
-    const uint4 rA = make_uint4(keyA, Px - xB, Py - yB, (Pc - cB) | tag);
-    const uint4 rB = make_uint4(keyB, Px, Py, Pc | tag);
+    const uint4 rA = make_uint4(keyA, Px - xB, Py - yB, (Pc - cB) | f1);
+    const uint4 rB = make_uint4(keyB, Px, Py, Pc | f2);
     if (e1) {
       if (pos1 < kRecCap) L.rec[pos1] = rA; else G[pos1] = rA;
     }
@@ -297,8 +334,8 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
   const int vbias = p.vox_bias;
   const uint32_t nrec = L.misc[0];
   if (DBG && p.dbg && threadIdx.x == 0) pc.acc[7] += (unsigned long long)nrec << 40;
-  // thread t owns the queue records t, t + 512, ... ; prefix -> run sum against the record just
-  // before it when both come from the same wave-pass (equal tags)
+  // thread t owns the queue records t, t + kVB, ... ; prefix -> run sum against the record just
+  // before it unless it is the first record of its wave-pass
   uint4 mine[kRecPerThread];
   uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
 #pragma unroll
@@ -320,7 +357,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
           const uint4 t = L.rec[idx - 1u];
           pr.y = t.y; pr.z = t.z; pr.w = t.w;
         }
-        const bool same = ok && idx > 0u && (((raw.w ^ pr.w) >> 24) == 0u);
+        const bool same = ok && idx > 0u && !(raw.w & kFirstOfPass);
         m.y -= same ? pr.y : 0u;
         m.z -= same ? pr.z : 0u;
         m.w = (raw.w & 0x00FFFFFFu) - (same ? (pr.w & 0x00FFFFFFu) : 0u);
@@ -536,7 +573,11 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
     float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
-    uint32_t *__restrict__ status, uint32_t B, VoxelArena arena, uint4 *__restrict__ store) {
+    uint32_t *__restrict__ status, uint32_t B, VoxelArena arena, uint4 *__restrict__ store,
+    uint32_t group, uint32_t n_scans, const float *__restrict__ motion,
+    const float *__restrict__ pose2d) {
+  // B work items; item b = the scans [b * group, min(n_scans, (b + 1) * group)) sharing ONE grid
+  // (group == 1: a scan is an item, the round-1 behaviour; E8 otherwise)
   __shared__ VoxelLds L;
 
   if (threadIdx.x < 256) L.rcp[threadIdx.x] = T.rcp[threadIdx.x];  // (first barrier below publishes it)
@@ -544,8 +585,6 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // persistent workgroups, two per CU; the first scan is blockIdx.x, the next ones come from a
   // shared counter, so a workgroup that drew cheap scans simply takes more of them
   for (uint32_t b = blockIdx.x; b < B;) {
-  const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
-  const uint2 *scan = nodes + (size_t)b * n_stride;
   float4 *out = arena.base ? arena.base : xyzi + (size_t)b * out_stride;
   int emit_mode = arena.base ? kEmitArenaFirst : kEmitLegacy;
   unsigned long long arena_at = 0ull;  // first point of this scan in the arena
@@ -568,20 +607,6 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   PhaseClock<DBG> pc;
   pc.start();
 
-  // lane l of a round owns the sample pair (2i, 2i+1), i = round*512 + thread
-  const uint32_t npairs = (n + 1u) >> 1;
-  // Bounds-checked buffer resource over this scan's n*8 bytes: a pair (or its second node)
-  // beyond the scan reads as zero, i.e. dist 0, which the keep test drops.  Every lane
-  // always issues the load, so the compiler's vmcnt bookkeeping is exact and the prefetch
-  // distance below is really kept.
-  const __amdgpu_buffer_rsrc_t scan_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
-  auto load_pair = [&](uint32_t i) -> uint4 {
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)(i * 16u), 0, 2);
-    return make_uint4(t.x, t.y, t.z, t.w);
-  };
-
-  const uint32_t *ror_bits = keepmask ? keepmask + (size_t)b * mask_stride : nullptr;
   bool first_band = true;
   bool from_store = false;  // block-uniform: the scan's records are (all) in the record store
   uint32_t n_all = 0;       // records of the whole scan (valid once the scan was streamed)
@@ -611,14 +636,37 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       // Deeper prefetch does not pay (profiles/r02/voxel_phaseS_study.txt: two rounds per
       // trip, a copy-free four-buffer register ring in plain HIP and with hand-managed vmcnt,
       // staggered waves — the wait at the end of a round shrinks, the round does not).
-      auto stream = [&](auto hasq_tag, auto mask_tag) {
+      const bool use_xf = (group > 1u) || motion || pose2d;  // block-uniform
+      const uint32_t s_lo = b * group, s_hi = min(n_scans, s_lo + group);
+      for (uint32_t sc = s_lo; sc < s_hi; ++sc) {
+        const uint32_t n = min(n_per_scan[sc], min(n_stride, kMaxN));  // never past the slot
+        const uint2 *scan = nodes + (size_t)sc * n_stride;
+        // lane l of a round owns the sample pair (2i, 2i+1), i = round * kVB + thread
+        const uint32_t npairs = (n + 1u) >> 1;
+        // Bounds-checked buffer resource over this scan's n*8 bytes: a pair (or its second
+        // node) beyond the scan reads as zero, i.e. dist 0, which the keep test drops.  Every
+        // lane always issues the load, so the compiler's vmcnt bookkeeping is exact.
+        const __amdgpu_buffer_rsrc_t scan_rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
+        auto load_pair = [&](uint32_t i) -> uint4 {
+          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)(i * 16u), 0, 2);
+          return make_uint4(t.x, t.y, t.z, t.w);
+        };
+        const uint32_t *ror_bits = keepmask ? keepmask + (size_t)sc * mask_stride : nullptr;
+        ScanXf xf = {0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+        if (motion) { xf.vx = motion[4 * sc]; xf.vy = motion[4 * sc + 1]; xf.wz = motion[4 * sc + 2]; xf.dt = motion[4 * sc + 3]; }
+        if (pose2d) {
+          xf.r00 = pose2d[6 * sc]; xf.r01 = pose2d[6 * sc + 1]; xf.tx = pose2d[6 * sc + 2];
+          xf.r10 = pose2d[6 * sc + 3]; xf.r11 = pose2d[6 * sc + 4]; xf.ty = pose2d[6 * sc + 5];
+        }
+      auto stream = [&](auto hasq_tag, auto mask_tag, auto xf_tag) {
         constexpr bool HASQ = decltype(hasq_tag)::value;
         constexpr bool HASMASK = decltype(mask_tag)::value;
+        constexpr bool XF = decltype(xf_tag)::value;
         uint4 w1 = load_pair(threadIdx.x);
         uint4 w2 = load_pair(kVB + threadIdx.x);
         float2 cA1 = cs[w1.x & 0xFFFFu], cB1 = cs[w1.z & 0xFFFFu];
-        uint32_t round = 0;
-        for (uint32_t base = 0; base < npairs; base += kVB, ++round) {
+        for (uint32_t base = 0; base < npairs; base += kVB) {
           const uint4 w0 = w1;
           const float2 cA = cA1, cB = cB1;
           w1 = w2;
@@ -634,11 +682,12 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (!(two & 1u)) { w.x &= 0x0000FFFFu; w.y &= 0xFFFF0000u; }
             if (!(two & 2u)) { w.z &= 0x0000FFFFu; w.w &= 0xFFFF0000u; }
           }
+          const uint32_t iA = 2u * (base + threadIdx.x);  // sample index inside the scan
           uint32_t keyA, xA, yA, ciA, keyB, xB, yB, ciB;
-          const bool okA = voxel_sample<FAST_DIV, SAFE, HASQ>(w.x, w.y, cA, p, q_min16, ibfe_off,
-                                                              ibfe_w, keyA, xA, yA, ciA, flags);
-          const bool okB = voxel_sample<FAST_DIV, SAFE, HASQ>(w.z, w.w, cB, p, q_min16, ibfe_off,
-                                                              ibfe_w, keyB, xB, yB, ciB, flags);
+          const bool okA = voxel_sample<FAST_DIV, SAFE, HASQ, XF>(
+              w.x, w.y, cA, p, q_min16, ibfe_off, ibfe_w, keyA, xA, yA, ciA, flags, iA, &xf);
+          const bool okB = voxel_sample<FAST_DIV, SAFE, HASQ, XF>(
+              w.z, w.w, cB, p, q_min16, ibfe_off, ibfe_w, keyB, xB, yB, ciB, flags, iA + 1u, &xf);
           bool vA = okA, vB = okB;
           if (HASQ || HASMASK) {
             // A sample the quality filter or the E5 mask drops must not END the run it sits in
@@ -649,19 +698,20 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             keyA = okA ? keyA : keyB;
             keyB = okB ? keyB : keyA;
           }
-          // tag: (round, wave) — unique per wave-pass of a scan (<= 32 rounds, 8 waves)
-          const uint32_t tag = kVB == 512 ? ((((round & 31u) << 3) | wave_id()) << 24)
-                                          : ((((round & 15u) << 4) | wave_id()) << 24);
-          voxel_pair_pass(L, G, tag, vA, keyA, xA, yA, ciA, vB, keyB, xB, yB, ciB);
+          voxel_pair_pass(L, G, vA, keyA, xA, yA, ciA, vB, keyB, xB, yB, ciB);
         }
       };
       {
         using T_ = std::true_type;
         using F_ = std::false_type;
-        if (keepmask) stream(T_{}, T_{});
-        else if (q_min16) stream(T_{}, F_{});
-        else stream(F_{}, F_{});
+        if (use_xf) {  // (E8 / de-skew: one instance, quality test and mask word always on)
+          if (keepmask) stream(T_{}, T_{}, T_{});
+          else stream(T_{}, F_{}, T_{});
+        } else if (keepmask) stream(T_{}, T_{}, F_{});
+        else if (q_min16) stream(T_{}, F_{}, F_{});
+        else stream(F_{}, F_{}, F_{});
       }
+      }  // scans of the group
       first_band = false;
       __syncthreads();  // (workgroup-scope release / acquire: covers the record store too)
       pc.lap(0);
@@ -676,7 +726,7 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     } else {
       // ---- a band of a scan that lives in the record store: select its records ----------
-      // record i -> run sums against record i - 1 (same wave-pass: equal tags), exactly what
+      // record i -> run sums against record i - 1 (unless first of its wave-pass), exactly what
       // phase R does for the LDS queue; the records of the band are appended to the LDS queue
       bool fits = true;
       uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;  // keys of this band's records seen by this lane
@@ -704,7 +754,7 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           pr.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw[j].z, 0x138, 0xF, 0xF, false);
           pr.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw[j].w, 0x138, 0xF, 0xF, false);
           if (lane_id() == 0u) { pr.y = prl[j].y; pr.z = prl[j].z; pr.w = prl[j].w; }
-          const bool same = i > 0u && (((raw[j].w ^ pr.w) >> 24) == 0u);
+          const bool same = i > 0u && !(raw[j].w & kFirstOfPass);
           m[j] = raw[j];
           m[j].y -= same ? pr.y : 0u;
           m[j].z -= same ? pr.z : 0u;
@@ -885,8 +935,13 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               const Tables &T, const uint32_t *keepmask, uint32_t mask_stride,
                               float *xyzi, uint32_t out_stride, uint32_t *n_points,
                               uint32_t *status, float *arena, unsigned long long arena_capacity,
-                              unsigned long long *arena_cursor, unsigned long long *scan_start) {
+                              unsigned long long *arena_cursor, unsigned long long *scan_start,
+                              uint32_t group, const float *motion, const float *pose2d) {
   if (B == 0) return hipSuccess;
+  if (group == 0) group = 1;
+  if (kVB == 512 && group > 1) return hipErrorInvalidValue;  // (groups: 16-wave geometry only)
+  const uint32_t n_scans = B;
+  B = (B + group - 1u) / group;  // work items
   if (!T.voxel_store || T.voxel_store_wgs == 0) return hipErrorInvalidValue;
   VoxelArena ar;
   ar.base = (float4 *)arena;
@@ -906,7 +961,7 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
 #define RPL_LAUNCH_VOXEL(FD, SF, DB)                                                              \
   hipLaunchKernelGGL((k_cloud_voxel<FD, SF, DB>), dim3(grid), dim3(kVB), 0, s, (const uint2 *)nodes, \
                      n_stride, n_per_scan, p, T, keepmask, mask_stride, (float4 *)xyzi, out_stride, \
-                     n_points, status, B, ar, (uint4 *)T.voxel_store)
+                     n_points, status, B, ar, (uint4 *)T.voxel_store, group, n_scans, motion, pose2d)
   if (p.dbg) {  // developer aid: the instrumented build of the kernel
     if (p.fast_div) {
       if (p.cell_range_safe) RPL_LAUNCH_VOXEL(true, true, true); else RPL_LAUNCH_VOXEL(true, false, true);

@@ -647,6 +647,37 @@ int32_t rplgpu_cloud_arena_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
   return RPLGPU_OK;
 }
 
+int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
+                                     uint32_t n_stride, const uint32_t *d_n_per_scan, uint32_t B,
+                                     uint32_t group, const rplgpu_params_t *p,
+                                     const float *d_motion, const float *d_pose2d, float *d_arena,
+                                     uint64_t arena_capacity, uint64_t *d_cursor,
+                                     uint64_t *d_group_start, uint32_t *d_n_points,
+                                     uint32_t *d_status) {
+  int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
+  if (rc) return rc;
+  if (!p || !d_arena || !d_cursor || !d_group_start || !d_n_points || group == 0)
+    return RPLGPU_ERR_INVALID_ARG;
+  if (!p->voxel_enable) {
+    h->err = "rplgpu_cloud_fused_voxel_dev needs voxel_enable";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  if ((d_motion && !device_readable(h, d_motion, "d_motion")) ||
+      (d_pose2d && !device_readable(h, d_pose2d, "d_pose2d")))
+    return RPLGPU_ERR_INVALID_ARG;
+  rpl::KParams kp;
+  const uint32_t *mask = nullptr;
+  if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
+  RPL_HIP(h, hipMemsetAsync(d_cursor, 0, 8, h->stream));
+  RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
+                                     tables_of(h), mask, kMaskStride, nullptr, 0, d_n_points,
+                                     d_status, d_arena, arena_capacity,
+                                     reinterpret_cast<unsigned long long *>(d_cursor),
+                                     reinterpret_cast<unsigned long long *>(d_group_start), group,
+                                     d_motion, d_pose2d));
+  return RPLGPU_OK;
+}
+
 int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
                                const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
                                float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,

@@ -438,3 +438,92 @@ def test_laserscan_to_cloud_matches_oracle(gpu, oracle):
             assert np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2])) <= 1e-6
             assert got[:, 2:].tobytes() == want[:, 2:].tobytes()
         assert msgs[b, : ml[b]].tobytes() == cdr.cloud_msg(fid, 100 + b, 7 * b, got)
+
+
+# ------------------------------------------------ E8: one voxel grid per group of scans (row 4)
+def _e8_oracle(oracle, scans, p, motion, pose2d, leaf):
+    """Spec of rplgpu_cloud_fused_voxel_dev from its parts: E1 + E2 per scan (C oracle), E6
+    de-skew and the planar pose (numpy restatements in oracle/fusion_oracle.py), then E4 over all
+    points of the group (C oracle's voxel grid)."""
+    import fusion_oracle as fo
+    op = oracle_lib.copy_params(p)
+    op.voxel_enable = 0
+    pts = []
+    for s, nodes in enumerate(scans):
+        cloud = oracle.scan_to_cloud(nodes, op)  # kept samples in input order (E5 applied too)
+        dm = nodes["dist_mm_q2"].astype(np.float32) / np.float32(4000.0)
+        keep = (nodes["dist_mm_q2"] != 0) & (dm >= np.float32(p.range_min)) & (dm <= np.float32(p.range_max)) \
+            & (nodes["quality"] >= p.q_min)
+        idx = np.flatnonzero(keep)
+        assert not p.ror_enable and len(idx) == len(cloud)
+        if motion is not None:
+            cloud = fo.deskew_cloud(cloud, idx, motion[s])
+        if pose2d is not None:
+            r00, r01, tx, r10, r11, ty = pose2d[s]
+            pose = np.array([[r00, r01, 0, tx], [r10, r11, 0, ty], [0, 0, 1, 0]], np.float32)
+            cloud = fo.transform_cloud(cloud, pose)
+        pts.append(cloud)
+    return oracle.voxel_grid(np.concatenate(pts), leaf)
+
+
+def test_fused_voxel_groups_match_oracle(gpu, oracle):
+    """De-skew in front of the voxel grid (group = 1, motion) and the cross-sensor voxel grid
+    (8 sensors with poses -> one grid per time step)."""
+    import torch
+    import fusion_oracle as fo
+    dev = torch.device("cuda:0")
+    n = 12000
+    for group, G, noise in ((1, 6, 0.0), (8, 3, 0.01), (3, 2, 0.0)):
+        B = group * G + (1 if group == 3 else 0)  # (3, 2): a last, partial group of one scan
+        scans = [synth.make_scan(1000 + group, b, n, noise_m=noise, r0_range=(2.0, 12.0)) for b in range(B)]
+        batch = np.stack(scans)
+        rng = np.random.default_rng(group)
+        motion = np.stack([[rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), rng.uniform(-0.4, 0.4),
+                            0.1 / n] for _ in range(B)]).astype(np.float32)
+        poses = np.stack([fo.planar_pose(rng.uniform(-3, 3), rng.uniform(-4, 4), rng.uniform(-4, 4))
+                          for _ in range(B)])
+        pose2d = np.ascontiguousarray(poses[:, :2][:, :, [0, 1, 3]].reshape(B, 6))
+        p = Params.defaults(clip_enable=1, q_min=8, range_min=0.15, range_max=40.0, voxel_enable=1,
+                            voxel_leaf=0.05)
+        d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+        d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
+        d_motion = torch.from_numpy(motion).to(dev)
+        d_pose = torch.from_numpy(pose2d).to(dev)
+        ng = (B + group - 1) // group
+        cap = B * n
+        for use_m, use_p in ((True, True), (True, False), (False, True), (False, False)):
+            d_arena = torch.zeros(cap, 4, dtype=torch.float32, device=dev)
+            d_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+            d_start = torch.zeros(ng, dtype=torch.int64, device=dev)
+            d_np = torch.zeros(ng, dtype=torch.int32, device=dev)
+            d_st = torch.zeros(ng, dtype=torch.int32, device=dev)
+            gpu.cloud_fused_voxel_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, group, p,
+                                      d_motion.data_ptr() if use_m else 0,
+                                      d_pose.data_ptr() if use_p else 0, d_arena.data_ptr(), cap,
+                                      d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(),
+                                      d_st.data_ptr())
+            gpu.synchronize()
+            assert int(d_st.max()) == 0
+            arena, start, npts = d_arena.cpu().numpy(), d_start.cpu().numpy(), d_np.cpu().numpy()
+            assert int(d_cur.item()) == int(npts.sum())
+            for g in range(ng):
+                sl = slice(g * group, min(B, (g + 1) * group))
+                want, wcells, _ = _e8_oracle(oracle, scans[sl], p, motion[sl] if use_m else None,
+                                             pose2d[sl] if use_p else None, 0.05)
+                got = arena[start[g]: start[g] + npts[g]]
+                assert len(got) == len(want), (group, g, use_m, use_p)
+                assert np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2])) <= 1e-6
+                assert np.all(got[:, 2] == 0.0)
+                assert got[:, 3].tobytes() == want[:, 3].tobytes()
+            if group == 1 and not use_m and not use_p:
+                # no motion, identity pose, groups of one: exactly rplgpu_cloud_arena_dev
+                d_a2 = torch.zeros(cap, 4, dtype=torch.float32, device=dev)
+                d_s2 = torch.zeros(B, dtype=torch.int64, device=dev)
+                d_n2 = torch.zeros(B, dtype=torch.int32, device=dev)
+                gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_a2.data_ptr(), cap,
+                                    d_cur.data_ptr(), d_s2.data_ptr(), d_n2.data_ptr(), d_st.data_ptr())
+                gpu.synchronize()
+                a2, s2, n2 = d_a2.cpu().numpy(), d_s2.cpu().numpy(), d_n2.cpu().numpy()
+                for b in range(B):
+                    assert npts[b] == n2[b]
+                    assert arena[start[b]: start[b] + npts[b]].tobytes() == a2[s2[b]: s2[b] + n2[b]].tobytes()
