@@ -226,6 +226,26 @@ int32_t rplgpu_scans_to_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_seg_
                                   uint32_t scan_cap, const uint32_t *d_n_scans, uint32_t B,
                                   uint32_t *d_scan_base, rplgpu_node_t *d_batch, uint32_t n_stride,
                                   uint32_t max_scans, uint32_t *d_n_per_scan);
+/* The whole step before the path in ONE call: recorded streams -> completed scans, written
+ * straight into the fixed-stride batch the *_batch_dev entry points take (the decoder reports
+ * its sync nodes, so the node stream is not searched again, and the scans are not copied
+ * twice).  Decoding as rplgpu_decode_batch_dev, assembly rules as rplgpu_segment_batch_dev
+ * (ScanDataHolder, src/sdk/src/sl_lidar_driver.cpp:272-315).  Completed scan s of stream b is
+ * batch slot g = b*scan_cap + s: nodes at d_batch + g*n_stride, d_n_per_scan[g] of them
+ * (RPLGPU_SCAN_OUT_TRUNCATED in d_status[b] when a scan is longer than n_stride); the slots a
+ * stream does not fill get d_n_per_scan[g] = 0, which every batch entry point takes as an empty
+ * scan.  d_n_scans[b] = completed scans of stream b (<= scan_cap).  d_status is required.
+ * RPLGPU_STREAM_RESETS_TRUNCATED: a stream completed more than scan_cap scans (the first scan_cap
+ * are delivered).  The decoded node streams live in scratch owned by the handle
+ * (B * max_frames * nodes_per_frame nodes; allocated on first use, grown on demand). */
+int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
+                                const uint8_t *d_bytes, uint64_t stream_stride,
+                                const uint32_t *d_frame_off, const uint8_t *d_gap,
+                                const uint32_t *d_n_frames, uint32_t max_frames, uint32_t B,
+                                const int32_t *d_state_in, int32_t *d_state_out,
+                                uint32_t max_count, rplgpu_node_t *d_batch, uint32_t n_stride,
+                                uint32_t scan_cap, uint32_t *d_n_per_scan, uint32_t *d_n_scans,
+                                uint32_t *d_n_errors, uint32_t *d_status);
 /* One stream of any length, HOST buffers: framing on the host, decode on the GPU in pieces of
  * rplgpu_decode_max_frames frames (overlapping by one frame, see flags bit 0).  No state is kept
  * in the handle: pass state in/out explicitly ({0,0,0,0} for a fresh unpacker).  nodes: cap

@@ -51,6 +51,13 @@ struct DecCfg {
       !kFiltered ? 1u : ANS == RPLGPU_ANS_DENSE_CAPSULED ? kDecMaxFrames * 40u / 64u : kUdMaxFrames;
   static constexpr uint32_t kSmoothSlots = ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? kUdMaxFrames * 64u : 1u;
   static constexpr uint32_t kCrcWords = ANS == RPLGPU_ANS_HQ ? 1024u : 1u;
+  // nodes one lane decodes in one go (all of ONE frame): per-frame arithmetic once per group,
+  // payload in one or two wide loads, nodes out in 16-byte stores
+  static constexpr uint32_t kGroup = ANS == RPLGPU_ANS_MEASUREMENT ? 1u
+                                     : ANS == RPLGPU_ANS_CAPSULED_ULTRA ? 6u
+                                                                        : 4u;
+  // ultra: the triangulation angle correction is a function of k2 = 98361 / dist (0..491) alone
+  static constexpr uint32_t kCorrSlots = ANS == RPLGPU_ANS_CAPSULED_ULTRA ? 496u : 1u;
   static constexpr uint32_t kStageWords = ANS == RPLGPU_ANS_HQ ? (kDecBlock / 64) * 64 * 17 : 1u;
 };
 
@@ -65,6 +72,16 @@ __device__ __forceinline__ uint32_t ld16(const uint8_t *p) {
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) {
   uint32_t v;
   __builtin_memcpy(&v, p, 4);
+  return v;
+}
+__device__ __forceinline__ uint64_t ld64(const uint8_t *p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+__device__ __forceinline__ uint4 ld128(const uint8_t *p) {
+  uint4 v;
+  __builtin_memcpy(&v, p, 16);
   return v;
 }
 
@@ -189,13 +206,14 @@ template <int ANS>
 struct DecodeLds {
   // per frame: bit31 valid, bits 0..15 start_angle_sync_q6
   uint32_t frame[DecCfg<ANS>::kTableSlots];
-  uint32_t emit_frame[DecCfg<ANS>::kTableSlots];  // compacted list of the frames that publish nodes
+  uint16_t emit_frame[DecCfg<ANS>::kTableSlots];  // compacted list of the frames that publish nodes
   unsigned long long rawbits[DecCfg<ANS>::kRawBitWords];  // dense types: raw sync bit per node
   uint16_t smooth[DecCfg<ANS>::kSmoothSlots];  // ultra-dense: bit15 scale 0, bits 0..13 raw dist_q2
   uint32_t crc_table[DecCfg<ANS>::kCrcWords];  // HQ: slicing-by-4 tables
   uint32_t stage[DecCfg<ANS>::kStageWords];    // HQ: per wave, 64 frames x 16 words (+1 pad)
+  int32_t corr[DecCfg<ANS>::kCorrSlots];       // ultra: angle correction (Q16 -> Q6 units) by k2
   uint32_t tmp[40];
-  uint32_t misc[8];  // 0 status, 3 last sync out, 4 last dist out, 5 error count
+  uint32_t misc[8];  // 0 status, 3 last sync out, 4 last dist out, 5 error count, 6 sync nodes
 };
 
 __device__ __forceinline__ uint32_t dec_block_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
@@ -215,14 +233,15 @@ __device__ __forceinline__ uint32_t dec_block_scan(uint32_t v, uint32_t *tmp, ui
   return base + inc - v;
 }
 
-template <int ANS>
+template <int ANS, bool FRAMED>  // FRAMED: frame offsets (and gaps) given; else frames back to back
 __global__ __launch_bounds__(kDecBlock) void k_decode(
     const uint8_t *__restrict__ bytes, uint64_t stream_stride, const uint32_t *__restrict__ frame_off,
     const uint8_t *__restrict__ gap, const uint32_t *__restrict__ n_frames, uint32_t max_frames,
     uint32_t sample_duration_us, const int32_t *__restrict__ state_in,
     int32_t *__restrict__ state_out, uint2 *__restrict__ nodes_out, uint32_t node_stride,
     uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ reset_at, uint32_t reset_stride,
-    uint32_t *__restrict__ n_reset, uint32_t *__restrict__ n_errors, uint32_t *__restrict__ status) {
+    uint32_t *__restrict__ n_reset, uint32_t *__restrict__ n_errors, uint32_t *__restrict__ status,
+    uint32_t *__restrict__ sync_at, uint32_t sync_stride, uint32_t *__restrict__ n_sync) {
   constexpr uint32_t S = dec_frame_size(ANS);
   constexpr uint32_t NPF = dec_nodes_per_frame(ANS);
   constexpr bool CAPS = ANS == RPLGPU_ANS_CAPSULED || ANS == RPLGPU_ANS_CAPSULED_ULTRA ||
@@ -234,12 +253,12 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
 
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   const uint8_t *base = bytes + (size_t)b * stream_stride;
-  const uint32_t *foff = frame_off ? frame_off + (size_t)b * max_frames : nullptr;
-  const uint8_t *fgap = gap ? gap + (size_t)b * max_frames : nullptr;
+  const uint32_t *foff = FRAMED ? frame_off + (size_t)b * max_frames : nullptr;
+  const uint8_t *fgap = (FRAMED && gap) ? gap + (size_t)b * max_frames : nullptr;
   const uint32_t nf = min(n_frames[b], min(max_frames, DecCfg<ANS>::kMaxFrames));
   uint2 *out = nodes_out + (size_t)b * node_stride;
   auto frame_ptr = [&](uint32_t k) -> const uint8_t * {
-    return base + (foff ? (size_t)foff[k] : (size_t)k * S);
+    return base + (FRAMED ? (size_t)foff[k] : (size_t)k * S);
   };
 
   // state word 2, bit 0: frame 0 is the previous call's last frame, handed over again only as
@@ -258,9 +277,30 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       L.crc_table[256 * k + tid] = c;
     }
   }
+  if (FILTERED) {  // raw sync bits are rare: P3 sets them with an LDS atomic, so start from zero
+    const uint32_t nw = min(kRawBitWords, (uint32_t)(((uint64_t)nf * NPF + 63u) >> 6));
+    for (uint32_t w = tid; w < nw; w += kDecBlock) L.rawbits[w] = 0ull;
+  }
+  if (ANS == RPLGPU_ANS_CAPSULED_ULTRA) {
+    // handler_capsules.cpp:545-556: offsetAngleMean_q16 depends on the distance only through
+    // k2 = 98361 / dist (0 .. 491 for dist >= 200); entry 492 = the default for dist < 200.
+    // The reference's double arithmetic, done once per value instead of once per node.
+    for (uint32_t k2 = tid; k2 < 493u; k2 += kDecBlock) {
+      int off_q16 = (int)(7.5 * 3.1415926535 * (1 << 16) / 180.0);
+      if (k2 < 492u) {
+        const int kk = (int)k2;
+        off_q16 = (int)(8 * 3.1415926535 * (1 << 16) / 180) - (kk << 6) - (kk * kk * kk) / 98304;
+      }
+      L.corr[k2] = (int)((double)(off_q16 * 180) / 3.14159265);
+    }
+  }
   if (n_frames[b] > nf && tid == 0) L.misc[0] = RPLGPU_STREAM_FRAMES_TRUNCATED;
   __syncthreads();
 
+#ifdef RPL_DEC_DBG
+  unsigned long long dbg_t[7];
+  dbg_t[0] = __builtin_amdgcn_s_memtime();
+#endif
   // ---- P1: per frame: framing check (unframed input only), checksum, header word ---------
   uint32_t my_err = 0, unframed = 0;
   if (ANS == RPLGPU_ANS_HQ) {  // handler_hqnode.cpp:99-172, a wave per 64 frames
@@ -268,46 +308,85 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     for (uint32_t k0 = wave_id() * 64u; k0 < nf; k0 += kDecBlock) {
       const uint32_t k = k0 + lane_id();
       const bool live = k < nf;
-      const uint32_t my_off = live ? (foff ? foff[k] : k * S) : 0u;
+      const uint32_t my_off = live ? (FRAMED ? foff[k] : k * S) : 0u;
       const uint32_t res = hq_crc_64frames(base, my_off, min(nf - k0, 64u), stg, L.crc_table);
       if (live) {
-        if (!foff && (res >> 8) != 0xA5u) unframed = 1;
+        if (!FRAMED && (res >> 8) != 0xA5u) unframed = 1;
         L.frame[k] = (res & 1u) ? 0x80000000u : 0u;
         my_err += (res & 1u) ? 0u : 1u;
       }
     }
   }
-  for (uint32_t k = tid; k < nf && ANS != RPLGPU_ANS_HQ && (DecCfg<ANS>::kTable || !foff);
-       k += kDecBlock) {
-    const uint8_t *f = frame_ptr(k);
-    uint32_t rec = 0;
-    if (ANS == RPLGPU_ANS_MEASUREMENT) {  // handler_normalnode.cpp:88-112
+  if (ANS == RPLGPU_ANS_MEASUREMENT && !FRAMED) {  // handler_normalnode.cpp:88-112
+    for (uint32_t k = tid; k < nf; k += kDecBlock) {
+      const uint8_t *f = frame_ptr(k);
       const uint32_t b0 = ld8(f), b1 = ld8(f + 1);
-      if (!foff && !((((b0 >> 1) ^ b0) & 1u) && (b1 & 1u))) unframed = 1;
-      continue;  // nothing to tabulate
-    } else if (ANS == RPLGPU_ANS_HQ) {
-      continue;  // done above
-    } else {  // the four capsule types: handler_capsules.cpp:107-194 and siblings
-      const uint32_t b0 = ld8(f), b1 = ld8(f + 1);
-      if (!foff && ((b0 >> 4) != 0xAu || (b1 >> 4) != 0x5u)) unframed = 1;
-      // XOR of bytes 2 .. S-1 (:137-150): whole (possibly unaligned) dwords, folded at the end —
-      // a quarter of the load instructions of a byte loop; bytes 0 and 1 are XOR-ed out again
-      uint32_t xw = 0;
-#pragma unroll 7
-      for (uint32_t i = 0; i + 4u <= S; i += 4u) xw ^= ld32(f + i);
-      for (uint32_t i = S & ~3u; i < S; ++i) xw ^= f[i];
-      xw ^= xw >> 16;
-      const uint32_t x = ((xw ^ (xw >> 8)) ^ b0 ^ b1) & 0xFFu;
-      const bool ok = (((b0 & 0xFu) | (b1 << 4)) & 0xFFu) == x;
-      my_err += (ok || (carry0 && k == 0u)) ? 0u : 1u;
-      rec = (ok ? 0x80000000u : 0u) | ld16(f + SA_OFF);
+      if (!((((b0 >> 1) ^ b0) & 1u) && (b1 & 1u))) unframed = 1;
     }
-    L.frame[k] = rec;
+  }
+  if (CAPS) {  // the four capsule types: handler_capsules.cpp:107-194 and siblings
+    // XOR of bytes 2 .. S-1 (:137-150).  EIGHT lanes share a frame: lane j takes the (possibly
+    // unaligned) dwords j, j+8, ... of it, so a wave instruction reads eight 32-byte runs of
+    // eight neighbouring frames and the next instruction continues in the same lines (one lane
+    // per frame touched a different line with every lane of every load).  The loads of FOUR
+    // such trips (4 x 32 frames per workgroup) are issued before the first is consumed.
+    // Alone this pass takes 30 k cycles per 801-frame stream; next to other workgroups' node
+    // stores it takes 130 k whatever its shape — it queues behind them (decode_study.txt).
+    constexpr uint32_t LPF = 8, NDW = (S + 3u) / 4u, TRIPS = (NDW + LPF - 1u) / LPF;
+    constexpr uint32_t FPT = kDecBlock / LPF, DEPTH = 4;  // frames per trip, trips in flight
+    const uint32_t j = tid & (LPF - 1u);
+    for (uint32_t k0 = 0; k0 < nf; k0 += DEPTH * FPT) {
+      uint32_t v[DEPTH][TRIPS];
+#pragma unroll
+      for (uint32_t u = 0; u < DEPTH; ++u) {
+        const uint32_t k = k0 + u * FPT + tid / LPF;
+        const bool live = k < nf;
+        const uint8_t *f = frame_ptr(live ? k : 0u);
+#pragma unroll
+        for (uint32_t i = 0; i < TRIPS; ++i) {
+          const uint32_t d = j + LPF * i;
+          uint32_t w = 0;
+          if (live && 4u * d + 4u <= S) {
+            w = ld32(f + 4u * d);
+          } else if ((S & 3u) != 0u && live && d == NDW - 1u) {  // the frame's last, partial dword
+#pragma unroll
+            for (uint32_t q = 0; q < (S & 3u); ++q) w |= (uint32_t)f[4u * (NDW - 1u) + q] << (8u * q);
+          }
+          v[u][i] = w;
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < DEPTH; ++u) {
+        const uint32_t k = k0 + u * FPT + tid / LPF;
+        const bool live = k < nf;
+        uint32_t xw = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < TRIPS; ++i) xw ^= v[u][i];
+        const uint32_t first = v[u][0];
+        xw ^= (uint32_t)__shfl_xor((int)xw, 1, 64);
+        xw ^= (uint32_t)__shfl_xor((int)xw, 2, 64);
+        xw ^= (uint32_t)__shfl_xor((int)xw, 4, 64);
+        if (live && j == 0u) {
+          const uint32_t b0 = first & 0xFFu, b1 = (first >> 8) & 0xFFu;  // XOR-ed out again below
+          if (!FRAMED && ((b0 >> 4) != 0xAu || (b1 >> 4) != 0x5u)) unframed = 1;
+          xw ^= xw >> 16;
+          const uint32_t x = ((xw ^ (xw >> 8)) ^ b0 ^ b1) & 0xFFu;
+          const bool ok = (((b0 & 0xFu) | (b1 << 4)) & 0xFFu) == x;
+          my_err += (ok || (carry0 && k == 0u)) ? 0u : 1u;
+          const uint32_t sa = SA_OFF == 2u ? (first >> 16) : ld16(frame_ptr(k) + SA_OFF);
+          L.frame[k] = (ok ? 0x80000000u : 0u) | sa;
+        }
+      }
+    }
   }
   if (unframed) atomicOr(&L.misc[0], RPLGPU_STREAM_UNFRAMED);
   __syncthreads();
   const bool bad_framing = (L.misc[0] & RPLGPU_STREAM_UNFRAMED) != 0u;
 
+#ifdef RPL_DEC_DBG
+  __syncthreads();
+  dbg_t[1] = __builtin_amdgcn_s_memtime();
+#endif
   // ---- P2: which frames publish, node offsets, reset requests ------------------------------
   // (loop over chunks of 256 frames with a running carry)
   uint32_t carry_nodes = 0, carry_emit = 0, carry_reset = 0;
@@ -340,7 +419,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     uint32_t tot_e, tot_r;
     const uint32_t ex_e = dec_block_scan(emits, L.tmp, &tot_e);
     const uint32_t ex_r = dec_block_scan(resets, L.tmp, &tot_r);
-    if (emits) L.emit_frame[carry_emit + ex_e] = k;
+    if (emits) L.emit_frame[carry_emit + ex_e] = (uint16_t)k;
     if (resets) {
       const uint32_t slot = carry_reset + ex_r;
       if (reset_at && slot < reset_stride)
@@ -354,115 +433,266 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   const uint32_t n_emit = carry_emit;
   const uint32_t n_out = min(carry_nodes, node_stride);
 
+#ifdef RPL_DEC_DBG
+  __syncthreads();
+  dbg_t[2] = __builtin_amdgcn_s_memtime();
+#endif
   // ---- P3: the nodes ----------------------------------------------------------------------
+  // A lane decodes G consecutive nodes of ONE frame: the per-frame arithmetic (table look-ups,
+  // angle step, the divisions) is paid once per group, the payload arrives in one or two wide
+  // loads and the nodes leave in 16-byte stores.  (One node per lane and pass, as in round 1,
+  // spent ~85 instructions per node, most of them per-frame work repeated 40 times, behind a
+  // chain of four dependent loads.)  Sync nodes are rare (one or two per revolution): they are
+  // reported through LDS / global atomics instead of a ballot per pass.
   const int last_sync_in = state_in ? state_in[4 * b] : 0;
   const int last_dist_in = state_in ? state_in[4 * b + 1] : 0;
-  for (uint32_t i0 = 0; i0 < carry_nodes; i0 += kDecBlock) {
-    const uint32_t i = i0 + tid;
-    const bool live = i < carry_nodes;
-    uint2 node = make_uint2(0u, 0u);
-    uint32_t raw_sync = 0;
-    if (live) {
-      const uint32_t e = i / NPF, pos = i - e * NPF;
-      const uint32_t k = DecCfg<ANS>::kTable ? L.emit_frame[e] : e;
-      if (ANS == RPLGPU_ANS_MEASUREMENT) {  // handler_normalnode.cpp:121-130
-        const uint8_t *f = frame_ptr(k);
-        const uint32_t b0 = ld8(f), aq = ld16(f + 1), d = ld16(f + 3);
-        const uint32_t q14 = (((aq >> 1) << 8) / 90u) & 0xFFFFu;
-        node.x = q14 | (d << 16);
-        node.y = (((b0 >> 2) << 2) << 16) | ((b0 & 1u) << 24);
-      } else if (ANS == RPLGPU_ANS_HQ) {  // handler_hqnode.cpp:150-160: verbatim copy
-        const uint8_t *f = frame_ptr(k) + 9u + 8u * pos;
-        node.x = ld32(f);
-        node.y = ld32(f + 4);
-      } else {
-        const uint8_t *prev = frame_ptr(k - 1), *cur = frame_ptr(k);
-        // signed arithmetic throughout, as in the reference: a corrupted-but-checksummed start
-        // angle above 360 deg makes the step (and everything derived from it) negative
-        const int cur_q8 = (int)(L.frame[k] & 0x7FFFu) << 2;
-        const int prev_q8 = (int)(L.frame[k - 1] & 0x7FFFu) << 2;
-        int diff_q8 = cur_q8 - prev_q8;
-        if (prev_q8 > cur_q8) diff_q8 += (360 << 8);
-        if (ANS == RPLGPU_ANS_CAPSULED) {  // :206-260
-          const int inc = diff_q8 << 3;
-          const int ang = (prev_q8 << 8) + (int)pos * inc;
-          const uint8_t *c = prev + 4u + 5u * (pos >> 1);
-          const uint32_t da = ld16(c + 2u * (pos & 1u)), offs = ld8(c + 4);
-          const int dist = (int)(da & 0xFFFCu);
-          const int aoff = (int)(((pos & 1u) ? (offs >> 4) : (offs & 0xFu)) | ((da & 0x3u) << 4));
-          const int angle_q6 = (ang - (aoff << 13)) >> 10;
-          const uint32_t sync = (((ang + inc) % (360 << 16)) < inc) ? 1u : 0u;
-          node = make_node(angle_q6, (uint32_t)dist, dist ? (0x2Fu << 2) : 0u, sync);
-        } else if (ANS == RPLGPU_ANS_CAPSULED_ULTRA) {  // :460-577
-          const int inc = (diff_q8 << 3) / 3;
-          const int ang = (prev_q8 << 8) + (int)pos * inc;
-          const uint32_t cab = pos / 3u, j = pos - cab * 3u;
-          const uint32_t cx = ld32(prev + 4u + 4u * cab);
-          const uint32_t nx = (cab == 31u) ? ld32(cur + 4u) : ld32(prev + 4u + 4u * (cab + 1u));
-          uint32_t lvl1, lvl2;
-          const int major = (int)varbitscale(cx & 0xFFFu, lvl1);
-          const int major2 = (int)varbitscale(nx & 0xFFFu, lvl2);
-          int dist;
-          if (j == 0u) {
-            dist = major << 2;
+  constexpr uint32_t G = DecCfg<ANS>::kGroup, GPF = NPF / G;
+  static_assert(GPF * G == NPF, "groups tile a frame");
+  const uint32_t n_groups = carry_emit * GPF;
+  uint32_t *my_sync = sync_at ? sync_at + (size_t)b * sync_stride : nullptr;
+  auto report_sync = [&](uint32_t i) {  // node i carries the sync flag (and is inside the output)
+    const uint32_t slot = atomicAdd(&L.misc[6], 1u);
+    if (my_sync && slot < sync_stride) my_sync[slot] = i;
+  };
+  // What a group needs from memory (fetched for U groups before the first one is decoded: the
+  // frame-table look-ups and the payload loads of the next groups travel while this one is
+  // being computed — one group per trip left the kernel waiting on a chain of dependent loads)
+  struct GroupIn {
+    uint32_t pos0, off_prev, off_cur;  // byte offsets of the frames k-1 and k in the stream
+    int prev_q8, diff_q8;
+    uint64_t w;   // first 8 payload bytes of the group
+    uint32_t w2;  // the bytes after them (express / ultra-dense: 2, ultra: the next cabin word)
+    uint4 a, c;   // HQ: the four nodes
+  };
+  auto locate = [&](uint32_t t, GroupIn &g) {  // which frames, where (table look-ups only)
+    const uint32_t e = t / GPF, q = t - e * GPF;
+    g.pos0 = q * G;
+    const uint32_t k = DecCfg<ANS>::kTable ? (uint32_t)L.emit_frame[e] : e;
+    constexpr bool kPrev = CAPS;  // capsule types decode frame k-1 with frame k's start angle
+    if (FRAMED) {
+      g.off_cur = foff[k];
+      g.off_prev = kPrev ? foff[k - 1u] : 0u;
+    } else {
+      g.off_cur = k * S;
+      g.off_prev = kPrev ? (k - 1u) * S : 0u;
+    }
+    if (CAPS) {
+      // signed arithmetic throughout, as in the reference: a corrupted-but-checksummed start
+      // angle above 360 deg makes the step (and everything derived from it) negative
+      const int cur_q8 = (int)(L.frame[k] & 0x7FFFu) << 2;
+      g.prev_q8 = (int)(L.frame[k - 1] & 0x7FFFu) << 2;
+      g.diff_q8 = cur_q8 - g.prev_q8;
+      if (g.prev_q8 > cur_q8) g.diff_q8 += (360 << 8);
+    }
+  };
+  auto fetch = [&](GroupIn &g) {  // the payload loads (nothing here waits for another load)
+    if (ANS == RPLGPU_ANS_MEASUREMENT) {
+      const uint8_t *f = base + g.off_cur;
+      g.w = (uint64_t)ld8(f) | ((uint64_t)ld16(f + 1) << 8) | ((uint64_t)ld16(f + 3) << 24);
+    } else if (ANS == RPLGPU_ANS_HQ) {
+      const uint8_t *f = base + g.off_cur + 9u + 8u * g.pos0;
+      g.a = ld128(f);
+      g.c = ld128(f + 16);
+    } else {
+      const uint8_t *prev = base + g.off_prev;
+      if (ANS == RPLGPU_ANS_CAPSULED) {  // two cabins of 5 bytes
+        const uint8_t *c = prev + 4u + 5u * (g.pos0 >> 1);
+        g.w = ld64(c);
+        g.w2 = ld16(c + 8);
+      } else if (ANS == RPLGPU_ANS_CAPSULED_ULTRA) {  // two cabins of 4 bytes + the one behind
+        const uint32_t cab0 = g.pos0 / 3u;  // even
+        g.w = ld64(prev + 4u + 4u * cab0);
+        g.w2 = (cab0 + 2u == 32u) ? ld32(base + g.off_cur + 4u) : ld32(prev + 4u + 4u * (cab0 + 2u));
+      } else if (ANS == RPLGPU_ANS_DENSE_CAPSULED) {  // four 16-bit distances
+        g.w = ld64(prev + 4u + 2u * g.pos0);
+      } else {  // ultra dense: two cabins of 5 bytes
+        const uint8_t *c = prev + 10u + 5u * (g.pos0 >> 1);
+        g.w = ld64(c);
+        g.w2 = ld16(c + 8);
+      }
+    }
+  };
+  auto emit = [&](uint32_t t, const GroupIn &g) {
+    const uint32_t i = t * G, pos0 = g.pos0;
+    const int prev_q8 = g.prev_q8, diff_q8 = g.diff_q8;
+    uint2 nd[G];
+    uint32_t rs = 0;  // bit j: node j of the group has its (raw) sync bit set
+    if (ANS == RPLGPU_ANS_MEASUREMENT) {  // handler_normalnode.cpp:121-130
+      const uint32_t b0 = (uint32_t)g.w & 0xFFu, aq = (uint32_t)(g.w >> 8) & 0xFFFFu, d = (uint32_t)(g.w >> 24) & 0xFFFFu;
+      const uint32_t q14 = (((aq >> 1) << 8) / 90u) & 0xFFFFu;
+      nd[0].x = q14 | (d << 16);
+      nd[0].y = (((b0 >> 2) << 2) << 16) | ((b0 & 1u) << 24);
+      rs = b0 & 1u;
+    } else if (ANS == RPLGPU_ANS_HQ) {  // handler_hqnode.cpp:150-160: verbatim copy
+      nd[0] = make_uint2(g.a.x, g.a.y);
+      nd[G > 1 ? 1 : 0] = make_uint2(g.a.z, g.a.w);
+      nd[G > 2 ? 2 : 0] = make_uint2(g.c.x, g.c.y);
+      nd[G > 3 ? 3 : 0] = make_uint2(g.c.z, g.c.w);
+#pragma unroll
+      for (uint32_t j = 0; j < G; ++j) rs |= ((nd[j].y >> 24) & 1u) << j;
+    } else if (ANS == RPLGPU_ANS_CAPSULED) {  // :206-260 — two cabins of 5 bytes = 4 nodes
+      const int inc = diff_q8 << 3;
+      const uint64_t cab[2] = {g.w & 0xFFFFFFFFFFull, (g.w >> 40) | ((uint64_t)g.w2 << 24)};
+#pragma unroll
+      for (uint32_t j = 0; j < G; ++j) {
+        const uint32_t pos = pos0 + j;
+        const int ang = (prev_q8 << 8) + (int)pos * inc;
+        const uint64_t cb = cab[j >> 1];
+        const uint32_t da = (uint32_t)(cb >> (16u * (j & 1u))) & 0xFFFFu, offs = (uint32_t)(cb >> 32) & 0xFFu;
+        const int dist = (int)(da & 0xFFFCu);
+        const int aoff = (int)(((j & 1u) ? (offs >> 4) : (offs & 0xFu)) | ((da & 0x3u) << 4));
+        const int angle_q6 = (ang - (aoff << 13)) >> 10;
+        const uint32_t sync = (((ang + inc) % (360 << 16)) < inc) ? 1u : 0u;
+        nd[j] = make_node(angle_q6, (uint32_t)dist, dist ? (0x2Fu << 2) : 0u, sync);
+        rs |= sync << j;
+      }
+    } else if (ANS == RPLGPU_ANS_CAPSULED_ULTRA) {  // :460-577 — two cabins of 4 bytes = 6 nodes
+      const int inc = (diff_q8 << 3) / 3;
+      const uint32_t cw[3] = {(uint32_t)g.w, (uint32_t)(g.w >> 32), g.w2};
+      uint32_t lvl[3];
+      int major[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) major[c] = (int)varbitscale(cw[c] & 0xFFFu, lvl[c]);
+#pragma unroll
+      for (uint32_t j = 0; j < G; ++j) {
+        const uint32_t pos = pos0 + j, cb = j / 3u, jj = j - cb * 3u;
+        const int ang = (prev_q8 << 8) + (int)pos * inc;
+        const uint32_t cx = cw[cb];
+        const int mj = major[cb], mj2 = major[cb + 1u];
+        const uint32_t lvl1 = lvl[cb], lvl2 = lvl[cb + 1u];
+        int dist;
+        if (jj == 0u) {
+          dist = mj << 2;
+        } else {
+          int pred = (jj == 1u) ? (((int)(cx << 10)) >> 22) : (((int)cx) >> 22);
+          if ((uint32_t)pred == 0xFFFFFE00u || (uint32_t)pred == 0x1FFu) {
+            dist = 0;
+          } else if (jj == 1u) {
+            int base1 = mj;
+            uint32_t l1 = lvl1;
+            if (!mj && mj2) { base1 = mj2; l1 = lvl2; }
+            pred = (int)((uint32_t)pred << l1);
+            dist = (int)((uint32_t)(pred + base1) << 2);
           } else {
-            int pred = (j == 1u) ? (((int)(cx << 10)) >> 22) : (((int)cx) >> 22);
-            if ((uint32_t)pred == 0xFFFFFE00u || (uint32_t)pred == 0x1FFu) {
-              dist = 0;
-            } else if (j == 1u) {
-              int base1 = major;
-              uint32_t l1 = lvl1;
-              if (!major && major2) { base1 = major2; l1 = lvl2; }
-              pred = (int)((uint32_t)pred << l1);
-              dist = (int)((uint32_t)(pred + base1) << 2);
-            } else {
-              pred = (int)((uint32_t)pred << lvl2);
-              dist = (int)((uint32_t)(pred + major2) << 2);
-            }
+            pred = (int)((uint32_t)pred << lvl2);
+            dist = (int)((uint32_t)(pred + mj2) << 2);
           }
-          const uint32_t sync = (((ang + inc) % (360 << 16)) < inc) ? 1u : 0u;
-          int off_q16 = (int)(7.5 * 3.1415926535 * (1 << 16) / 180.0);
-          if (dist >= (50 * 4)) {  // triangulation angle correction :547-553
-            const int k1 = 98361;
-            const int k2 = k1 / dist;
-            off_q16 = (int)(8 * 3.1415926535 * (1 << 16) / 180) - (k2 << 6) - (k2 * k2 * k2) / 98304;
-          }
-          const int angle_q6 = (ang - (int)((double)(off_q16 * 180) / 3.14159265)) >> 10;
-          node = make_node(angle_q6, (uint32_t)dist, dist ? (0x2Fu << 2) : 0u, sync);
-        } else if (ANS == RPLGPU_ANS_DENSE_CAPSULED) {  // :756-784
-          const int inc = (diff_q8 << 8) / 40;
-          const int ang = (prev_q8 << 8) + (int)pos * inc;
-          const int dist = (int)ld16(prev + 4u + 2u * pos) << 2;
-          raw_sync = (((ang + inc) % (360 << 16)) < (inc * 2)) ? 1u : 0u;
-          node = make_node(ang >> 10, (uint32_t)dist, dist ? (0x2Fu << 2) : 0u, 0u);
-        } else {  // ultra dense :979-1045
-          const int inc = (diff_q8 << 8) / 64;
-          const int ang = (prev_q8 << 8) + (int)pos * inc;
-          const uint8_t *c = prev + 10u + 5u * (pos >> 1);
-          const uint32_t q4 = ld8(c + 4);
-          const uint32_t qds = ld16(c + 2u * (pos & 1u)) | (((pos & 1u) ? (q4 >> 4) : (q4 & 0xFu)) << 16);
-          const uint32_t scale = qds & 3u;
-          uint32_t quality, dist;
-          if (scale == 0u) { quality = qds >> 12; dist = (qds & 0xFFCu) * 2u; }
-          else if (scale == 1u) { quality = (qds >> 13) << 1; dist = (qds & 0x1FFCu) * 3u + (2046u << 2); }
-          else if (scale == 2u) { quality = (qds >> 14) << 2; dist = (qds & 0x3FFCu) * 4u + (8187u << 2); }
-          else { quality = (qds >> 15) << 3; dist = (qds & 0x7FFCu) * 5u + (24567u << 2); }
-          raw_sync = (((ang + inc) % (360 << 16)) < (inc * 2)) ? 1u : 0u;
-          node = make_node(ang >> 10, dist, quality, 0u);
-          // raw distance for the smoothing pass: scale 0 -> bit 15 + value (<= 8184);
-          // other scales only matter as "last distance" of a scale-0 successor, whose rule
-          // |d - last| <= 8 can hold only if last <= 8192: store min(dist, 0x3FFF)
-          L.smooth[i] = (uint16_t)(scale == 0u ? (0x8000u | dist) : min(dist, 0x3FFFu));
+        }
+        const uint32_t sync = (((ang + inc) % (360 << 16)) < inc) ? 1u : 0u;
+        // triangulation angle correction :547-556, from the table (see the kernel's head);
+        // k2 = 98361 / dist exactly: dist < 2^24, so the float quotient is off by at most one
+        uint32_t slot = 492u;
+        if (dist >= (50 * 4)) {
+          uint32_t k2 = (uint32_t)(98361.0f * __builtin_amdgcn_rcpf((float)dist));
+          int r = 98361 - (int)(k2 * (uint32_t)dist);
+          if (r < 0) { --k2; r += dist; }
+          if (r >= dist) ++k2;
+          slot = k2;
+        }
+        const int angle_q6 = (ang - L.corr[slot]) >> 10;
+        nd[j] = make_node(angle_q6, (uint32_t)dist, dist ? (0x2Fu << 2) : 0u, sync);
+        rs |= sync << j;
+      }
+    } else if (ANS == RPLGPU_ANS_DENSE_CAPSULED) {  // :756-784 — four 16-bit distances
+      const int inc = (diff_q8 << 8) / 40;
+#pragma unroll
+      for (uint32_t j = 0; j < G; ++j) {
+        const int ang = (prev_q8 << 8) + (int)(pos0 + j) * inc;
+        const int dist = (int)((uint32_t)(g.w >> (16u * j)) & 0xFFFFu) << 2;
+        rs |= ((((ang + inc) % (360 << 16)) < (inc * 2)) ? 1u : 0u) << j;
+        nd[j] = make_node(ang >> 10, (uint32_t)dist, dist ? (0x2Fu << 2) : 0u, 0u);
+      }
+    } else {  // ultra dense :979-1045 — two cabins of 5 bytes = 4 nodes
+      const int inc = (diff_q8 << 8) / 64;
+      const uint64_t cab[2] = {g.w & 0xFFFFFFFFFFull, (g.w >> 40) | ((uint64_t)g.w2 << 24)};
+      uint32_t sm[G];
+#pragma unroll
+      for (uint32_t j = 0; j < G; ++j) {
+        const int ang = (prev_q8 << 8) + (int)(pos0 + j) * inc;
+        const uint64_t cb = cab[j >> 1];
+        const uint32_t q4 = (uint32_t)(cb >> 32) & 0xFFu;
+        const uint32_t qds = ((uint32_t)(cb >> (16u * (j & 1u))) & 0xFFFFu) |
+                             (((j & 1u) ? (q4 >> 4) : (q4 & 0xFu)) << 16);
+        const uint32_t scale = qds & 3u;
+        uint32_t quality, dist;
+        if (scale == 0u) { quality = qds >> 12; dist = (qds & 0xFFCu) * 2u; }
+        else if (scale == 1u) { quality = (qds >> 13) << 1; dist = (qds & 0x1FFCu) * 3u + (2046u << 2); }
+        else if (scale == 2u) { quality = (qds >> 14) << 2; dist = (qds & 0x3FFCu) * 4u + (8187u << 2); }
+        else { quality = (qds >> 15) << 3; dist = (qds & 0x7FFCu) * 5u + (24567u << 2); }
+        rs |= ((((ang + inc) % (360 << 16)) < (inc * 2)) ? 1u : 0u) << j;
+        nd[j] = make_node(ang >> 10, dist, quality, 0u);
+        // raw distance for the smoothing pass: scale 0 -> bit 15 + value (<= 8184);
+        // other scales only matter as "last distance" of a scale-0 successor, whose rule
+        // |d - last| <= 8 can hold only if last <= 8192: store min(dist, 0x3FFF)
+        sm[j] = scale == 0u ? (0x8000u | dist) : min(dist, 0x3FFFu);
+      }
+      if (i + G <= DecCfg<ANS>::kSmoothSlots)  // (always: emitted frames <= kUdMaxFrames)
+        *reinterpret_cast<uint2 *>(&L.smooth[i]) =
+            make_uint2(sm[0] | (sm[G > 1 ? 1 : 0] << 16), sm[G > 2 ? 2 : 0] | (sm[G > 3 ? 3 : 0] << 16));
+    }
+#ifdef RPL_DEC_NOSTORE
+    {
+      uint32_t hsh = rs;
+#pragma unroll
+      for (uint32_t j = 0; j < G; ++j) hsh = hsh * 31u + nd[j].x + nd[j].y;
+      if (hsh != 0xDEADBEEFu) return;
+    }
+#endif
+    if (i + G <= n_out) {  // dense types: the (rare) sync flags are set in P4
+      if (G == 1) {
+        out[i] = nd[0];
+      } else {
+#pragma unroll
+        for (uint32_t j = 0; j + 1u < G; j += 2u) {
+          const uint4 v = make_uint4(nd[j].x, nd[j].y, nd[j + 1u].x, nd[j + 1u].y);
+          __builtin_memcpy(out + i + j, &v, 16);
+        }
+      }
+    } else {
+#pragma unroll
+      for (uint32_t j = 0; j < G; ++j)
+        if (i + j < n_out) out[i + j] = nd[j];
+    }
+    if (rs) {
+#pragma unroll
+      for (uint32_t j = 0; j < G; ++j) {
+        if (!((rs >> j) & 1u)) continue;
+        if (FILTERED) {
+          if (((i + j) >> 6) < kRawBitWords) atomicOr(&L.rawbits[(i + j) >> 6], 1ull << ((i + j) & 63u));
+        } else if (i + j < n_out) {
+          report_sync(i + j);
         }
       }
     }
-    if (FILTERED) {  // raw sync bits of 64 consecutive nodes -> one LDS word
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(live && raw_sync);
-      if (lane_id() == 0 && (i >> 6) < kRawBitWords) L.rawbits[i >> 6] = m;
-    }
-    if (live && i < n_out) out[i] = node;  // dense types: the (rare) sync flags are set in P4
+  };
+  // U groups per lane and trip: all table look-ups, then all payload loads, then the decoding —
+  // the loads of a trip travel together.  (Tried and dropped, profiles/r02/decode_study.txt:
+  // issuing trip n+1's loads before trip n is decoded and stored.  The vector-memory counter
+  // orders loads among loads and stores among stores but not one against the other, so a wave
+  // that has stores in flight can only wait for "everything"; the dense kernel is
+  // (decode + loads) + (stores) = 0.19 + 0.21 ms, not the larger of the two.)
+  constexpr uint32_t U = ANS == RPLGPU_ANS_HQ ? 2u : 4u;
+  uint32_t t0 = tid;
+  for (; t0 + (U - 1u) * kDecBlock < n_groups; t0 += U * kDecBlock) {  // full trips: no conditions
+    GroupIn gi[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) locate(t0 + u * kDecBlock, gi[u]);
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) fetch(gi[u]);
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) emit(t0 + u * kDecBlock, gi[u]);
+  }
+  for (; t0 < n_groups; t0 += kDecBlock) {
+    GroupIn g1;
+    locate(t0, g1);
+    fetch(g1);
+    emit(t0, g1);
   }
 
+#ifdef RPL_DEC_DBG
+  __syncthreads();
+  dbg_t[3] = __builtin_amdgcn_s_memtime();
+#endif
   // ---- P4 (dense / ultra-dense): the sync-bit filter, s_i = r_i & ~s_{i-1} -------------------
   int last_sync_out = last_sync_in, last_dist_out = last_dist_in;
   if (FILTERED) {
@@ -488,6 +718,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
           uint2 v = out[i];
           v.y = (v.y & 0x00FFFFFFu) | (1u << 24);
           out[i] = v;
+          report_sync(i);
         }
         if (i == carry_nodes - 1u) L.misc[3] = s;  // carried-out state
       }
@@ -500,6 +731,10 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     if (carry_nodes) last_sync_out = (int)L.misc[3];
   }
 
+#ifdef RPL_DEC_DBG
+  __syncthreads();
+  dbg_t[4] = __builtin_amdgcn_s_memtime();
+#endif
   // ---- P5 (ultra-dense): distance smoothing (:997-1003, :1020) -------------------------------
   // out_i = smooth(d_i, out_{i-1}) is a recurrence, but a smoothed value stays within +-4 of its
   // raw value, so "out_{i-1} - d_{i-1} + 4" is one of 9 states and every node is a map from
@@ -533,13 +768,34 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     const uint32_t N = carry_nodes;
     const uint32_t seg = (N + kDecBlock - 1u) / kDecBlock;
     const uint32_t i_lo = min(tid * seg, N), i_hi = min(i_lo + seg, N);
-    // pass A: the segment as one map (all 9 entry states at once; they usually collapse fast)
+    auto patch = [&](uint32_t i, int st) {  // node i has state st: patch dist_mm_q2 if smoothed
+      if (st != 4 && i < n_out) {  // (bits 16.. of the packed node)
+        const uint32_t d = (uint32_t)(rawd(i) + st - 4);
+        uint2 v = out[i];
+        v.x = (v.x & 0xFFFFu) | (d << 16);
+        v.y = (v.y & 0xFFFF0000u) | (d >> 16);
+        out[i] = v;
+      }
+      if (i == N - 1u && is_s0(i)) L.misc[4] = (uint32_t)(rawd(i) + st - 4) | 0x80000000u;
+    };
+    // pass A: the segment as one map.  All 9 entry states are tracked only until the map's
+    // image has shrunk to two values (smoothing halves differences: a few nodes), then only
+    // those two (which entry state leads to which is fixed from there on), and once they have
+    // met — the first node that is not scale 0, follows a zero or jumps by more than 12 forgets
+    // its predecessor; past ~2 m every node does — the segment's states no longer depend on
+    // what came before it: they are final and written right away.  (A constant distance keeps
+    // two states apart for ever: (x >> 1) has the fixed points 0 and -1.)
     unsigned long long M = kIdent;
+    uint32_t i_open = i_hi;  // [i_lo, i_open): states that depend on the entry state (pass C)
     if (i_lo < i_hi) {
       int cur[9];
 #pragma unroll
       for (int c = 0; c < 9; ++c) cur[c] = c;
-      for (uint32_t i = i_lo; i < i_hi; ++i) {
+      uint32_t i = i_lo;
+      int va = 0, vb = 0;
+      uint32_t in_b = 0;  // entry states that lead to vb (the others lead to va)
+      bool two = false;
+      for (; i < i_hi && !two; ++i) {
         if (i == 0u) {
           const int st0 = step(0u, last_dist_in);
 #pragma unroll
@@ -549,6 +805,35 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
 #pragma unroll
           for (int c = 0; c < 9; ++c) cur[c] = step(i, pd + cur[c] - 4);
         }
+        va = cur[0];
+        vb = va;
+#pragma unroll
+        for (int c = 1; c < 9; ++c) vb = (cur[c] != va) ? cur[c] : vb;
+        two = true;
+        in_b = 0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+          two = two && (cur[c] == va || cur[c] == vb);
+          in_b |= (cur[c] != va ? 1u : 0u) << c;
+        }
+      }
+      if (two) {
+        for (; i < i_hi && va != vb; ++i) {
+          const int pd = rawd(i - 1u);
+          va = step(i, pd + va - 4);
+          vb = step(i, pd + vb - 4);
+        }
+        if (va == vb) {
+          i_open = i - 1u;  // node i-1 merged the last two states: it has state va whatever the entry
+          patch(i - 1u, va);
+          for (; i < i_hi; ++i) {
+            va = step(i, rawd(i - 1u) + va - 4);
+            patch(i, va);
+          }
+          vb = va;
+        }
+#pragma unroll
+        for (int c = 0; c < 9; ++c) cur[c] = ((in_b >> c) & 1u) ? vb : va;
       }
       M = 0;
 #pragma unroll
@@ -577,18 +862,11 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     // every map in front of a non-empty segment starts with node 0's constant map, so any
     // entry state (take 4) gives the state its predecessor node really has
     int sp = (int)((excl >> (4 * 4)) & 15ull);
-    // pass C: the walk with the true entry state
-    for (uint32_t i = i_lo; i < i_hi; ++i) {
+    // pass C: the (usually empty) head of the segment, with the true entry state
+    for (uint32_t i = i_lo; i < min(i_open, i_hi); ++i) {
       const int last = (i == 0u) ? last_dist_in : rawd(i - 1u) + sp - 4;
       sp = step(i, last);
-      if (sp != 4 && i < n_out) {  // patch dist_mm_q2 (bits 16.. of the packed node)
-        const uint32_t d = (uint32_t)(rawd(i) + sp - 4);
-        uint2 v = out[i];
-        v.x = (v.x & 0xFFFFu) | (d << 16);
-        v.y = (v.y & 0xFFFF0000u) | (d >> 16);
-        out[i] = v;
-      }
-      if (i == N - 1u && is_s0(i)) L.misc[4] = (uint32_t)(rawd(i) + sp - 4) | 0x80000000u;
+      patch(i, sp);
     }
     __syncthreads();
     if (L.misc[4] & 0x80000000u) {
@@ -607,6 +885,10 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     }
   }
 
+#ifdef RPL_DEC_DBG
+  __syncthreads();
+  dbg_t[5] = __builtin_amdgcn_s_memtime();
+#endif
   // ---- per-stream results ---------------------------------------------------------------------
   for (int d = 32; d > 0; d >>= 1) my_err += (uint32_t)__shfl_xor((int)my_err, d, 64);
   if (lane_id() == 0 && my_err) atomicAdd(&L.misc[5], my_err);
@@ -618,7 +900,13 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     if (FILTERED && carry_nodes > kRawBitWords * 64u) st |= RPLGPU_STREAM_FRAMES_TRUNCATED;
     n_nodes[b] = bad_framing ? 0u : n_out;
     if (n_reset) n_reset[b] = bad_framing ? 0u : min(carry_reset, reset_at ? reset_stride : carry_reset);
+#ifdef RPL_DEC_DBG
+    if (reset_at && reset_stride >= 8)
+      for (int d = 0; d < 5; ++d) reset_at[(size_t)b * reset_stride + 3 + d] = (uint32_t)(dbg_t[d + 1] - dbg_t[d]);
+#endif
     if (n_errors) n_errors[b] = L.misc[5];
+    if (n_sync) n_sync[b] = bad_framing ? 0u : min(L.misc[6], sync_stride);
+    if (my_sync && L.misc[6] > sync_stride) st |= RPLGPU_STREAM_FRAMES_TRUNCATED;
     if (status) status[b] = st;
     if (state_out) {
       state_out[4 * b] = bad_framing ? last_sync_in : last_sync_out;
@@ -647,7 +935,8 @@ __global__ __launch_bounds__(kDecBlock) void k_segment(
     const uint32_t *__restrict__ reset_at, uint32_t reset_stride, const uint32_t *__restrict__ n_reset,
     uint32_t max_count, uint2 *__restrict__ out_nodes, uint32_t out_stride,
     uint32_t *__restrict__ scan_off, uint32_t scan_cap, uint32_t *__restrict__ n_scans,
-    uint32_t *__restrict__ status) {
+    uint32_t *__restrict__ status, const uint32_t *__restrict__ sync_at, uint32_t sync_stride,
+    const uint32_t *__restrict__ n_sync) {
   __shared__ uint32_t sync_pos[kSegMaxSync + 1];
   __shared__ uint32_t scan_len[kSegMaxSync];  // 0 = not completed
   __shared__ uint32_t tmp[40];
@@ -665,12 +954,23 @@ __global__ __launch_bounds__(kDecBlock) void k_segment(
   __shared__ uint32_t unsorted[kSegMaxSync + 1];
   if (tid == 0) tmp[32] = 0u;
   __syncthreads();
-  for (uint32_t i0 = 0; i0 < n; i0 += kDecBlock) {
-    const uint32_t i = i0 + tid;
-    const bool is = i < n && ((in[i].y >> 24) & 1u);
-    if (__builtin_amdgcn_ballot_w64(is) != 0ull && is) {
-      const uint32_t slot = atomicAdd(&tmp[32], 1u);
-      if (slot <= kSegMaxSync) unsorted[slot] = i;
+  if (sync_at) {  // the decoder's (unordered) list of sync nodes: no pass over the stream
+    const uint32_t ns = min(n_sync[b], sync_stride);
+    for (uint32_t j = tid; j < ns; j += kDecBlock) {
+      const uint32_t i = sync_at[(size_t)b * sync_stride + j];
+      if (i < n) {
+        const uint32_t slot = atomicAdd(&tmp[32], 1u);
+        if (slot <= kSegMaxSync) unsorted[slot] = i;
+      }
+    }
+  } else {
+    for (uint32_t i0 = 0; i0 < n; i0 += kDecBlock) {
+      const uint32_t i = i0 + tid;
+      const bool is = i < n && ((in[i].y >> 24) & 1u);
+      if (__builtin_amdgcn_ballot_w64(is) != 0ull && is) {
+        const uint32_t slot = atomicAdd(&tmp[32], 1u);
+        if (slot <= kSegMaxSync) unsorted[slot] = i;
+      }
     }
   }
   __syncthreads();
@@ -730,6 +1030,115 @@ __global__ __launch_bounds__(kDecBlock) void k_segment(
   }
 }
 
+// Scan assembly straight into the batch layout: the same rules as k_segment, but the sync nodes
+// come from the decoder's list and completed scan s of stream b is written to batch slot
+// g = b * scan_cap + s (n_per_scan[g] = its length, 0 for the slots a stream does not fill) —
+// no pass over the node stream to find the sync nodes, no intermediate copy, no prefix over
+// streams.  One workgroup per (slot, stream): each redoes the (tiny) judgement and copies its
+// own scan.
+__global__ __launch_bounds__(kDecBlock) void k_assemble(
+    const uint2 *__restrict__ nodes, uint32_t node_stride, const uint32_t *__restrict__ n_nodes,
+    const uint32_t *__restrict__ sync_at, uint32_t sync_stride, const uint32_t *__restrict__ n_sync,
+    const uint32_t *__restrict__ reset_at, uint32_t reset_stride, const uint32_t *__restrict__ n_reset,
+    uint32_t max_count, uint2 *__restrict__ batch, uint32_t n_stride, uint32_t scan_cap,
+    uint32_t *__restrict__ n_per_scan, uint32_t *__restrict__ n_scans, uint32_t *__restrict__ status, uint32_t dbg_mode) {
+  __shared__ uint32_t sync_pos[kSegMaxSync + 1];
+  __shared__ uint32_t unsorted[kSegMaxSync + 1];
+  __shared__ uint32_t tmp[8];
+  // (stream index fastest: consecutive workgroup ids go round the XCDs, and the workgroups that
+  // have a scan to copy are mostly those of slot 0 — with the slot fastest and scan_cap = 4 all
+  // of them landed on two of the eight XCDs: 0.50 ms instead of 0.2 ms per 0.5 GB)
+  const uint32_t b = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x;
+  const uint2 *in = nodes + (size_t)b * node_stride;
+  const uint32_t n = min(n_nodes[b], node_stride);
+  const uint32_t nr = (reset_at && n_reset) ? min(n_reset[b], reset_stride) : 0u;
+  const uint32_t *rs = reset_at ? reset_at + (size_t)b * reset_stride : nullptr;
+  if (tid == 0) tmp[0] = 0u;
+  __syncthreads();
+  const uint32_t ns_in = min(n_sync[b], sync_stride);
+  for (uint32_t j = tid; j < ns_in; j += kDecBlock) {
+    const uint32_t i = sync_at[(size_t)b * sync_stride + j];
+    if (i < n) {
+      const uint32_t at = atomicAdd(&tmp[0], 1u);
+      if (at <= kSegMaxSync) unsorted[at] = i;
+    }
+  }
+  __syncthreads();
+  uint32_t st = 0;
+  uint32_t nsync = tmp[0];
+  if (nsync > kSegMaxSync + 1u) {
+    st |= RPLGPU_STREAM_FRAMES_TRUNCATED;
+    nsync = kSegMaxSync + 1u;
+  }
+  for (uint32_t j = tid; j < nsync; j += kDecBlock) {
+    const uint32_t v = unsorted[j];
+    uint32_t rank = 0;
+    for (uint32_t q = 0; q < nsync; ++q) rank += unsorted[q] < v ? 1u : 0u;
+    sync_pos[rank] = v;
+  }
+  __syncthreads();
+  const uint32_t ncand = nsync ? nsync - 1u : 0u;
+  // the slot-th completed scan: candidates in order (a stream holds a handful; one lane walks)
+  if (tid == 0) {
+    uint32_t completed = 0, mine = 0xFFFFFFFFu;
+    uint32_t ri = 0;  // reset positions <= s0 so far (both lists ascend)
+    for (uint32_t j = 0; j < ncand; ++j) {
+      const uint32_t s0 = sync_pos[j], s1 = sync_pos[j + 1];
+      while (ri < nr && rs[ri] <= s0) ++ri;
+      const bool broken = ri < nr && rs[ri] <= s1;  // a reset position p with s0 < p <= s1
+      if (!broken) {
+        if (completed == slot) mine = j;
+        ++completed;
+      }
+    }
+    tmp[1] = mine;
+    tmp[2] = completed;
+  }
+  __syncthreads();
+  const uint32_t mine = tmp[1], completed = tmp[2];
+  const uint32_t g = b * scan_cap + slot;
+  if (slot == 0 && tid == 0) {
+    n_scans[b] = min(completed, scan_cap);
+    if (completed > scan_cap) st |= RPLGPU_STREAM_RESETS_TRUNCATED;
+  }
+  uint32_t len = 0;
+  if (mine != 0xFFFFFFFFu && !(dbg_mode & 1u)) {
+    const uint32_t s0 = sync_pos[mine], s1 = sync_pos[mine + 1];
+    const uint32_t full = min(s1 - s0, max_count);  // ScanDataHolder keeps max_count nodes
+    len = min(full, n_stride);
+    if (full > n_stride) st |= RPLGPU_SCAN_OUT_TRUNCATED;
+    uint2 *dst = batch + (size_t)g * n_stride;
+    const uint2 *src = in + s0;
+    // 16-byte copies, four in flight; a scan starts at any node, so the two sides are only
+    // 8-byte aligned (the target runs in unaligned access mode: a 1 KiB wave access that starts
+    // 8 bytes into a line touches nine lines instead of eight)
+    const uint32_t body = len ? len - 1u : 0u;  // the last slot may come from the scan's end
+    const uint32_t n4 = body >> 1;
+    auto ld = [&](uint32_t t) { uint4 v; __builtin_memcpy(&v, src + 2u * t, 16); return v; };
+    auto st16 = [&](uint32_t t, const uint4 &v) { __builtin_memcpy(dst + 2u * t, &v, 16); };
+    uint32_t t = tid;
+    for (; t + 3u * kDecBlock < n4; t += 4u * kDecBlock) {
+      const uint4 a = ld(t), c = ld(t + kDecBlock), d = ld(t + 2u * kDecBlock), e = ld(t + 3u * kDecBlock);
+      st16(t, a);
+      st16(t + kDecBlock, c);
+      st16(t + 2u * kDecBlock, d);
+      st16(t + 3u * kDecBlock, e);
+    }
+    for (; t < n4; t += kDecBlock) st16(t, ld(t));
+    if (tid == 0 && (body & 1u)) dst[body - 1u] = src[body - 1u];
+    if (tid == 0 && len) {
+      // a scan longer than max_count kept overwriting its last slot: that slot holds the
+      // scan's last node (src/sdk/src/sl_lidar_driver.cpp:286-292)
+      const uint32_t last_src = (len == full && (s1 - s0) > full) ? s1 - 1u : s0 + len - 1u;
+      dst[len - 1u] = in[last_src];
+    }
+  }
+  if (tid == 0) {
+    n_per_scan[g] = len;
+    if (status && st) atomicOr(&status[b], st);  // (on top of what the decoder stored there)
+  }
+}
+
 // Completed scans of every stream -> the fixed-stride batch (scan g at batch + g*n_stride) that
 // rplgpu_ascend_batch_dev / rplgpu_laserscan_batch_dev / rplgpu_cloud_batch_dev take.  The
 // global scan index is the stream-major running count (d_scan_base from a prefix sum over
@@ -775,13 +1184,19 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
                          const int32_t *state_in, int32_t *state_out, void *nodes,
                          uint32_t node_stride, uint32_t *n_nodes, uint32_t *reset_at,
                          uint32_t reset_stride, uint32_t *n_reset, uint32_t *n_errors,
-                         uint32_t *status) {
+                         uint32_t *status, uint32_t *sync_at, uint32_t sync_stride,
+                         uint32_t *n_sync) {
   if (B == 0) return hipSuccess;
-#define RPL_LAUNCH_DEC(A)                                                                        \
-  hipLaunchKernelGGL((k_decode<A>), dim3(B), dim3(kDecBlock), 0, s, bytes, stream_stride,       \
+#define RPL_LAUNCH_DEC2(A, F)                                                                    \
+  hipLaunchKernelGGL((k_decode<A, F>), dim3(B), dim3(kDecBlock), 0, s, bytes, stream_stride,    \
                      frame_off, gap, n_frames, max_frames, sample_duration_us, state_in,         \
                      state_out, (uint2 *)nodes, node_stride, n_nodes, reset_at, reset_stride,    \
-                     n_reset, n_errors, status)
+                     n_reset, n_errors, status, sync_at, sync_stride, n_sync)
+#define RPL_LAUNCH_DEC(A)                   \
+  do {                                      \
+    if (frame_off) RPL_LAUNCH_DEC2(A, true); \
+    else RPL_LAUNCH_DEC2(A, false);         \
+  } while (0)
   switch (ans) {
     case RPLGPU_ANS_MEASUREMENT: RPL_LAUNCH_DEC(RPLGPU_ANS_MEASUREMENT); break;
     case RPLGPU_ANS_CAPSULED: RPL_LAUNCH_DEC(RPLGPU_ANS_CAPSULED); break;
@@ -792,6 +1207,7 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
     default: return hipErrorInvalidValue;
   }
 #undef RPL_LAUNCH_DEC
+#undef RPL_LAUNCH_DEC2
   return hipGetLastError();
 }
 
@@ -799,13 +1215,29 @@ hipError_t launch_segment(hipStream_t s, const void *nodes, uint32_t node_stride
                           const uint32_t *n_nodes, const uint32_t *reset_at, uint32_t reset_stride,
                           const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *out_nodes,
                           uint32_t out_stride, uint32_t *scan_off, uint32_t scan_cap,
-                          uint32_t *n_scans, uint32_t *status) {
+                          uint32_t *n_scans, uint32_t *status, const uint32_t *sync_at,
+                          uint32_t sync_stride, const uint32_t *n_sync) {
   if (B == 0) return hipSuccess;
   hipLaunchKernelGGL(k_segment, dim3(B), dim3(kDecBlock), 0, s, (const uint2 *)nodes, node_stride,
                      n_nodes, reset_at, reset_stride, n_reset, max_count, (uint2 *)out_nodes,
-                     out_stride, scan_off, scan_cap, n_scans, status);
+                     out_stride, scan_off, scan_cap, n_scans, status, sync_at, sync_stride, n_sync);
   return hipGetLastError();
 }
+
+hipError_t launch_assemble(hipStream_t s, const void *nodes, uint32_t node_stride,
+                           const uint32_t *n_nodes, const uint32_t *sync_at, uint32_t sync_stride,
+                           const uint32_t *n_sync, const uint32_t *reset_at, uint32_t reset_stride,
+                           const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *batch,
+                           uint32_t n_stride, uint32_t scan_cap, uint32_t *n_per_scan,
+                           uint32_t *n_scans, uint32_t *status) {
+  if (B == 0 || scan_cap == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_assemble, dim3(B, scan_cap), dim3(kDecBlock), 0, s, (const uint2 *)nodes,
+                     node_stride, n_nodes, sync_at, sync_stride, n_sync, reset_at, reset_stride,
+                     n_reset, max_count, (uint2 *)batch, n_stride, scan_cap, n_per_scan, n_scans,
+                     status, (uint32_t)(std::getenv("RPLGPU_ASM_MODE") ? std::atoi(std::getenv("RPLGPU_ASM_MODE")) : 0));
+  return hipGetLastError();
+}
+uint32_t decode_sync_stride() { return kSegMaxSync + 1u; }
 
 hipError_t launch_scans_to_batch(hipStream_t s, const void *seg_nodes, uint32_t seg_stride,
                                  const uint32_t *scan_off, uint32_t scan_cap,

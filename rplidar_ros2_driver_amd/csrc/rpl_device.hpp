@@ -31,8 +31,9 @@ struct Tables {
   const double *rcp;       // rcp[c] = RN(1.0 / c), c = 1..32768 (voxel centroids), rcp[0] = 0
   uint32_t *work_ctr;      // dynamic scan queue of k_cloud_voxel (one word, cleared by every launch)
   uint32_t n_cu;           // compute units of the handle's device (persistent-workgroup grids)
-  void *voxel_store;       // k_cloud_voxel's record stores: voxel_store_wgs x 32768 x 16 B
+  void *voxel_store;       // k_cloud_voxel's record stores: voxel_store_wgs x voxel_store_recs x 16 B
   uint32_t voxel_store_wgs;
+  uint32_t voxel_store_recs;  // records per workgroup (>= kMaxN; group x kMaxN for an E8 group)
 };
 
 struct KParams {

@@ -49,7 +49,6 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               const float *pose2d = nullptr);
 // record stores k_cloud_voxel needs: one per resident workgroup (two per CU), this many bytes each
 uint32_t voxel_max_workgroups(uint32_t n_cu);
-size_t voxel_store_bytes_per_workgroup();
 hipError_t launch_ror_mask(hipStream_t s, const void *nodes, uint32_t n_stride,
                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                            const Tables &T, uint32_t *mask, uint32_t mask_stride);
@@ -84,12 +83,22 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
                          const int32_t *state_in, int32_t *state_out, void *nodes,
                          uint32_t node_stride, uint32_t *n_nodes, uint32_t *reset_at,
                          uint32_t reset_stride, uint32_t *n_reset, uint32_t *n_errors,
-                         uint32_t *status);
+                         uint32_t *status, uint32_t *sync_at = nullptr, uint32_t sync_stride = 0,
+                         uint32_t *n_sync = nullptr);
 hipError_t launch_segment(hipStream_t s, const void *nodes, uint32_t node_stride,
                           const uint32_t *n_nodes, const uint32_t *reset_at, uint32_t reset_stride,
                           const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *out_nodes,
                           uint32_t out_stride, uint32_t *scan_off, uint32_t scan_cap,
-                          uint32_t *n_scans, uint32_t *status);
+                          uint32_t *n_scans, uint32_t *status, const uint32_t *sync_at = nullptr,
+                          uint32_t sync_stride = 0, const uint32_t *n_sync = nullptr);
+// decoder's sync list + node stream -> completed scans in batch slots b*scan_cap + s
+hipError_t launch_assemble(hipStream_t s, const void *nodes, uint32_t node_stride,
+                           const uint32_t *n_nodes, const uint32_t *sync_at, uint32_t sync_stride,
+                           const uint32_t *n_sync, const uint32_t *reset_at, uint32_t reset_stride,
+                           const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *batch,
+                           uint32_t n_stride, uint32_t scan_cap, uint32_t *n_per_scan,
+                           uint32_t *n_scans, uint32_t *status);
+uint32_t decode_sync_stride();
 hipError_t launch_scans_to_batch(hipStream_t s, const void *seg_nodes, uint32_t seg_stride,
                                  const uint32_t *scan_off, uint32_t scan_cap,
                                  const uint32_t *n_scans, uint32_t B, uint32_t *scan_base,

@@ -581,7 +581,9 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   __shared__ VoxelLds L;
 
   if (threadIdx.x < 256) L.rcp[threadIdx.x] = T.rcp[threadIdx.x];  // (first barrier below publishes it)
-  uint4 *G = store + (size_t)blockIdx.x * kMaxN;  // this workgroup's record store (kMaxN records)
+  // this workgroup's record store (T.voxel_store_recs >= group * kMaxN records: every sample of
+  // the work item could end a run)
+  uint4 *G = store + (size_t)blockIdx.x * T.voxel_store_recs;
   // persistent workgroups, two per CU; the first scan is blockIdx.x, the next ones come from a
   // shared counter, so a workgroup that drew cheap scans simply takes more of them
   for (uint32_t b = blockIdx.x; b < B;) {
@@ -928,7 +930,6 @@ hipError_t launch_validate_div(hipStream_t s, float d, float rd, uint32_t e_lo, 
 }
 
 uint32_t voxel_max_workgroups(uint32_t n_cu) { return (kVB == 512 ? 2u : 1u) * (n_cu ? n_cu : 256u); }
-size_t voxel_store_bytes_per_workgroup() { return (size_t)kMaxN * sizeof(uint4); }
 
 hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_stride,
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
@@ -943,6 +944,7 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   const uint32_t n_scans = B;
   B = (B + group - 1u) / group;  // work items
   if (!T.voxel_store || T.voxel_store_wgs == 0) return hipErrorInvalidValue;
+  if ((uint64_t)group * std::min(n_stride, kMaxN) > T.voxel_store_recs) return hipErrorInvalidValue;
   VoxelArena ar;
   ar.base = (float4 *)arena;
   ar.cursor = arena_cursor;

@@ -54,8 +54,11 @@ struct rplgpu_ctx {
   uint32_t n_cu = 0;                  // compute units of `device`
   void *d_vstore = nullptr;           // k_cloud_voxel record stores (one per resident workgroup)
   uint32_t vstore_wgs = 0;
+  uint32_t vstore_recs = 0;           // records per workgroup (grows with the largest E8 group seen)
   unsigned char *d_dec = nullptr;     // rplgpu_decode_stream staging (grown on demand, kept)
   size_t dec_cap = 0;
+  unsigned char *d_scans = nullptr;   // rplgpu_decode_scans_dev scratch (node streams, sync lists)
+  size_t scans_cap = 0;
   bool check_ptrs = true;             // batch entry points verify that buffers are device memory
   // multi-GPU exchange (include/rplgpu_comm.h)
   void *comm = nullptr;               // ncclComm_t
@@ -167,6 +170,7 @@ rpl::Tables tables_of(const rplgpu_ctx *c) {
   t.n_cu = c->n_cu;
   t.voxel_store = c->d_vstore;
   t.voxel_store_wgs = c->vstore_wgs;
+  t.voxel_store_recs = c->vstore_recs;
   return t;
 }
 
@@ -230,6 +234,7 @@ void free_ctx(rplgpu_ctx *c) {
   if (c->d_rormask) (void)hipFree(c->d_rormask);
   if (c->d_need_sort) (void)hipFree(c->d_need_sort);
   if (c->d_dec) (void)hipFree(c->d_dec);
+  if (c->d_scans) (void)hipFree(c->d_scans);
   if (c->d_vstore) (void)hipFree(c->d_vstore);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -491,7 +496,8 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   // the voxel kernel's record stores (overflow of its LDS queue; 512 KiB per resident workgroup,
   // at most two workgroups per CU and never more than scans in a batch)
   c->vstore_wgs = std::min<uint32_t>(c->max_b, rpl::voxel_max_workgroups(c->n_cu));
-  if (hipMalloc(&c->d_vstore, (size_t)c->vstore_wgs * rpl::voxel_store_bytes_per_workgroup()) != hipSuccess) {
+  c->vstore_recs = rpl::kMaxN;
+  if (hipMalloc(&c->d_vstore, (size_t)c->vstore_wgs * c->vstore_recs * 16u) != hipSuccess) {
     c->err = "record store allocation failed";
     return fail(RPLGPU_ERR_HIP);
   }
@@ -665,6 +671,26 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
   if ((d_motion && !device_readable(h, d_motion, "d_motion")) ||
       (d_pose2d && !device_readable(h, d_pose2d, "d_pose2d")))
     return RPLGPU_ERR_INVALID_ARG;
+  // Every sample of a group can end a run record: the record stores grow (only ever grow, and
+  // only here — the first call with a larger group pays one reallocation) to group x stride.
+  const uint64_t need = (uint64_t)std::min(group, B) * std::min(n_stride, rpl::kMaxN);
+  if (need > h->vstore_recs) {
+    if (need > (1ull << 24)) {
+      h->err = "rplgpu_cloud_fused_voxel_dev: group x n_stride above 2^24 samples";
+      return RPLGPU_ERR_CAPACITY;
+    }
+    RPL_HIP(h, hipSetDevice(h->device));
+    RPL_HIP(h, hipStreamSynchronize(h->stream));
+    void *bigger = nullptr;
+    if (hipMalloc(&bigger, (size_t)h->vstore_wgs * need * 16u) != hipSuccess) {
+      h->err = "record store allocation failed";
+      (void)hipGetLastError();
+      return RPLGPU_ERR_HIP;
+    }
+    (void)hipFree(h->d_vstore);
+    h->d_vstore = bigger;
+    h->vstore_recs = (uint32_t)need;
+  }
   rpl::KParams kp;
   const uint32_t *mask = nullptr;
   if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
@@ -932,6 +958,59 @@ int32_t rplgpu_decode_batch_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
                                 d_n_frames, max_frames, B, sample_duration_us, d_state_in,
                                 d_state_out, d_nodes, node_stride, d_n_nodes, d_reset_at,
                                 reset_stride, d_n_reset, d_n_errors, d_status));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
+                                const uint8_t *d_bytes, uint64_t stream_stride,
+                                const uint32_t *d_frame_off, const uint8_t *d_gap,
+                                const uint32_t *d_n_frames, uint32_t max_frames, uint32_t B,
+                                const int32_t *d_state_in, int32_t *d_state_out,
+                                uint32_t max_count, rplgpu_node_t *d_batch, uint32_t n_stride,
+                                uint32_t scan_cap, uint32_t *d_n_per_scan, uint32_t *d_n_scans,
+                                uint32_t *d_n_errors, uint32_t *d_status) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  const size_t npf = rplgpu_nodes_per_frame(ans_type);
+  if (!npf || max_count == 0 || scan_cap == 0 || n_stride == 0) return RPLGPU_ERR_INVALID_ARG;
+  if (sample_duration_us == 0 || sample_duration_us > 1000000u) return RPLGPU_ERR_INVALID_ARG;
+  if (B && (!d_bytes || !d_n_frames || !d_batch || !d_n_per_scan || !d_n_scans || !d_status))
+    return RPLGPU_ERR_INVALID_ARG;
+  if (d_gap && !d_frame_off) return RPLGPU_ERR_INVALID_ARG;
+  if (max_frames == 0 || max_frames > rpl::decode_max_frames(ans_type)) return RPLGPU_ERR_CAPACITY;
+  if ((uint64_t)max_frames * npf > 0x7FFFFFFFull || (uint64_t)B * scan_cap > 0xFFFFFFFFull)
+    return RPLGPU_ERR_CAPACITY;
+  if (B == 0) return RPLGPU_OK;
+  RPL_HIP(h, hipSetDevice(h->device));
+  // scratch kept in the handle (grows when a larger call arrives, never shrinks): the decoded
+  // node streams, the decoder's sync-node and reset lists, three counters per stream
+  const uint32_t node_stride = (uint32_t)((size_t)max_frames * npf);
+  const uint32_t sync_stride = rpl::decode_sync_stride();
+  const uint32_t reset_stride = std::min<uint32_t>(max_frames, 2048u);  // a frame requests at most one reset
+  auto up256 = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const size_t sz_nodes = up256((size_t)B * node_stride * 8), sz_sync = up256((size_t)B * sync_stride * 4);
+  const size_t sz_rst = up256((size_t)B * reset_stride * 4), sz_cnt = up256((size_t)B * 4);
+  const size_t need = sz_nodes + sz_sync + sz_rst + 3 * sz_cnt;
+  if (h->scans_cap < need) {
+    RPL_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->d_scans) (void)hipFree(h->d_scans);
+    h->d_scans = nullptr;
+    h->scans_cap = 0;
+    RPL_HIP(h, hipMalloc((void **)&h->d_scans, need));
+    h->scans_cap = need;
+  }
+  unsigned char *p = h->d_scans;
+  rplgpu_node_t *t_nodes = reinterpret_cast<rplgpu_node_t *>(p);
+  uint32_t *t_sync = reinterpret_cast<uint32_t *>(p + sz_nodes);
+  uint32_t *t_rst = reinterpret_cast<uint32_t *>(p + sz_nodes + sz_sync);
+  uint32_t *t_nn = reinterpret_cast<uint32_t *>(p + sz_nodes + sz_sync + sz_rst);
+  uint32_t *t_nr = t_nn + sz_cnt / 4, *t_ns = t_nr + sz_cnt / 4;
+  RPL_HIP(h, rpl::launch_decode(h->stream, ans_type, d_bytes, stream_stride, d_frame_off, d_gap,
+                                d_n_frames, max_frames, B, sample_duration_us, d_state_in,
+                                d_state_out, t_nodes, node_stride, t_nn, t_rst, reset_stride, t_nr,
+                                d_n_errors, d_status, t_sync, sync_stride, t_ns));
+  RPL_HIP(h, rpl::launch_assemble(h->stream, t_nodes, node_stride, t_nn, t_sync, sync_stride, t_ns,
+                                  t_rst, reset_stride, t_nr, B, max_count, d_batch, n_stride,
+                                  scan_cap, d_n_per_scan, d_n_scans, d_status));
   return RPLGPU_OK;
 }
 

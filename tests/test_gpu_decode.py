@@ -292,6 +292,101 @@ def test_recorded_stream_to_laserscan_pipeline(gpu, oracle):
     assert gidx == total
 
 
+@pytest.mark.parametrize("ans", ALL_ANS)
+def test_decode_scans_matches_oracle_chain(gpu, oracle, ans):
+    """rplgpu_decode_scans_dev (decode + scan assembly straight into batch slots, the decoder's
+    own sync list) against oracle.unpack -> oracle.segment, stream by stream: clean and corrupted
+    streams, framed (offsets + gaps after junk bytes) and back to back, several max_count /
+    n_stride / scan_cap combinations (truncation flags), and the slots a stream leaves empty."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
+    nf = 220 if ans != 0x81 else 6000
+    rng = np.random.default_rng(ans)
+    for framed in (False, True):
+        streams = []
+        for b in range(9):
+            fpr = [9.3, 25.0, 4.2, 60.0, 2.5, 14.0, 33.3, 7.0, 110.0][b]
+            if ans == 0x81:
+                fpr *= 40
+            d = cp.make_stream(ans, nf - 7 * b, 500 + b, corrupt=framed and b % 3 == 1,
+                               payload="ring" if b % 2 else "random", frames_per_rev=fpr)
+            if framed and b % 2 == 0:  # junk between frames: gaps clear the capsule latch
+                cut = (len(d) // S // 2) * S
+                d = np.concatenate([d[:cut], rng.integers(0, 256, 13, dtype=np.uint8), d[cut:]])
+            streams.append(d)
+        B = len(streams)
+        stride = max(len(d) for d in streams)
+        buf = np.zeros((B, stride), np.uint8)
+        offs = np.zeros((B, nf), np.uint32)
+        gaps = np.zeros((B, nf), np.uint8)
+        nfs = np.zeros(B, np.int32)
+        for b, d in enumerate(streams):
+            buf[b, : len(d)] = d
+            if framed:
+                o, g = abi.frame_stream(ans, d)
+                nfs[b] = len(o)
+                offs[b, : len(o)], gaps[b, : len(o)] = o, g
+            else:
+                nfs[b] = len(d) // S
+        d_bytes = torch.from_numpy(buf).to(dev)
+        d_off = torch.from_numpy(offs.view(np.int32)).to(dev)
+        d_gap = torch.from_numpy(gaps).to(dev)
+        d_nf = torch.from_numpy(nfs).to(dev)
+        want = []
+        for d in streams:
+            nodes, rst, err, _ = oracle.unpack(ans, d, 125)
+            want.append((nodes, rst, err))
+        for max_count, n_stride, scan_cap in ((8192, 4096, 64), (37, 64, 64), (8192, 50, 3), (1, 8, 512)):
+            d_batch = torch.zeros(B * scan_cap, n_stride * 8, dtype=torch.uint8, device=dev)
+            d_len = torch.full((B * scan_cap,), -1, dtype=torch.int32, device=dev)
+            d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
+            d_ne = torch.zeros(B, dtype=torch.int32, device=dev)
+            d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+            gpu.decode_scans_dev(ans, 125, d_bytes.data_ptr(), stride,
+                                 d_off.data_ptr() if framed else 0, d_gap.data_ptr() if framed else 0,
+                                 d_nf.data_ptr(), nf, B, 0, 0, max_count, d_batch.data_ptr(), n_stride,
+                                 scan_cap, d_len.data_ptr(), d_ns.data_ptr(), d_ne.data_ptr(),
+                                 d_st.data_ptr())
+            gpu.synchronize()
+            batch = d_batch.cpu().numpy().view(NODE_DTYPE).reshape(B * scan_cap, n_stride)
+            lens, ns, ne, st = (t.cpu().numpy() for t in (d_len, d_ns, d_ne, d_st))
+            for b in range(B):
+                nodes, rst, err = want[b]
+                scans, w_off = oracle.segment(nodes, rst, max_count)
+                n_want = len(w_off) - 1
+                key = (hex(ans), framed, b, max_count, n_stride, scan_cap)
+                assert ne[b] == err, key
+                assert ns[b] == min(n_want, scan_cap), key
+                assert bool(st[b] & abi_status("RESETS_TRUNCATED")) == (n_want > scan_cap), key
+                too_long = False
+                for s_ in range(scan_cap):
+                    g = b * scan_cap + s_
+                    if s_ >= n_want:
+                        assert lens[g] == 0, key
+                        continue
+                    scan = scans[w_off[s_]: w_off[s_ + 1]]
+                    keep = min(len(scan), n_stride)
+                    too_long |= len(scan) > n_stride
+                    assert lens[g] == keep, key
+                    assert batch[g, :keep].tobytes() == scan[:keep].tobytes(), key
+                assert bool(st[b] & 0x8) == too_long, key  # RPLGPU_SCAN_OUT_TRUNCATED
+    # the slot layout feeds the batch entry points as it is: empty slots are empty scans
+    p = Params.defaults(range_max=40.0)
+    total = min(B * scan_cap, 4096)
+    lens = lens[:total]
+    d_status = torch.zeros(total, dtype=torch.int32, device=dev)
+    gpu.ascend_batch_dev(d_batch.data_ptr(), n_stride, d_len.data_ptr(), total, d_status.data_ptr())
+    d_r = torch.zeros(total, n_stride, dtype=torch.float32, device=dev)
+    d_i = torch.zeros(total, n_stride, dtype=torch.float32, device=dev)
+    d_cnt = torch.full((total,), -1, dtype=torch.int32, device=dev)
+    gpu.laserscan_batch_dev(d_batch.data_ptr(), n_stride, d_len.data_ptr(), total, p,
+                            d_r.data_ptr(), d_i.data_ptr(), d_cnt.data_ptr())
+    gpu.synchronize()
+    cnt = d_cnt.cpu().numpy()
+    assert np.all(cnt[lens == 0] == 0)
+
+
 def test_decode_full_size_properties(gpu):
     """BASELINE config-3 shape for the decode stage (4096 DenseBoost streams x 801 capsules =
     131 M nodes), checked through size-independent properties computed on the device:

@@ -9,10 +9,14 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dev = torch.device("cuda:0")
 gpu = RplGpu(0, 32768, 16)
 st = torch.cuda.Stream(); torch.cuda.set_stream(st); gpu.set_stream(st.cuda_stream)
+import os
+ONLY = int(os.environ.get('DEC_ONLY', '0'), 0)
 for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334), (0x81, 4000)):
+    if ONLY and ans != ONLY:
+        continue
     S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
     uniq = 16
-    base = np.stack([cp.make_stream(ans, nf, 10 + s, payload="ring", frames_per_rev=nf / 1.0 - 0.7) for s in range(uniq)])
+    base = np.stack([cp.make_stream(ans, nf, 10 + s, payload="ring", frames_per_rev=nf / 2.0 + 0.3) for s in range(uniq)])
     buf = torch.from_numpy(base).to(dev).repeat((B + uniq - 1) // uniq, 1)[:B].contiguous()
     d_nf = torch.full((B,), nf, dtype=torch.int32, device=dev)
     node_stride = nf * npf
@@ -30,8 +34,28 @@ for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334)
         a.record(st); run(); b.record(st); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     nodes = int(d_nn.sum().item())
     t = min(ts)
+    if os.environ.get('DEC_DBG'):
+        ph = d_rst.cpu().numpy()[:, 3:8].astype(np.float64)
+        print("   phase cycles P1 P2 P3 P4 P5 (mean):", ph.mean(0).round(0), "sum", ph.sum(1).mean().round(0))
+        print("   P1 p10/p50/p90:", np.percentile(ph[:, 0], [10, 50, 90]).round(0), " first 1792 WGs mean", ph[:1792, 0].mean().round(0), "rest", ph[1792:, 0].mean().round(0),
+              " P3 p10/p50/p90:", np.percentile(ph[:, 2], [10, 50, 90]).round(0))
     print(f"ans {ans:#x}: {nodes/1e6:.1f} Mnodes in {t:.3f} ms -> {nodes/t/1e6:.1f} Gnodes/s, "
           f"in {B*nf*S/1e6:.0f} MB out {nodes*8/1e6:.0f} MB -> {(B*nf*S+nodes*8)/t/1e6:.0f} GB/s")
+    if True:
+        scan_cap, n_stride = 4, min(node_stride, 32768)
+        d_batch = torch.empty(B * scan_cap, n_stride * 8, dtype=torch.uint8, device=dev)
+        d_len = torch.zeros(B * scan_cap, dtype=torch.int32, device=dev)
+        d_ns2 = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_st2 = torch.zeros(B, dtype=torch.int32, device=dev)
+        def fused():
+            gpu.decode_scans_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0, 32768,
+                                 d_batch.data_ptr(), n_stride, scan_cap, d_len.data_ptr(), d_ns2.data_ptr(), 0, d_st2.data_ptr())
+        fused(); torch.cuda.synchronize(); ts = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st); fused(); b.record(st); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+        print(f"  segment-fused decode_scans_dev: {min(ts):.3f} ms, scans {int(d_ns2.sum().item())}, nodes in scans {int(d_len.sum().item())}, status {int(d_st2.max().item())}")
+        del d_batch
     if ans == 0x85:
         d_seg = torch.empty_like(d_nodes)
         scan_cap = 8
