@@ -236,6 +236,25 @@ def decode_stage(gpu, dev, stream, cpu_seconds):
 
             out["segment_ms"] = round(timed(seg, stream, 5, sync), 4)
             out["segment_scans"] = int(d_ns.sum().item())
+            del d_seg
+            # the same step in ONE call: the decoder's sync list, completed scans written straight
+            # into batch slots (rplgpu_decode_scans_dev) — what replaces decode + segment + to_batch
+            scap, nst = 4, min(node_stride, 32768)
+            d_batch = torch.empty(B * scap, nst * 8, dtype=torch.uint8, device=dev)
+            d_len = torch.zeros(B * scap, dtype=torch.int32, device=dev)
+            d_st2 = torch.zeros(B, dtype=torch.int32, device=dev)
+
+            def fused_scans():
+                gpu.decode_scans_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0,
+                                     32768, d_batch.data_ptr(), nst, scap, d_len.data_ptr(), d_ns.data_ptr(),
+                                     0, d_st2.data_ptr())
+
+            ms2 = timed(fused_scans, stream, 5, sync)
+            kept = int(d_len.to(torch.int64).sum().item())
+            out["decode_scans"] = {"ms": round(ms2, 4), "scans": int(d_ns.sum().item()), "nodes_in_scans": kept,
+                                   "status_bits": int(d_st2.max().item()),
+                                   "frac": round((B * nf * S + 8 * kept) / ms2 / 1e6 / HBM_PEAK_GBS, 4)}
+            del d_batch
             if cpu_seconds > 0:  # the oracle restatement of the SDK unpacker, one core, one stream
                 from tests import oracle_lib
 
@@ -247,7 +266,6 @@ def decode_stage(gpu, dev, stream, cpu_seconds):
                     orc.unpack(ans, base[reps % uniq], 125)
                     reps += 1
                 out["dense_cpu1_mnodes"] = round(reps * (nf - 1) * npf / (time.perf_counter() - t0) / 1e6, 1)
-            del d_seg
         del buf, d_nodes
     return out
 

@@ -159,21 +159,23 @@ __device__ __forceinline__ uint32_t hq_crc_64frames(const uint8_t *base, uint32_
   const uint32_t lane = lane_id(), c = lane & 15u;
   const uint32_t sh = ((uint32_t)(uintptr_t)(base + my_off) & 3u) * 8u;
   // lane (4*it + q, c) fetches word c of every piece of frame 4*it + q: its 16 frame addresses
-  // (aligned down) are fixed for the whole call
-  const uint32_t *src[16];
+  // (aligned down) are fixed for the whole call — kept as 32-bit offsets from the (uniform,
+  // aligned-down) stream base: half the registers of 16 pointers, and the loads take the base
+  // from scalar registers
+  const uint32_t *abase = reinterpret_cast<const uint32_t *>((uintptr_t)base & ~(uintptr_t)3);
+  const uint32_t bmis = (uint32_t)((uintptr_t)base & 3u);
+  uint32_t so[16];  // word index of (frame start, aligned down) + c; 0xFFFFFFFF = no frame
 #pragma unroll
   for (uint32_t it = 0; it < 16u; ++it) {
     const uint32_t fj = it * 4u + (lane >> 4);
     const uint32_t off_j = (uint32_t)__shfl((int)my_off, (int)fj);
-    src[it] = fj < nlive
-                  ? reinterpret_cast<const uint32_t *>((uintptr_t)(base + off_j) & ~(uintptr_t)3) + c
-                  : nullptr;
+    so[it] = fj < nlive ? ((bmis + off_j) >> 2) + c : 0xFFFFFFFFu;
   }
   uint32_t v[16];
   auto fetch = [&](uint32_t p) {  // 16 independent loads in flight
 #pragma unroll
     for (uint32_t it = 0; it < 16u; ++it)
-      v[it] = (src[it] && p * 16u + c < 196u) ? src[it][p * 16u] : 0u;
+      v[it] = (so[it] != 0xFFFFFFFFu && p * 16u + c < 196u) ? abase[so[it] + p * 16u] : 0u;
   };
   fetch(0u);
   uint32_t crc = 0xFFFFFFFFu, prev = 0u, stored = 0u, first = 0u;
