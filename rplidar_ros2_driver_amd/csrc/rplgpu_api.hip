@@ -954,6 +954,9 @@ int32_t rplgpu_decode_batch_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
   if (d_gap && !d_frame_off) return RPLGPU_ERR_INVALID_ARG;
   if (max_frames > rpl::decode_max_frames(ans_type)) return RPLGPU_ERR_CAPACITY;
   RPL_HIP(h, hipSetDevice(h->device));
+  if (B && (!device_readable(h, d_bytes, "d_bytes") || !device_readable(h, d_n_frames, "d_n_frames") ||
+            (d_frame_off && !device_readable(h, d_frame_off, "d_frame_off"))))
+    return RPLGPU_ERR_INVALID_ARG;
   RPL_HIP(h, rpl::launch_decode(h->stream, ans_type, d_bytes, stream_stride, d_frame_off, d_gap,
                                 d_n_frames, max_frames, B, sample_duration_us, d_state_in,
                                 d_state_out, d_nodes, node_stride, d_n_nodes, d_reset_at,
@@ -979,8 +982,13 @@ int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
   if (max_frames == 0 || max_frames > rpl::decode_max_frames(ans_type)) return RPLGPU_ERR_CAPACITY;
   if ((uint64_t)max_frames * npf > 0x7FFFFFFFull || (uint64_t)B * scan_cap > 0xFFFFFFFFull)
     return RPLGPU_ERR_CAPACITY;
+  if (scan_cap > 65535u) return RPLGPU_ERR_CAPACITY;  // (a grid dimension of k_assemble)
   if (B == 0) return RPLGPU_OK;
   RPL_HIP(h, hipSetDevice(h->device));
+  if (!device_readable(h, d_bytes, "d_bytes") || !device_readable(h, d_n_frames, "d_n_frames") ||
+      (d_frame_off && !device_readable(h, d_frame_off, "d_frame_off")) ||
+      !device_readable(h, d_batch, "d_batch"))
+    return RPLGPU_ERR_INVALID_ARG;
   // scratch kept in the handle (grows when a larger call arrives, never shrinks): the decoded
   // node streams, the decoder's sync-node and reset lists, three counters per stream
   const uint32_t node_stride = (uint32_t)((size_t)max_frames * npf);

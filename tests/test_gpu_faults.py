@@ -155,3 +155,99 @@ def test_switching_streams_between_launches_is_safe(oracle):
             assert [t.cpu().numpy().tobytes() for t in o] == ref
         want, _, _ = oracle.cloud_pipeline(batch[5], oracle_lib.copy_params(pv))
         assert int(outs[0][1][5]) == len(want)
+
+
+def test_round2_entry_points_reject_bad_arguments_and_recover(oracle):
+    """The entry points added in round 2 (decode -> scans, fused voxel grid, LaserScan -> cloud,
+    the exchange) with wrong arguments: an error code, a message, and a handle that still works."""
+    import torch
+    from rplidar_ros2_driver_amd import capsules as cp
+    dev = torch.device("cuda:0")
+    lib = abi.load_library()
+    with RplGpu(device=0, max_samples_per_scan=8192, max_batch=8) as gpu:
+        h = gpu._h
+        ans, nf, B = cp.ANS_DENSE_CAPSULED, 60, 3
+        S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
+        streams = np.stack([cp.make_stream(ans, nf, 70 + b, payload="ring", frames_per_rev=9.0) for b in range(B)])
+        d_bytes = torch.from_numpy(streams).to(dev)
+        d_nf = torch.full((B,), nf, dtype=torch.int32, device=dev)
+        scan_cap, n_stride = 8, 1024
+        d_batch = torch.zeros(B * scan_cap, n_stride * 8, dtype=torch.uint8, device=dev)
+        d_len = torch.zeros(B * scan_cap, dtype=torch.int32, device=dev)
+        d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+
+        def dec(ans_=ans, dur=125, bytes_=None, nfp=None, max_frames=nf, max_count=8192, batch=None,
+                n_stride_=n_stride, cap=scan_cap, lens=None, st=None):
+            return lib.rplgpu_decode_scans_dev(
+                h, ans_, dur, d_bytes.data_ptr() if bytes_ is None else bytes_, nf * S, 0, 0,
+                d_nf.data_ptr() if nfp is None else nfp, max_frames, B, 0, 0, max_count,
+                d_batch.data_ptr() if batch is None else batch, n_stride_, cap,
+                d_len.data_ptr() if lens is None else lens, d_ns.data_ptr(), 0,
+                d_st.data_ptr() if st is None else st)
+
+        assert dec() == abi.OK
+        gpu.synchronize()
+        good = (d_len.cpu().numpy().copy(), d_batch.cpu().numpy().copy())
+        assert good[0].sum() > 0
+        assert dec(ans_=0x42) == abi.ERR_INVALID_ARG
+        assert dec(dur=0) == abi.ERR_INVALID_ARG
+        assert dec(max_count=0) == abi.ERR_INVALID_ARG
+        assert dec(cap=0) == abi.ERR_INVALID_ARG
+        assert dec(n_stride_=0) == abi.ERR_INVALID_ARG
+        assert dec(batch=0) == abi.ERR_INVALID_ARG
+        assert dec(st=0) == abi.ERR_INVALID_ARG
+        assert dec(max_frames=4096) == abi.ERR_CAPACITY
+        assert dec(cap=70000) == abi.ERR_CAPACITY
+        assert dec(bytes_=streams.ctypes.data) == abi.ERR_INVALID_ARG  # host memory
+        assert lib.rplgpu_last_error(h)
+        host_nf = np.full(B, nf, np.int32)
+        assert dec(nfp=host_nf.ctypes.data) == abi.ERR_INVALID_ARG
+        d_len.zero_(); d_batch.zero_()
+        assert dec() == abi.OK
+        gpu.synchronize()
+        assert d_len.cpu().numpy().tobytes() == good[0].tobytes()
+        assert d_batch.cpu().numpy().tobytes() == good[1].tobytes()
+        _still_works(gpu, oracle)
+
+        # fused voxel grid
+        n, Bs = 1500, 4
+        batch = synth.make_batch(5, Bs, n)
+        d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(Bs, n * 8)).to(dev)
+        d_n = torch.full((Bs,), n, dtype=torch.int32, device=dev)
+        d_arena = torch.zeros(Bs * n, 4, dtype=torch.float32, device=dev)
+        d_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_gs = torch.zeros(Bs, dtype=torch.int64, device=dev)
+        d_np = torch.zeros(Bs, dtype=torch.int32, device=dev)
+        pv = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
+        pn = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=0)
+
+        def fused(group=2, p=pv, arena=None, motion=0):
+            return lib.rplgpu_cloud_fused_voxel_dev(
+                h, d_nodes.data_ptr(), n, d_n.data_ptr(), Bs, group, C.byref(p), motion, 0,
+                d_arena.data_ptr() if arena is None else arena, Bs * n, d_cur.data_ptr(),
+                d_gs.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+
+        assert fused() == abi.OK
+        assert fused(group=0) == abi.ERR_INVALID_ARG
+        assert fused(p=pn) == abi.ERR_INVALID_ARG
+        assert fused(arena=0) == abi.ERR_INVALID_ARG
+        host_motion = np.zeros((Bs, 4), np.float32)
+        assert fused(motion=host_motion.ctypes.data) == abi.ERR_INVALID_ARG
+        _still_works(gpu, oracle)
+
+        # LaserScan -> cloud, and the exchange before rplgpu_comm_init
+        d_r = torch.zeros(Bs, n, dtype=torch.float32, device=dev)
+        d_cnt = torch.full((Bs,), n, dtype=torch.int32, device=dev)
+        assert lib.rplgpu_laserscan_to_cloud_batch_dev(h, 0, d_r.data_ptr(), n, d_cnt.data_ptr(), Bs,
+                                                       C.byref(pn), d_arena.data_ptr(), n,
+                                                       d_np.data_ptr(), d_st.data_ptr()) == abi.ERR_INVALID_ARG
+        assert lib.rplgpu_laserscan_to_cloud_batch_dev(h, d_r.data_ptr(), d_r.data_ptr(), n,
+                                                       d_cnt.data_ptr(), Bs, None, d_arena.data_ptr(), n,
+                                                       d_np.data_ptr(), d_st.data_ptr()) == abi.ERR_INVALID_ARG
+        d_meta = torch.zeros(64, dtype=torch.int32, device=dev)
+        assert lib.rplgpu_allgather_clouds_dev(h, d_arena.data_ptr(), 16, d_meta.data_ptr(), 8,
+                                               d_arena.data_ptr(), d_meta.data_ptr()) == abi.ERR_INVALID_ARG
+        assert b"rplgpu_comm_init" in lib.rplgpu_last_error(h)
+        assert lib.rplgpu_comm_fence(h) in (abi.OK, abi.ERR_INVALID_ARG)
+        _still_works(gpu, oracle)
