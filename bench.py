@@ -454,6 +454,7 @@ def main():
                         "exchange_only_ms": round(ms_x, 4),
                         "overlapped_ms": round(elapsed / args.steps * 1e3, 4),
                         "gathered_bytes_per_rank": exch.last_bytes(),
+                        "exchange_backend": exch.backend,
                         "note": "compute = the rank's whole block in one launch, no exchange; "
                                 "exchange_only = RCCL all-gather of the last step's clouds; "
                                 "overlapped = the timed step (chunked, two streams)"}

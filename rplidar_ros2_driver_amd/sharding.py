@@ -188,12 +188,34 @@ class CloudExchange:
         self.chunks = max(1, min(chunks, max(B, 1)))
         self.Bc = (B + self.chunks - 1) // self.chunks
         self.mw = meta_words(self.Bc)
-        # communicator: rank 0's unique id travels through torch.distributed
-        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            uid.copy_(torch.from_numpy(gpu.comm_unique_id()))
-        self.dist.broadcast(uid, src=0)
-        gpu.comm_init(rank, world, uid.cpu().numpy())
+        # communicator: rank 0's unique id travels through torch.distributed.  Should the library's
+        # own communicator not come up on some rank (RCCL not loadable, init error), EVERY rank
+        # falls back to torch.distributed's all-gather for the same buffers, and `backend` says so
+        # (RPL_EXCHANGE=torch forces that path).
+        import os
+        self.backend = "rccl behind the C ABI (rplgpu_comm.h)"
+        ok = 1
+        if os.environ.get("RPL_EXCHANGE") == "torch":
+            ok, self.backend = 0, "torch.distributed (forced by RPL_EXCHANGE=torch)"
+        else:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            try:
+                if rank == 0:
+                    uid.copy_(torch.from_numpy(gpu.comm_unique_id()))
+            except Exception as e:  # (the broadcast below still has to happen on every rank)
+                ok, self.backend = 0, f"torch.distributed (rplgpu_comm_unique_id failed: {e})"
+            self.dist.broadcast(uid, src=0)
+            if ok:
+                try:
+                    gpu.comm_init(rank, world, uid.cpu().numpy())
+                except Exception as e:
+                    ok, self.backend = 0, f"torch.distributed (rplgpu_comm_init failed: {e})"
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+            if ok and int(flag.item()) == 0:
+                self.backend = "torch.distributed (a peer's communicator did not come up)"
+            ok = int(flag.item())
+        self.native = bool(ok)
         self.cursor = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.chunks)]
         self.start = [torch.zeros(self.Bc, dtype=torch.int64, device=dev) for _ in range(self.chunks)]
         self.npts = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(self.chunks)]
@@ -242,21 +264,29 @@ class CloudExchange:
                               self.start[c].data_ptr(), self.npts[c].data_ptr(), self.stat[c].data_ptr())
             g.pack_cloud_meta_dev(self.cursor[c].data_ptr(), self.start[c].data_ptr(),
                                   self.npts[c].data_ptr(), nb, self.slot, self.Bc, meta.data_ptr())
-            g.allgather_clouds_dev(mine.data_ptr(), self.slot, meta.data_ptr(), self.mw,
-                                   self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
-        g.comm_fence(0)
+            self._gather(c, mine, meta)
+        if self.native:
+            g.comm_fence(0)
+
+    def _gather(self, c, mine, meta):
+        if self.native:
+            self.gpu.allgather_clouds_dev(mine.data_ptr(), self.slot, meta.data_ptr(), self.mw,
+                                          self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
+        else:  # fallback: torch.distributed (its own stream handling; a send copy to be safe)
+            self.dist.all_gather_into_tensor(self.recv_pts[c].view(-1), mine.reshape(-1).clone())
+            self.dist.all_gather_into_tensor(self.recv_meta[c].view(-1), meta.reshape(-1).clone())
 
     def exchange_only(self):
         r = self.rank
         for c in range(self.chunks):
-            self.gpu.allgather_clouds_dev(self.recv_pts[c, r].data_ptr(), self.slot,
-                                          self.recv_meta[c, r].data_ptr(), self.mw,
-                                          self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
-        self.gpu.comm_fence(0)
+            self._gather(c, self.recv_pts[c, r], self.recv_meta[c, r])
+        if self.native:
+            self.gpu.comm_fence(0)
 
     def last_bytes(self):
         """bytes this rank RECEIVES from its peers per step"""
         return int(self.chunks * (self.world - 1) * (self.slot or 0) * 16)
 
     def close(self):
-        self.gpu.comm_destroy()
+        if self.native:
+            self.gpu.comm_destroy()
