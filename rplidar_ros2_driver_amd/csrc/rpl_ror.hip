@@ -8,8 +8,13 @@
 //   1. index neighbours.  A lidar scan is ordered by angle: the nearest points of sample i are
 //      almost always samples i+-1, i+-2, ...  Every kept sample tests its 8 index neighbours
 //      (coalesced loads of the shifted scan) and is settled as soon as k of them lie within r.
-//   2. the few samples that stay unsettled (isolated returns, borders of drop-outs, real
-//      outliers) are searched exhaustively but cooperatively: the kept samples are binned by y
+//   1b. the samples that stay unsettled are mostly islands between drop-outs whose spatial
+//      neighbours are a few more indices away: ONE WAVE per unsettled sample tests the 64 samples
+//      before and the 64 after it (two ballots).  Only what is still unsettled then goes on;
+//      on ring-like scans that is nothing, and the row structure of stage 2 (two more passes
+//      over the whole scan) is not built at all (C5 at 4096 scans: 2.56 -> see DESIGN.md).
+//   2. the few samples that stay unsettled (isolated returns, real outliers) are searched
+//      exhaustively but cooperatively: the kept samples are binned by y
 //      into rows of height h >= 1.001 r (h grows with the scan's y extent so that 2048 rows
 //      always suffice) with a counting sort in LDS, and ONE WAVE per unsettled sample sweeps
 //      the candidates of its own row and the two rows next to it, 64 at a time (ballot +
@@ -36,7 +41,9 @@ struct RorLds {
   uint32_t misc[8];             // 0/1 ymin/ymax (order-preserving uint encoding), 2 #unsettled
   uint32_t tmp[32];
   uint16_t todo[kRorTodo];      // unsettled samples of stage 1
+  uint16_t todo2[kRorTodo];     // ... still unsettled after the +-64 window of stage 1b
   uint32_t late[kMaxN / 32];    // keep bits found by stage 2 (bit i of word i/32)
+  float2 win[2 * kBlock + 2 * kRorNear];  // stage 1: (x, y) of the 2048 samples of a trip + halo
 };
 
 // order-preserving float <-> uint map (for LDS atomicMin / atomicMax on floats)
@@ -72,6 +79,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
     L.misc[0] = 0xFFFFFFFFu;
     L.misc[1] = 0u;
     L.misc[2] = 0u;
+    L.misc[3] = 0u;
   }
   for (uint32_t t = threadIdx.x; t < kRorRows; t += kBlock) L.rowstart[t] = 0u;
   for (uint32_t t = threadIdx.x; t < kMaxN / 32u; t += kBlock) L.late[t] = 0u;
@@ -82,38 +90,79 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   // ---- stage 1: E1 keep bits, y extent, and the index-neighbour test ----------------------
   uint32_t kept = 0, keep = 0;
   float ymin = __uint_as_float(0x7F800000u), ymax = __uint_as_float(0xFF800000u);
-  for (int j = 0; j < kIters; ++j) {
-    const uint32_t i = ((uint32_t)(j * kWaves) + wave) * 64u + lane;
-    if (i >= n) continue;
-    const uint2 nd = scan[i];
-    if (!nd_keep(nd_dist(nd), nd_quality(nd), p)) continue;
-    kept |= 1u << j;
-    const float2 me = node_xy(nd, cs);
-    ymin = fminf(ymin, me.y);
-    ymax = fmaxf(ymax, me.y);
-    uint32_t cnt = 0;
+  // A trip covers the 2048 consecutive samples [2048 t, 2048 t + 2048): every thread computes
+  // the points of its two samples ONCE and publishes them in LDS (a sample that is not kept, or
+  // lies outside the scan, as NaN: it then fails every distance test), four halo samples on
+  // either side come from eight extra threads; the index neighbours are read from there, and the
+  // raw nodes of the next trip are already on their way.  (Every thread loading and converting
+  // its eight neighbours itself — nine node loads and nine table gathers per sample behind
+  // data-dependent branches — made this stage 1.9 ms of C5's 4.3; one 1024-sample window per
+  // trip without prefetch 1.35.)
+  const float qnan = __uint_as_float(0x7FC00000u);
+  auto load_node = [&](uint32_t q) -> uint2 { return q < n ? scan[q] : make_uint2(0u, 0u); };  // dist 0: dropped
+  auto point_of = [&](uint2 c) -> float2 {
+    return nd_keep(nd_dist(c), nd_quality(c), p) ? node_xy(c, cs) : make_float2(qnan, qnan);
+  };
+  constexpr uint32_t kSpan = 2u * kBlock;
+  const int trips = (int)((n + kSpan - 1u) / kSpan);  // block-uniform
+  // software pipeline: raw nodes two trips ahead, points (the table gather) one trip ahead; the
+  // eight halo samples are a third slot of threads 0..7 and ride the same pipeline
+  const uint32_t halo_q = threadIdx.x < (uint32_t)kRorNear ? threadIdx.x - (uint32_t)kRorNear  // base - 4 + t
+                          : threadIdx.x < 2u * kRorNear    ? kSpan + threadIdx.x - (uint32_t)kRorNear
+                                                           : 0xFFFFFFFFu;  // no halo duty
+  auto halo_index = [&](uint32_t base) -> uint32_t {
+    // (first trip: base - 4 + t wraps below 0 and fails q < n; no duty: always out of range)
+    return halo_q == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + halo_q;
+  };
+  float2 p0 = point_of(load_node(threadIdx.x)), p1 = point_of(load_node(kBlock + threadIdx.x));
+  float2 ph = point_of(load_node(halo_index(0u)));
+  uint2 n0 = load_node(kSpan + threadIdx.x), n1 = load_node(kSpan + kBlock + threadIdx.x);
+  uint2 nh = load_node(halo_index(kSpan));
+  for (int t = 0; t < trips; ++t) {
+    const uint32_t base = (uint32_t)t * kSpan, i0 = base + threadIdx.x, i1 = i0 + kBlock;
+    const float2 me0 = p0, me1 = p1, meh = ph;
+    const uint2 c0 = n0, c1 = n1, ch = nh;           // nodes of trip t + 1 (loaded a trip ago)
+    n0 = load_node(i0 + 2u * kSpan);                 // nodes of trip t + 2
+    n1 = load_node(i1 + 2u * kSpan);
+    nh = load_node(halo_index(base + 2u * kSpan));
+    p0 = point_of(c0);                               // points of trip t + 1: gathers issued now
+    p1 = point_of(c1);
+    ph = point_of(ch);
+    L.win[kRorNear + threadIdx.x] = me0;
+    L.win[kRorNear + kBlock + threadIdx.x] = me1;
+    if (threadIdx.x < (uint32_t)kRorNear) L.win[threadIdx.x] = meh;
+    else if (threadIdx.x < 2u * kRorNear) L.win[kSpan + threadIdx.x] = meh;
+    __syncthreads();
 #pragma unroll
-    for (int o = 1; o <= kRorNear; ++o) {
+    for (int h = 0; h < 2; ++h) {
+      const float2 me = h ? me1 : me0;
+      const uint32_t i = h ? i1 : i0;
+      const int j = 2 * t + h;  // bit j of kept / keep: sample 1024 j + thread
+      if (me.x == me.x) {       // kept (not NaN)
+        kept |= 1u << j;
+        ymin = fminf(ymin, me.y);
+        ymax = fmaxf(ymax, me.y);
+        uint32_t cnt = 0;
+        const int at = (int)(kRorNear + threadIdx.x) + h * kBlock;
 #pragma unroll
-      for (int sgn = 0; sgn < 2; ++sgn) {
-        const uint32_t q = sgn ? i - (uint32_t)o : i + (uint32_t)o;  // i - o wraps below 0: fails q < n
-        if (cnt < need && q < n) {
-          const uint2 c = scan[q];
-          if (nd_keep(nd_dist(c), nd_quality(c), p)) {
-            const float2 pc = node_xy(c, cs);
+        for (int o = 1; o <= kRorNear; ++o) {
+#pragma unroll
+          for (int sgn = 0; sgn < 2; ++sgn) {
+            const float2 pc = L.win[at + (sgn ? -o : o)];
             const float dx = me.x - pc.x, dy = me.y - pc.y;
             const float d2 = dx * dx + dy * dy;  // products then sum (-ffp-contract=off)
-            cnt += (d2 <= r2) ? 1u : 0u;
+            cnt += (d2 <= r2) ? 1u : 0u;         // (false for a NaN neighbour)
           }
+        }
+        if (cnt >= need) {
+          keep |= 1u << j;
+        } else {  // unsettled: stage 1b / 2
+          const uint32_t slot = atomicAdd(&L.misc[2], 1u);
+          if (slot < kRorTodo) L.todo[slot] = (uint16_t)i;
         }
       }
     }
-    if (cnt >= need) {
-      keep |= 1u << j;
-    } else {  // unsettled: stage 2
-      const uint32_t slot = atomicAdd(&L.misc[2], 1u);
-      if (slot < kRorTodo) L.todo[slot] = (uint16_t)i;
-    }
+    __syncthreads();
   }
   ymin = fminf(ymin, __shfl_xor(ymin, 32, 64));  // (six steps of a butterfly)
   ymax = fmaxf(ymax, __shfl_xor(ymax, 32, 64));
@@ -127,7 +176,41 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
     atomicMax(&L.misc[1], f2ord(ymax));
   }
   __syncthreads();
-  const uint32_t n_todo_all = L.misc[2];  // block-uniform
+  // ---- stage 1b: a wave per unsettled sample, the 64 samples before and after it -------------
+  const uint32_t n_todo1 = L.misc[2];  // block-uniform
+  if (n_todo1 != 0u && n_todo1 <= kRorTodo) {
+    for (uint32_t t = wave; t < n_todo1; t += kWaves) {
+      const uint32_t i = L.todo[t];
+      const float2 me = node_xy(scan[i], cs);  // wave-uniform address
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        const uint32_t q = side ? i + 1u + lane : i - 1u - lane;  // (wraps below 0: fails q < n)
+        bool hit = false;
+        if (q < n) {
+          const uint2 c = scan[q];
+          if (nd_keep(nd_dist(c), nd_quality(c), p)) {
+            const float2 pc = node_xy(c, cs);
+            const float dx = me.x - pc.x, dy = me.y - pc.y;
+            const float d2 = dx * dx + dy * dy;
+            hit = d2 <= r2;
+          }
+        }
+        cnt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit));
+      }
+      if (lane == 0) {
+        if (cnt >= need) {
+          atomicOr(&L.late[i >> 5], 1u << (i & 31u));
+        } else {
+          L.todo2[atomicAdd(&L.misc[3], 1u)] = (uint16_t)i;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // (a scan with more unsettled samples than the list holds skips 1b: stage 2 re-examines all)
+  const uint32_t n_todo_all = n_todo1 <= kRorTodo ? L.misc[3] : n_todo1;  // block-uniform
+  const uint16_t *todo = n_todo1 <= kRorTodo ? L.todo2 : L.todo;
   if (n_todo_all != 0u) {
     const float y0 = ord2f(L.misc[0]), y1 = ord2f(L.misc[1]);
     const float r = sqrtf(p.ror_r2);
@@ -168,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
     // ---- stage 2: one wave per unsettled sample, 64 candidates at a time ---------------------
     const uint32_t n_todo = min(n_todo_all, kRorTodo);
     for (uint32_t t = wave; t < n_todo; t += kWaves) {
-      const uint32_t i = L.todo[t];
+      const uint32_t i = todo[t];
       const float2 me = node_xy(scan[i], cs);  // wave-uniform address
       const uint32_t row = row_of(me.y);
       const uint32_t a = L.rowstart[row > 0u ? row - 1u : 0u];
