@@ -8,4 +8,4 @@ timeout 300 python bench.py --cpu-seconds 0 --no-laserscan --no-decode --no-sing
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('bench', d['ms_per_step'], d['roofline']['kernel_ms_min'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'])
-print({k:(v["ms"],v["frac"]) for k,v in d["variants"].items()}, d["c5"]["ms"], d["c5"]["fused_grid"]["ms"])"
+print({k:(v[\"ms\"],v[\"frac\"]) for k,v in d[\"variants\"].items()}, d[\"c5\"][\"ms\"], d[\"c5\"][\"fused_grid\"][\"ms\"])"
