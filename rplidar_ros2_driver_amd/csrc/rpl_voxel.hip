@@ -67,6 +67,9 @@ static_assert(kRecCap * 2u <= 2u * kRowCap * 4u, "the cell-head list (u16) lives
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef RPL_RAW_AUX
+#define RPL_RAW_AUX 2  // cache policy of the raw-pair loads (bit 0 glc, bit 1 slc): streamed once
+#endif
 
 // Three independent inclusive wave64 prefix sums, interleaved so that every DPP read is two
 // issue slots behind the write it depends on (no s_nop needed) and every step is ONE
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const __amdgpu_buffer_rsrc_t scan_rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
         auto load_pair = [&](uint32_t i) -> uint4 {
-          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)(i * 16u), 0, 2);
+          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)(i * 16u), 0, RPL_RAW_AUX);
           return make_uint4(t.x, t.y, t.z, t.w);
         };
         const uint32_t *ror_bits = keepmask ? keepmask + (size_t)sc * mask_stride : nullptr;
