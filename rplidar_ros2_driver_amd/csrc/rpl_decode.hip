@@ -58,6 +58,13 @@ struct DecCfg {
                                                                         : 4u;
   // ultra: the triangulation angle correction is a function of k2 = 98361 / dist (0..491) alone
   static constexpr uint32_t kCorrSlots = ANS == RPLGPU_ANS_CAPSULED_ULTRA ? 496u : 1u;
+  // express / ultra / dense: the sync bit of a node follows from the capsule HEADERS alone, so
+  // scan boundaries are known before the payload is decoded and the nodes of completed scans
+  // can be written straight into batch slots (k_decode<..., FUSE = true>); up to kFuseSyn sync
+  // nodes and kFuseRst reset requests per stream and call, else the unfused path takes over
+  static constexpr bool kFusable = ANS == RPLGPU_ANS_CAPSULED || ANS == RPLGPU_ANS_CAPSULED_ULTRA ||
+                                   ANS == RPLGPU_ANS_DENSE_CAPSULED;
+  static constexpr uint32_t kFuseSyn = kFusable ? 256u : 1u, kFuseRst = kFusable ? 64u : 1u;
   static constexpr uint32_t kStageWords = ANS == RPLGPU_ANS_HQ ? (kDecBlock / 64) * 64 * 17 : 1u;
 };
 
@@ -214,6 +221,10 @@ struct DecodeLds {
   uint32_t crc_table[DecCfg<ANS>::kCrcWords];  // HQ: slicing-by-4 tables
   uint32_t stage[DecCfg<ANS>::kStageWords];    // HQ: per wave, 64 frames x 16 words (+1 pad)
   int32_t corr[DecCfg<ANS>::kCorrSlots];       // ultra: angle correction (Q16 -> Q6 units) by k2
+  uint32_t syn[DecCfg<ANS>::kFuseSyn];         // FUSE: sync nodes from the header pre-pass (unordered)
+  uint32_t spos[DecCfg<ANS>::kFuseSyn];        // FUSE: ... in order
+  uint16_t sslot[DecCfg<ANS>::kFuseSyn];       // FUSE: batch slot of the scan that starts at spos[j] (0xFFFF: none)
+  uint32_t rst[DecCfg<ANS>::kFuseRst];         // FUSE: reset requests (node positions, ascending)
   uint32_t tmp[40];
   uint32_t misc[8];  // 0 status, 3 last sync out, 4 last dist out, 5 error count, 6 sync nodes
 };
@@ -235,7 +246,18 @@ __device__ __forceinline__ uint32_t dec_block_scan(uint32_t v, uint32_t *tmp, ui
   return base + inc - v;
 }
 
-template <int ANS, bool FRAMED>  // FRAMED: frame offsets (and gaps) given; else frames back to back
+// k_decode<..., FUSE = true>: where the completed scans go (the batch layout of k_assemble), and
+// the per-stream switches between the fused kernel, the plain kernel and k_assemble
+struct DecFuse {
+  uint2 *batch;             // scan slot g = b * scan_cap + s at batch + g * n_stride
+  uint32_t *n_per_scan;     // [B * scan_cap]
+  uint32_t *n_scans;        // [B]
+  uint32_t *todo;           // FUSE: [B], set to 1 when this stream has to take the unfused path
+  const uint32_t *only;     // plain kernel: streams with only[b] == 0 are skipped (null: all)
+  uint32_t n_stride, scan_cap, max_count;
+};
+
+template <int ANS, bool FRAMED, bool FUSE>  // FRAMED: frame offsets (and gaps) given; else back to back
 __global__ __launch_bounds__(kDecBlock) void k_decode(
     const uint8_t *__restrict__ bytes, uint64_t stream_stride, const uint32_t *__restrict__ frame_off,
     const uint8_t *__restrict__ gap, const uint32_t *__restrict__ n_frames, uint32_t max_frames,
@@ -243,7 +265,8 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     int32_t *__restrict__ state_out, uint2 *__restrict__ nodes_out, uint32_t node_stride,
     uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ reset_at, uint32_t reset_stride,
     uint32_t *__restrict__ n_reset, uint32_t *__restrict__ n_errors, uint32_t *__restrict__ status,
-    uint32_t *__restrict__ sync_at, uint32_t sync_stride, uint32_t *__restrict__ n_sync) {
+    uint32_t *__restrict__ sync_at, uint32_t sync_stride, uint32_t *__restrict__ n_sync, DecFuse fz) {
+  static_assert(!FUSE || DecCfg<ANS>::kFusable, "FUSE: express, ultra and dense capsules only");
   constexpr uint32_t S = dec_frame_size(ANS);
   constexpr uint32_t NPF = dec_nodes_per_frame(ANS);
   constexpr bool CAPS = ANS == RPLGPU_ANS_CAPSULED || ANS == RPLGPU_ANS_CAPSULED_ULTRA ||
@@ -254,11 +277,12 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   constexpr uint32_t kRawBitWords = DecCfg<ANS>::kRawBitWords;
 
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  if (!FUSE && fz.only && fz.only[b] == 0u) return;  // (the fused kernel dealt with this stream)
   const uint8_t *base = bytes + (size_t)b * stream_stride;
   const uint32_t *foff = FRAMED ? frame_off + (size_t)b * max_frames : nullptr;
   const uint8_t *fgap = (FRAMED && gap) ? gap + (size_t)b * max_frames : nullptr;
   const uint32_t nf = min(n_frames[b], min(max_frames, DecCfg<ANS>::kMaxFrames));
-  uint2 *out = nodes_out + (size_t)b * node_stride;
+  uint2 *out = FUSE ? nullptr : nodes_out + (size_t)b * node_stride;
   auto frame_ptr = [&](uint32_t k) -> const uint8_t * {
     return base + (FRAMED ? (size_t)foff[k] : (size_t)k * S);
   };
@@ -426,6 +450,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       const uint32_t slot = carry_reset + ex_r;
       if (reset_at && slot < reset_stride)
         reset_at[(size_t)b * reset_stride + slot] = (carry_emit + ex_e) * NPF;
+      if (FUSE && slot < DecCfg<ANS>::kFuseRst) L.rst[slot] = (carry_emit + ex_e) * NPF;
     }
     carry_emit += tot_e;
     carry_reset += tot_r;
@@ -433,7 +458,118 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   carry_nodes = carry_emit * NPF;
   __syncthreads();
   const uint32_t n_emit = carry_emit;
-  const uint32_t n_out = min(carry_nodes, node_stride);
+  const uint32_t n_out = FUSE ? carry_nodes : min(carry_nodes, node_stride);
+  const int last_sync_in = state_in ? state_in[4 * b] : 0;
+  const int last_dist_in = state_in ? state_in[4 * b + 1] : 0;
+
+  // The sync-bit filter of the dense modes, s_i = r_i & ~s_{i-1} (see P4), over the raw bits in
+  // LDS; on_sync(i) is called for every node whose filtered bit is set, L.misc[3] receives the
+  // last node's bit (the state carried to the next call).
+  auto sync_filter = [&](auto on_sync) {
+    const uint32_t nwords = (carry_nodes + 63u) >> 6;
+    for (uint32_t w = tid; w < nwords && w < kRawBitWords; w += kDecBlock) {
+      unsigned long long m = L.rawbits[w];
+      while (m) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t i = (w << 6) + bit;
+        // length of the run of raw sync bits ending just before i (across words, and into the
+        // carried-in state when the run reaches the start of the stream)
+        uint32_t run = 0;
+        int j = (int)i - 1;
+        while (j >= 0 && ((L.rawbits[j >> 6] >> (j & 63)) & 1ull)) { ++run; --j; }
+        if (j < 0 && last_sync_in) {
+          // s_{-1} = 1 acts like one more raw bit in front of the run
+          ++run;
+        }
+        const uint32_t s = (run & 1u) ? 0u : 1u;
+        if (s) on_sync(i);
+        if (i == carry_nodes - 1u) L.misc[3] = s;  // carried-out state
+      }
+    }
+    if (tid == 0 && carry_nodes) {
+      const uint32_t i = carry_nodes - 1u;
+      if (!((L.rawbits[i >> 6] >> (i & 63)) & 1ull)) L.misc[3] = 0u;
+    }
+  };
+
+  // ---- FUSE: scan boundaries from the capsule headers, before any payload is touched -------
+  uint32_t f_nsync = 0;  // sync nodes of the stream (in order in L.spos)
+  if (FUSE) {
+    constexpr uint32_t kSyn = DecCfg<ANS>::kFuseSyn, kRst = DecCfg<ANS>::kFuseRst;
+    // every node's raw sync bit: ((angle + step) mod 360 deg) < step (dense: 2 x step), a function
+    // of the two start angles of its capsule pair (:246-257 and siblings) — one lane per frame
+    for (uint32_t e = tid; e < n_emit; e += kDecBlock) {
+      const uint32_t k = L.emit_frame[e];
+      const int cur_q8 = (int)(L.frame[k] & 0x7FFFu) << 2, prev_q8 = (int)(L.frame[k - 1] & 0x7FFFu) << 2;
+      int diff_q8 = cur_q8 - prev_q8;
+      if (prev_q8 > cur_q8) diff_q8 += (360 << 8);
+      const int inc = ANS == RPLGPU_ANS_CAPSULED         ? diff_q8 << 3
+                      : ANS == RPLGPU_ANS_CAPSULED_ULTRA ? (diff_q8 << 3) / 3
+                                                         : (diff_q8 << 8) / 40;
+      const int lim = ANS == RPLGPU_ANS_DENSE_CAPSULED ? inc * 2 : inc;
+      for (uint32_t pos = 0; pos < NPF; ++pos) {
+        const int ang = (prev_q8 << 8) + (int)pos * inc;
+        if (((ang + inc) % (360 << 16)) < lim) {
+          const uint32_t i = e * NPF + pos;
+          if (FILTERED) {
+            atomicOr(&L.rawbits[i >> 6], 1ull << (i & 63u));
+          } else {
+            const uint32_t at = atomicAdd(&L.misc[6], 1u);
+            if (at < kSyn) L.syn[at] = i;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (FILTERED) {
+      sync_filter([&](uint32_t i) {
+        const uint32_t at = atomicAdd(&L.misc[6], 1u);
+        if (at < kSyn) L.syn[at] = i;
+      });
+      __syncthreads();
+    }
+    f_nsync = L.misc[6];
+    if (f_nsync > kSyn || carry_reset > kRst) {  // (block-uniform) more than the tables hold:
+      if (tid == 0) fz.todo[b] = 1u;             // this stream takes the unfused path, nothing
+      return;                                    // has been written for it yet
+    }
+    if (tid == 0) fz.todo[b] = 0u;
+    // order the (few) sync nodes; scan j = [spos[j], spos[j+1]) is complete iff no reset request
+    // p has spos[j] < p <= spos[j+1] (ScanDataHolder, src/sdk/src/sl_lidar_driver.cpp:272-315)
+    if (tid < f_nsync) {
+      const uint32_t v = L.syn[tid];
+      uint32_t rank = 0;
+      for (uint32_t q = 0; q < f_nsync; ++q) rank += L.syn[q] < v ? 1u : 0u;
+      L.spos[rank] = v;
+    }
+    __syncthreads();
+    uint32_t ok = 0, s0 = 0, s1 = 0;
+    if (tid + 1u < f_nsync) {
+      s0 = L.spos[tid];
+      s1 = L.spos[tid + 1u];
+      ok = 1;
+      for (uint32_t r = 0; r < carry_reset; ++r) {
+        const uint32_t p = L.rst[r];
+        if (p > s0 && p <= s1) ok = 0;
+      }
+    }
+    uint32_t completed;
+    const uint32_t slot = dec_block_scan(ok, L.tmp, &completed);
+    if (tid < kSyn) L.sslot[tid] = (ok && slot < fz.scan_cap) ? (uint16_t)slot : (uint16_t)0xFFFFu;
+    uint32_t st_bits = 0;
+    if (ok && slot < fz.scan_cap) {
+      const uint32_t full = min(s1 - s0, fz.max_count);
+      fz.n_per_scan[(size_t)b * fz.scan_cap + slot] = min(full, fz.n_stride);
+      if (full > fz.n_stride) st_bits |= RPLGPU_SCAN_OUT_TRUNCATED;
+    }
+    if (completed > fz.scan_cap) st_bits |= RPLGPU_STREAM_RESETS_TRUNCATED;
+    if (st_bits) atomicOr(&L.misc[0], st_bits);
+    for (uint32_t q = min(completed, fz.scan_cap) + tid; q < fz.scan_cap; q += kDecBlock)
+      fz.n_per_scan[(size_t)b * fz.scan_cap + q] = 0u;
+    if (tid == 0) fz.n_scans[b] = min(completed, fz.scan_cap);
+    __syncthreads();
+  }
 
 #ifdef RPL_DEC_DBG
   __syncthreads();
@@ -446,8 +582,6 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   // spent ~85 instructions per node, most of them per-frame work repeated 40 times, behind a
   // chain of four dependent loads.)  Sync nodes are rare (one or two per revolution): they are
   // reported through LDS / global atomics instead of a ballot per pass.
-  const int last_sync_in = state_in ? state_in[4 * b] : 0;
-  const int last_dist_in = state_in ? state_in[4 * b + 1] : 0;
   constexpr uint32_t G = DecCfg<ANS>::kGroup, GPF = NPF / G;
   static_assert(GPF * G == NPF, "groups tile a frame");
   const uint32_t n_groups = carry_emit * GPF;
@@ -461,6 +595,8 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   // being computed — one group per trip left the kernel waiting on a chain of dependent loads)
   struct GroupIn {
     uint32_t pos0, off_prev, off_cur;  // byte offsets of the frames k-1 and k in the stream
+    uint32_t scan_j;                   // FUSE: the scan the group's first node lies in (-1: none yet)
+    bool live;                         // FUSE: some node of the group belongs to a stored scan
     int prev_q8, diff_q8;
     uint64_t w;   // first 8 payload bytes of the group
     uint32_t w2;  // the bytes after them (express / ultra-dense: 2, ultra: the next cabin word)
@@ -469,6 +605,17 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   auto locate = [&](uint32_t t, GroupIn &g) {  // which frames, where (table look-ups only)
     const uint32_t e = t / GPF, q = t - e * GPF;
     g.pos0 = q * G;
+    g.live = true;
+    if (FUSE) {
+      const uint32_t i = t * G;
+      uint32_t j = 0xFFFFFFFFu;
+      for (uint32_t s_ = 0; s_ < f_nsync && L.spos[s_] <= i; ++s_) j = s_;
+      g.scan_j = j;
+      const bool in_stored = j != 0xFFFFFFFFu && j + 1u < f_nsync && L.sslot[j] != 0xFFFFu;
+      const bool crosses = j + 1u < f_nsync && L.spos[j + 1u] < i + G;  // (j = -1: first sync node)
+      g.live = in_stored || crosses;
+      if (!g.live) return;
+    }
     const uint32_t k = DecCfg<ANS>::kTable ? (uint32_t)L.emit_frame[e] : e;
     constexpr bool kPrev = CAPS;  // capsule types decode frame k-1 with frame k's start angle
     if (FRAMED) {
@@ -488,6 +635,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     }
   };
   auto fetch = [&](GroupIn &g) {  // the payload loads (nothing here waits for another load)
+    if (FUSE && !g.live) return;
     if (ANS == RPLGPU_ANS_MEASUREMENT) {
       const uint8_t *f = base + g.off_cur;
       g.w = (uint64_t)ld8(f) | ((uint64_t)ld16(f + 1) << 8) | ((uint64_t)ld16(f + 3) << 24);
@@ -515,6 +663,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     }
   };
   auto emit = [&](uint32_t t, const GroupIn &g) {
+    if (FUSE && !g.live) return;
     const uint32_t i = t * G, pos0 = g.pos0;
     const int prev_q8 = g.prev_q8, diff_q8 = g.diff_q8;
     uint2 nd[G];
@@ -640,6 +789,34 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       if (hsh != 0xDEADBEEFu) return;
     }
 #endif
+    if (FUSE) {
+      // where the nodes go: scan j = the last sync node at or before the node; a node in front
+      // of the first sync node, in the scan still open at the end, in a scan a reset broke or
+      // beyond scan_cap is not stored at all
+      uint32_t j = g.scan_j;  // (-1: in front of the first sync node)
+#pragma unroll
+      for (uint32_t jn = 0; jn < G; ++jn) {
+        const uint32_t ii = i + jn;
+        while (j + 1u < f_nsync && L.spos[j + 1u] <= ii) ++j;  // (j = -1: 0 < f_nsync)
+        if (j == 0xFFFFFFFFu || j + 1u >= f_nsync) continue;
+        const uint32_t slot = L.sslot[j];
+        if (slot == 0xFFFFu) continue;
+        const uint32_t s0 = L.spos[j], total = L.spos[j + 1u] - s0;
+        const uint32_t full = min(total, fz.max_count), len = min(full, fz.n_stride);
+        const uint32_t off = ii - s0;
+        // ScanDataHolder keeps max_count nodes: the last slot of a longer scan holds its last node
+        uint32_t pos = off;
+        if (off + 1u >= len) {
+          const uint32_t last_src = (len == full && total > full) ? total - 1u : len - 1u;
+          if (off != last_src) continue;
+          pos = len - 1u;
+        }
+        uint2 v = nd[jn];
+        if (FILTERED && off == 0u) v.y = (v.y & 0x00FFFFFFu) | (1u << 24);  // flag byte 2 -> 1
+        fz.batch[((size_t)b * fz.scan_cap + slot) * fz.n_stride + pos] = v;
+      }
+      return;
+    }
     if (i + G <= n_out) {  // dense types: the (rare) sync flags are set in P4
       if (G == 1) {
         out[i] = nd[0];
@@ -699,37 +876,17 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   int last_sync_out = last_sync_in, last_dist_out = last_dist_in;
   if (FILTERED) {
     __syncthreads();
-    const uint32_t nwords = (carry_nodes + 63u) >> 6;
-    for (uint32_t w = tid; w < nwords && w < kRawBitWords; w += kDecBlock) {
-      unsigned long long m = L.rawbits[w];
-      while (m) {
-        const uint32_t bit = (uint32_t)__builtin_ctzll(m);
-        m &= m - 1ull;
-        const uint32_t i = (w << 6) + bit;
-        // length of the run of raw sync bits ending just before i (across words, and into the
-        // carried-in state when the run reaches the start of the stream)
-        uint32_t run = 0;
-        int j = (int)i - 1;
-        while (j >= 0 && ((L.rawbits[j >> 6] >> (j & 63)) & 1ull)) { ++run; --j; }
-        if (j < 0 && last_sync_in) {
-          // s_{-1} = 1 acts like one more raw bit in front of the run
-          ++run;
-        }
-        const uint32_t s = (run & 1u) ? 0u : 1u;
-        if (s && i < n_out) {  // flag byte: sync | (!sync << 1) : 2 -> 1
+    if (!FUSE) {  // (FUSE: done in front of P3, the flags were set as the nodes were stored)
+      sync_filter([&](uint32_t i) {
+        if (i < n_out) {  // flag byte: sync | (!sync << 1) : 2 -> 1
           uint2 v = out[i];
           v.y = (v.y & 0x00FFFFFFu) | (1u << 24);
           out[i] = v;
           report_sync(i);
         }
-        if (i == carry_nodes - 1u) L.misc[3] = s;  // carried-out state
-      }
+      });
+      __syncthreads();
     }
-    if (tid == 0 && carry_nodes) {
-      const uint32_t i = carry_nodes - 1u;
-      if (!((L.rawbits[i >> 6] >> (i & 63)) & 1ull)) L.misc[3] = 0u;
-    }
-    __syncthreads();
     if (carry_nodes) last_sync_out = (int)L.misc[3];
   }
 
@@ -897,10 +1054,10 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   __syncthreads();
   if (tid == 0) {
     uint32_t st = L.misc[0];
-    if (carry_nodes > node_stride) st |= RPLGPU_SCAN_OUT_TRUNCATED;
+    if (!FUSE && carry_nodes > node_stride) st |= RPLGPU_SCAN_OUT_TRUNCATED;
     if (reset_at && carry_reset > reset_stride) st |= RPLGPU_STREAM_RESETS_TRUNCATED;
     if (FILTERED && carry_nodes > kRawBitWords * 64u) st |= RPLGPU_STREAM_FRAMES_TRUNCATED;
-    n_nodes[b] = bad_framing ? 0u : n_out;
+    if (n_nodes) n_nodes[b] = bad_framing ? 0u : n_out;
     if (n_reset) n_reset[b] = bad_framing ? 0u : min(carry_reset, reset_at ? reset_stride : carry_reset);
 #ifdef RPL_DEC_DBG
     if (reset_at && reset_stride >= 8)
@@ -1043,7 +1200,8 @@ __global__ __launch_bounds__(kDecBlock) void k_assemble(
     const uint32_t *__restrict__ sync_at, uint32_t sync_stride, const uint32_t *__restrict__ n_sync,
     const uint32_t *__restrict__ reset_at, uint32_t reset_stride, const uint32_t *__restrict__ n_reset,
     uint32_t max_count, uint2 *__restrict__ batch, uint32_t n_stride, uint32_t scan_cap,
-    uint32_t *__restrict__ n_per_scan, uint32_t *__restrict__ n_scans, uint32_t *__restrict__ status, uint32_t dbg_mode) {
+    uint32_t *__restrict__ n_per_scan, uint32_t *__restrict__ n_scans, uint32_t *__restrict__ status,
+    const uint32_t *__restrict__ only) {
   __shared__ uint32_t sync_pos[kSegMaxSync + 1];
   __shared__ uint32_t unsorted[kSegMaxSync + 1];
   __shared__ uint32_t tmp[8];
@@ -1051,6 +1209,7 @@ __global__ __launch_bounds__(kDecBlock) void k_assemble(
   // have a scan to copy are mostly those of slot 0 — with the slot fastest and scan_cap = 4 all
   // of them landed on two of the eight XCDs: 0.50 ms instead of 0.2 ms per 0.5 GB)
   const uint32_t b = blockIdx.x, slot = blockIdx.y, tid = threadIdx.x;
+  if (only && only[b] == 0u) return;  // (the fused decoder delivered this stream's scans itself)
   const uint2 *in = nodes + (size_t)b * node_stride;
   const uint32_t n = min(n_nodes[b], node_stride);
   const uint32_t nr = (reset_at && n_reset) ? min(n_reset[b], reset_stride) : 0u;
@@ -1104,7 +1263,7 @@ __global__ __launch_bounds__(kDecBlock) void k_assemble(
     if (completed > scan_cap) st |= RPLGPU_STREAM_RESETS_TRUNCATED;
   }
   uint32_t len = 0;
-  if (mine != 0xFFFFFFFFu && !(dbg_mode & 1u)) {
+  if (mine != 0xFFFFFFFFu) {
     const uint32_t s0 = sync_pos[mine], s1 = sync_pos[mine + 1];
     const uint32_t full = min(s1 - s0, max_count);  // ScanDataHolder keeps max_count nodes
     len = min(full, n_stride);
@@ -1187,17 +1346,19 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
                          uint32_t node_stride, uint32_t *n_nodes, uint32_t *reset_at,
                          uint32_t reset_stride, uint32_t *n_reset, uint32_t *n_errors,
                          uint32_t *status, uint32_t *sync_at, uint32_t sync_stride,
-                         uint32_t *n_sync) {
+                         uint32_t *n_sync, const uint32_t *only) {
   if (B == 0) return hipSuccess;
-#define RPL_LAUNCH_DEC2(A, F)                                                                    \
-  hipLaunchKernelGGL((k_decode<A, F>), dim3(B), dim3(kDecBlock), 0, s, bytes, stream_stride,    \
+  DecFuse fz{};
+  fz.only = only;
+#define RPL_LAUNCH_DEC3(A, F, Z)                                                                 \
+  hipLaunchKernelGGL((k_decode<A, F, Z>), dim3(B), dim3(kDecBlock), 0, s, bytes, stream_stride, \
                      frame_off, gap, n_frames, max_frames, sample_duration_us, state_in,         \
                      state_out, (uint2 *)nodes, node_stride, n_nodes, reset_at, reset_stride,    \
-                     n_reset, n_errors, status, sync_at, sync_stride, n_sync)
-#define RPL_LAUNCH_DEC(A)                   \
-  do {                                      \
-    if (frame_off) RPL_LAUNCH_DEC2(A, true); \
-    else RPL_LAUNCH_DEC2(A, false);         \
+                     n_reset, n_errors, status, sync_at, sync_stride, n_sync, fz)
+#define RPL_LAUNCH_DEC(A)                          \
+  do {                                             \
+    if (frame_off) RPL_LAUNCH_DEC3(A, true, false); \
+    else RPL_LAUNCH_DEC3(A, false, false);         \
   } while (0)
   switch (ans) {
     case RPLGPU_ANS_MEASUREMENT: RPL_LAUNCH_DEC(RPLGPU_ANS_MEASUREMENT); break;
@@ -1209,7 +1370,48 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
     default: return hipErrorInvalidValue;
   }
 #undef RPL_LAUNCH_DEC
-#undef RPL_LAUNCH_DEC2
+  return hipGetLastError();
+}
+
+bool decode_fusable(int ans) {
+  return ans == RPLGPU_ANS_CAPSULED || ans == RPLGPU_ANS_CAPSULED_ULTRA || ans == RPLGPU_ANS_DENSE_CAPSULED;
+}
+
+// The fused decoder (express / ultra / dense): completed scans straight into batch slots; d_todo[b]
+// = 1 for a stream it could not take (more sync nodes or reset requests than its tables hold).
+hipError_t launch_decode_fused(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
+                               const uint32_t *frame_off, const uint8_t *gap,
+                               const uint32_t *n_frames, uint32_t max_frames, uint32_t B,
+                               uint32_t sample_duration_us, const int32_t *state_in,
+                               int32_t *state_out, uint32_t *n_errors, uint32_t *status,
+                               uint32_t max_count, void *batch, uint32_t n_stride,
+                               uint32_t scan_cap, uint32_t *n_per_scan, uint32_t *n_scans,
+                               uint32_t *todo) {
+  if (B == 0) return hipSuccess;
+  DecFuse fz{};
+  fz.batch = (uint2 *)batch;
+  fz.n_per_scan = n_per_scan;
+  fz.n_scans = n_scans;
+  fz.todo = todo;
+  fz.n_stride = n_stride;
+  fz.scan_cap = scan_cap;
+  fz.max_count = max_count;
+  uint2 *nodes = nullptr;
+  const uint32_t node_stride = 0xFFFFFFFFu, reset_stride = 0, sync_stride = 0;
+  uint32_t *n_nodes = nullptr, *reset_at = nullptr, *n_reset = nullptr, *sync_at = nullptr, *n_sync = nullptr;
+#define RPL_LAUNCH_FUSED(A)                         \
+  do {                                              \
+    if (frame_off) RPL_LAUNCH_DEC3(A, true, true);  \
+    else RPL_LAUNCH_DEC3(A, false, true);           \
+  } while (0)
+  switch (ans) {
+    case RPLGPU_ANS_CAPSULED: RPL_LAUNCH_FUSED(RPLGPU_ANS_CAPSULED); break;
+    case RPLGPU_ANS_CAPSULED_ULTRA: RPL_LAUNCH_FUSED(RPLGPU_ANS_CAPSULED_ULTRA); break;
+    case RPLGPU_ANS_DENSE_CAPSULED: RPL_LAUNCH_FUSED(RPLGPU_ANS_DENSE_CAPSULED); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef RPL_LAUNCH_FUSED
+#undef RPL_LAUNCH_DEC3
   return hipGetLastError();
 }
 
@@ -1231,12 +1433,12 @@ hipError_t launch_assemble(hipStream_t s, const void *nodes, uint32_t node_strid
                            const uint32_t *n_sync, const uint32_t *reset_at, uint32_t reset_stride,
                            const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *batch,
                            uint32_t n_stride, uint32_t scan_cap, uint32_t *n_per_scan,
-                           uint32_t *n_scans, uint32_t *status) {
+                           uint32_t *n_scans, uint32_t *status, const uint32_t *only) {
   if (B == 0 || scan_cap == 0) return hipSuccess;
   hipLaunchKernelGGL(k_assemble, dim3(B, scan_cap), dim3(kDecBlock), 0, s, (const uint2 *)nodes,
                      node_stride, n_nodes, sync_at, sync_stride, n_sync, reset_at, reset_stride,
                      n_reset, max_count, (uint2 *)batch, n_stride, scan_cap, n_per_scan, n_scans,
-                     status, (uint32_t)(std::getenv("RPLGPU_ASM_MODE") ? std::atoi(std::getenv("RPLGPU_ASM_MODE")) : 0));
+                     status, only);
   return hipGetLastError();
 }
 uint32_t decode_sync_stride() { return kSegMaxSync + 1u; }

@@ -84,7 +84,16 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
                          uint32_t node_stride, uint32_t *n_nodes, uint32_t *reset_at,
                          uint32_t reset_stride, uint32_t *n_reset, uint32_t *n_errors,
                          uint32_t *status, uint32_t *sync_at = nullptr, uint32_t sync_stride = 0,
-                         uint32_t *n_sync = nullptr);
+                         uint32_t *n_sync = nullptr, const uint32_t *only = nullptr);
+bool decode_fusable(int ans);
+hipError_t launch_decode_fused(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
+                               const uint32_t *frame_off, const uint8_t *gap,
+                               const uint32_t *n_frames, uint32_t max_frames, uint32_t B,
+                               uint32_t sample_duration_us, const int32_t *state_in,
+                               int32_t *state_out, uint32_t *n_errors, uint32_t *status,
+                               uint32_t max_count, void *batch, uint32_t n_stride,
+                               uint32_t scan_cap, uint32_t *n_per_scan, uint32_t *n_scans,
+                               uint32_t *todo);
 hipError_t launch_segment(hipStream_t s, const void *nodes, uint32_t node_stride,
                           const uint32_t *n_nodes, const uint32_t *reset_at, uint32_t reset_stride,
                           const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *out_nodes,
@@ -97,7 +106,7 @@ hipError_t launch_assemble(hipStream_t s, const void *nodes, uint32_t node_strid
                            const uint32_t *n_sync, const uint32_t *reset_at, uint32_t reset_stride,
                            const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *batch,
                            uint32_t n_stride, uint32_t scan_cap, uint32_t *n_per_scan,
-                           uint32_t *n_scans, uint32_t *status);
+                           uint32_t *n_scans, uint32_t *status, const uint32_t *only = nullptr);
 uint32_t decode_sync_stride();
 hipError_t launch_scans_to_batch(hipStream_t s, const void *seg_nodes, uint32_t seg_stride,
                                  const uint32_t *scan_off, uint32_t scan_cap,

@@ -997,7 +997,7 @@ int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
   auto up256 = [](size_t v) { return (v + 255) & ~size_t(255); };
   const size_t sz_nodes = up256((size_t)B * node_stride * 8), sz_sync = up256((size_t)B * sync_stride * 4);
   const size_t sz_rst = up256((size_t)B * reset_stride * 4), sz_cnt = up256((size_t)B * 4);
-  const size_t need = sz_nodes + sz_sync + sz_rst + 3 * sz_cnt;
+  const size_t need = sz_nodes + sz_sync + sz_rst + 4 * sz_cnt;
   if (h->scans_cap < need) {
     RPL_HIP(h, hipStreamSynchronize(h->stream));
     if (h->d_scans) (void)hipFree(h->d_scans);
@@ -1011,14 +1011,26 @@ int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
   uint32_t *t_sync = reinterpret_cast<uint32_t *>(p + sz_nodes);
   uint32_t *t_rst = reinterpret_cast<uint32_t *>(p + sz_nodes + sz_sync);
   uint32_t *t_nn = reinterpret_cast<uint32_t *>(p + sz_nodes + sz_sync + sz_rst);
-  uint32_t *t_nr = t_nn + sz_cnt / 4, *t_ns = t_nr + sz_cnt / 4;
+  uint32_t *t_nr = t_nn + sz_cnt / 4, *t_ns = t_nr + sz_cnt / 4, *t_todo = t_ns + sz_cnt / 4;
+  // express / ultra / dense: the fused decoder knows the scan boundaries from the capsule headers
+  // and writes the nodes of completed scans straight into their batch slots; a stream with more
+  // sync nodes / reset requests than its tables hold raises t_todo[b] and takes the general path
+  // below (decode to the node stream, then assemble), which skips every stream already done.
+  const uint32_t *only = nullptr;
+  if (rpl::decode_fusable(ans_type)) {
+    RPL_HIP(h, rpl::launch_decode_fused(h->stream, ans_type, d_bytes, stream_stride, d_frame_off,
+                                        d_gap, d_n_frames, max_frames, B, sample_duration_us,
+                                        d_state_in, d_state_out, d_n_errors, d_status, max_count,
+                                        d_batch, n_stride, scan_cap, d_n_per_scan, d_n_scans, t_todo));
+    only = t_todo;
+  }
   RPL_HIP(h, rpl::launch_decode(h->stream, ans_type, d_bytes, stream_stride, d_frame_off, d_gap,
                                 d_n_frames, max_frames, B, sample_duration_us, d_state_in,
                                 d_state_out, t_nodes, node_stride, t_nn, t_rst, reset_stride, t_nr,
-                                d_n_errors, d_status, t_sync, sync_stride, t_ns));
+                                d_n_errors, d_status, t_sync, sync_stride, t_ns, only));
   RPL_HIP(h, rpl::launch_assemble(h->stream, t_nodes, node_stride, t_nn, t_sync, sync_stride, t_ns,
                                   t_rst, reset_stride, t_nr, B, max_count, d_batch, n_stride,
-                                  scan_cap, d_n_per_scan, d_n_scans, d_status));
+                                  scan_cap, d_n_per_scan, d_n_scans, d_status, only));
   return RPLGPU_OK;
 }
 

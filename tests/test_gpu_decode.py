@@ -387,6 +387,63 @@ def test_decode_scans_matches_oracle_chain(gpu, oracle, ans):
     assert np.all(cnt[lens == 0] == 0)
 
 
+@pytest.mark.parametrize("ans", [0x82, 0x84, 0x85])
+def test_decode_scans_streams_beyond_the_fused_tables(gpu, oracle, ans):
+    """The fused decoder of the express / ultra / dense types holds 256 sync nodes and 64 reset
+    requests per stream; streams beyond that (a revolution per capsule, corrupted headers) must
+    come out the same through the general path, next to streams the fused path handles."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    S = cp.FRAME_SIZE[ans]
+    nf = 1200
+    streams = [cp.make_stream(ans, nf, 900 + b, corrupt=(b == 2), payload="random" if b % 2 else "ring",
+                              frames_per_rev=fpr) for b, fpr in enumerate((3.0, 30.0, 2.2, 3.7, 55.0, 2.6))]
+    B = len(streams)
+    stride = max(len(d) for d in streams)
+    mf = max(len(d) for d in streams) // S + 1
+    buf = np.zeros((B, stride), np.uint8)
+    offs = np.zeros((B, mf), np.uint32)
+    gaps = np.zeros((B, mf), np.uint8)
+    nfs = np.zeros(B, np.int32)
+    for b, d in enumerate(streams):  # (host framing: the corrupted stream has junk between frames)
+        buf[b, : len(d)] = d
+        o, g = abi.frame_stream(ans, d)
+        nfs[b] = len(o)
+        offs[b, : len(o)], gaps[b, : len(o)] = o, g
+    d_bytes = torch.from_numpy(buf).to(dev)
+    d_off = torch.from_numpy(offs.view(np.int32)).to(dev)
+    d_gap = torch.from_numpy(gaps).to(dev)
+    d_nf = torch.from_numpy(nfs).to(dev)
+    scan_cap, n_stride = 512, 256
+    d_batch = torch.zeros(B * scan_cap, n_stride * 8, dtype=torch.uint8, device=dev)
+    d_len = torch.full((B * scan_cap,), -1, dtype=torch.int32, device=dev)
+    d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_ne = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    gpu.decode_scans_dev(ans, 125, d_bytes.data_ptr(), stride, d_off.data_ptr(), d_gap.data_ptr(),
+                         d_nf.data_ptr(), mf, B, 0, 0, 8192, d_batch.data_ptr(), n_stride, scan_cap, d_len.data_ptr(), d_ns.data_ptr(),
+                         d_ne.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    batch = d_batch.cpu().numpy().view(NODE_DTYPE).reshape(B * scan_cap, n_stride)
+    lens, ns, ne = d_len.cpu().numpy(), d_ns.cpu().numpy(), d_ne.cpu().numpy()
+    many = 0
+    for b, d in enumerate(streams):
+        nodes, rst, err, _ = oracle.unpack(ans, d, 125)
+        scans, w_off = oracle.segment(nodes, rst, 8192)
+        n_want = len(w_off) - 1
+        many += n_want > 256 or len(rst) > 64
+        assert ne[b] == err and ns[b] == min(n_want, scan_cap), (hex(ans), b)
+        for s_ in range(scan_cap):
+            g = b * scan_cap + s_
+            if s_ >= n_want:
+                assert lens[g] == 0
+                continue
+            scan = scans[w_off[s_]: w_off[s_ + 1]]
+            keep = min(len(scan), n_stride)
+            assert lens[g] == keep and batch[g, :keep].tobytes() == scan[:keep].tobytes(), (hex(ans), b, s_)
+    assert many >= 2  # the general path really was taken
+
+
 def test_decode_full_size_properties(gpu):
     """BASELINE config-3 shape for the decode stage (4096 DenseBoost streams x 801 capsules =
     131 M nodes), checked through size-independent properties computed on the device:
