@@ -227,9 +227,11 @@ int32_t rplgpu_scans_to_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_seg_
                                   uint32_t *d_scan_base, rplgpu_node_t *d_batch, uint32_t n_stride,
                                   uint32_t max_scans, uint32_t *d_n_per_scan);
 /* The whole step before the path in ONE call: recorded streams -> completed scans, written
- * straight into the fixed-stride batch the *_batch_dev entry points take (the decoder reports
- * its sync nodes, so the node stream is not searched again, and the scans are not copied
- * twice).  Decoding as rplgpu_decode_batch_dev, assembly rules as rplgpu_segment_batch_dev
+ * straight into the fixed-stride batch the *_batch_dev entry points take.  Express, ultra and
+ * dense capsules: scan boundaries follow from the capsule headers, so the nodes of completed scans
+ * are decoded directly into their slots and the others not at all; the other types (and streams
+ * with more than 256 sync nodes / 64 reset requests per call) are decoded to a node stream in
+ * scratch first, with the decoder's own list of sync nodes.  Decoding as rplgpu_decode_batch_dev, assembly rules as rplgpu_segment_batch_dev
  * (ScanDataHolder, src/sdk/src/sl_lidar_driver.cpp:272-315).  Completed scan s of stream b is
  * batch slot g = b*scan_cap + s: nodes at d_batch + g*n_stride, d_n_per_scan[g] of them
  * (RPLGPU_SCAN_OUT_TRUNCATED in d_status[b] when a scan is longer than n_stride); the slots a
