@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--samples", type=int, default=32000, help="samples per scan")
     ap.add_argument("--out-stride", type=int, default=8192, help="cloud slots per scan")
     ap.add_argument("--seed", type=int, default=2026)
-    ap.add_argument("--chunks", type=int, default=2,
+    ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1: pieces a rank's block is cut into (gather of piece k overlaps "
                          "compute of piece k + 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
@@ -425,7 +425,10 @@ def main():
     if use_dist:
         # N > 1: the library's own exchange (RCCL behind the C ABI): the rank's block is cut into
         # chunks; chunk k is voxelised into arena half (k & 1) while chunk k - 1 is gathered
-        exch = CloudExchange(gpu, dist, dev, world, rank, B, n, out_stride, args.chunks)
+        # (auto: with one rank there is no transfer to hide, so one chunk = one launch; with peers
+        # two chunks, so that the first half's clouds travel while the second half is voxelised)
+        n_chunks = args.chunks if args.chunks > 0 else (1 if world == 1 else 2)
+        exch = CloudExchange(gpu, dist, dev, world, rank, B, n, out_stride, n_chunks)
 
     def step():
         if exch is None:
@@ -469,7 +472,7 @@ def main():
                         "exchange_only_ms": round(ms_x, 4),
                         "overlapped_ms": round(elapsed / args.steps * 1e3, 4),
                         "gathered_bytes_per_rank": exch.last_bytes(),
-                        "exchange_backend": exch.backend,
+                        "exchange_backend": exch.backend, "chunks": exch.chunks,
                         "note": "compute = the rank's whole block in one launch, no exchange; "
                                 "exchange_only = RCCL all-gather of the last step's clouds; "
                                 "overlapped = the timed step (chunked, two streams)"}
