@@ -35,7 +35,7 @@ constexpr int kDecBlock = 256;
 constexpr uint32_t kDecMaxFrames = 2048;     // frames of one stream per call (LDS frame table)
 constexpr uint32_t kUdMaxFrames = 512;       // ultra-dense: 64 nodes each -> 32768 LDS slots
 // LDS is sized per answer type so that several streams share a CU (a 32 000-sample DenseBoost
-// scan is 800 frames): dense 26 KiB, express / ultra / legacy 16 KiB, HQ 20 KiB, ultra-dense 72 KiB
+// scan is 800 frames): dense 25 KiB, express / ultra 16 KiB, HQ 34 KiB, ultra-dense 24 KiB
 template <int ANS>
 struct DecCfg {
   static constexpr bool kFiltered =
@@ -49,7 +49,11 @@ struct DecCfg {
   // u64 words of raw sync bits: one bit per node the stream can publish in one call
   static constexpr uint32_t kRawBitWords =
       !kFiltered ? 1u : ANS == RPLGPU_ANS_DENSE_CAPSULED ? kDecMaxFrames * 40u / 64u : kUdMaxFrames;
-  static constexpr uint32_t kSmoothSlots = ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? kUdMaxFrames * 64u : 1u;
+  // ultra-dense: nodes are decoded and smoothed in chunks of kUdChunk (the smoothing pass needs the
+  // raw distances of a chunk in LDS: 16 KiB instead of 64 KiB for the whole stream, i.e. six
+  // instead of two workgroups per CU)
+  static constexpr uint32_t kUdChunk = 8192u;
+  static constexpr uint32_t kSmoothSlots = ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? kUdChunk : 1u;
   static constexpr uint32_t kCrcWords = ANS == RPLGPU_ANS_HQ ? 1024u : 1u;
   // nodes one lane decodes in one go (all of ONE frame): per-frame arithmetic once per group,
   // payload in one or two wide loads, nodes out in 16-byte stores
@@ -225,7 +229,7 @@ struct DecodeLds {
   uint32_t spos[DecCfg<ANS>::kFuseSyn];        // FUSE: ... in order
   uint16_t sslot[DecCfg<ANS>::kFuseSyn];       // FUSE: batch slot of the scan that starts at spos[j] (0xFFFF: none)
   uint32_t rst[DecCfg<ANS>::kFuseRst];         // FUSE: reset requests (node positions, ascending)
-  uint32_t tmp[40];
+  alignas(8) uint32_t tmp[40];
   uint32_t misc[8];  // 0 status, 3 last sync out, 4 last dist out, 5 error count, 6 sync nodes
 };
 
@@ -593,6 +597,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   // What a group needs from memory (fetched for U groups before the first one is decoded: the
   // frame-table look-ups and the payload loads of the next groups travel while this one is
   // being computed — one group per trip left the kernel waiting on a chain of dependent loads)
+  uint32_t chunk0 = 0;  // ultra-dense: first node of the chunk being decoded / smoothed
   struct GroupIn {
     uint32_t pos0, off_prev, off_cur;  // byte offsets of the frames k-1 and k in the stream
     uint32_t scan_j;                   // FUSE: the scan the group's first node lies in (-1: none yet)
@@ -777,8 +782,8 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
         // |d - last| <= 8 can hold only if last <= 8192: store min(dist, 0x3FFF)
         sm[j] = scale == 0u ? (0x8000u | dist) : min(dist, 0x3FFFu);
       }
-      if (i + G <= DecCfg<ANS>::kSmoothSlots)  // (always: emitted frames <= kUdMaxFrames)
-        *reinterpret_cast<uint2 *>(&L.smooth[i]) =
+      if (i - chunk0 + G <= DecCfg<ANS>::kSmoothSlots)  // (always: a chunk is kUdChunk nodes)
+        *reinterpret_cast<uint2 *>(&L.smooth[i - chunk0]) =
             make_uint2(sm[0] | (sm[G > 1 ? 1 : 0] << 16), sm[G > 2 ? 2 : 0] | (sm[G > 3 ? 3 : 0] << 16));
     }
 #ifdef RPL_DEC_NOSTORE
@@ -851,8 +856,15 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   // that has stores in flight can only wait for "everything"; the dense kernel is
   // (decode + loads) + (stores) = 0.19 + 0.21 ms, not the larger of the two.)
   constexpr uint32_t U = ANS == RPLGPU_ANS_HQ ? 2u : 4u;
-  uint32_t t0 = tid;
-  for (; t0 + (U - 1u) * kDecBlock < n_groups; t0 += U * kDecBlock) {  // full trips: no conditions
+  constexpr bool UD = ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
+  constexpr uint32_t kChunk = UD ? DecCfg<ANS>::kUdChunk : 0xFFFFFFFFu;  // nodes per pass (UD only)
+  int last_sync_out = last_sync_in, last_dist_out = last_dist_in;
+  int chunk_last = last_dist_in;  // ultra-dense: what the node in front of the chunk left behind
+  for (chunk0 = 0; chunk0 < (UD ? max(carry_nodes, 1u) : 1u); chunk0 += (UD ? kChunk : 1u)) {
+  const uint32_t g_lo = UD ? chunk0 / G : 0u;
+  const uint32_t g_hi = UD ? min(n_groups, (chunk0 + kChunk) / G) : n_groups;
+  uint32_t t0 = g_lo + tid;
+  for (; t0 + (U - 1u) * kDecBlock < g_hi; t0 += U * kDecBlock) {  // full trips: no conditions
     GroupIn gi[U];
 #pragma unroll
     for (uint32_t u = 0; u < U; ++u) locate(t0 + u * kDecBlock, gi[u]);
@@ -861,7 +873,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
 #pragma unroll
     for (uint32_t u = 0; u < U; ++u) emit(t0 + u * kDecBlock, gi[u]);
   }
-  for (; t0 < n_groups; t0 += kDecBlock) {
+  for (; t0 < g_hi; t0 += kDecBlock) {
     GroupIn g1;
     locate(t0, g1);
     fetch(g1);
@@ -872,24 +884,6 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   __syncthreads();
   dbg_t[3] = __builtin_amdgcn_s_memtime();
 #endif
-  // ---- P4 (dense / ultra-dense): the sync-bit filter, s_i = r_i & ~s_{i-1} -------------------
-  int last_sync_out = last_sync_in, last_dist_out = last_dist_in;
-  if (FILTERED) {
-    __syncthreads();
-    if (!FUSE) {  // (FUSE: done in front of P3, the flags were set as the nodes were stored)
-      sync_filter([&](uint32_t i) {
-        if (i < n_out) {  // flag byte: sync | (!sync << 1) : 2 -> 1
-          uint2 v = out[i];
-          v.y = (v.y & 0x00FFFFFFu) | (1u << 24);
-          out[i] = v;
-          report_sync(i);
-        }
-      });
-      __syncthreads();
-    }
-    if (carry_nodes) last_sync_out = (int)L.misc[3];
-  }
-
 #ifdef RPL_DEC_DBG
   __syncthreads();
   dbg_t[4] = __builtin_amdgcn_s_memtime();
@@ -901,7 +895,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   // each thread folds a contiguous segment of the stream into one map (tracking all 9 inputs),
   // a block scan composes the segment maps, and a second walk with the now known entry state
   // writes the smoothed distances.  Exact for any input, O(n / 256) steps per thread.
-  if (ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED && carry_nodes) {
+  if (UD && carry_nodes) {  // (indices below are relative to the chunk)
     __syncthreads();
     auto rawd = [&](uint32_t i) -> int { return (int)(L.smooth[i] & 0x3FFFu); };
     auto is_s0 = [&](uint32_t i) -> bool { return (L.smooth[i] & 0x8000u) != 0u; };
@@ -924,18 +918,22 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       }
       return r;
     };
-    const uint32_t N = carry_nodes;
+    const uint32_t N = min(kChunk, carry_nodes - chunk0);
+    const bool last_chunk = chunk0 + N == carry_nodes;
     const uint32_t seg = (N + kDecBlock - 1u) / kDecBlock;
     const uint32_t i_lo = min(tid * seg, N), i_hi = min(i_lo + seg, N);
     auto patch = [&](uint32_t i, int st) {  // node i has state st: patch dist_mm_q2 if smoothed
-      if (st != 4 && i < n_out) {  // (bits 16.. of the packed node)
+      if (st != 4 && chunk0 + i < n_out) {  // (bits 16.. of the packed node)
         const uint32_t d = (uint32_t)(rawd(i) + st - 4);
-        uint2 v = out[i];
+        uint2 v = out[chunk0 + i];
         v.x = (v.x & 0xFFFFu) | (d << 16);
         v.y = (v.y & 0xFFFF0000u) | (d >> 16);
-        out[i] = v;
+        out[chunk0 + i] = v;
       }
-      if (i == N - 1u && is_s0(i)) L.misc[4] = (uint32_t)(rawd(i) + st - 4) | 0x80000000u;
+      if (i == N - 1u) {
+        L.misc[7] = (uint32_t)(rawd(i) + st - 4);  // what this chunk leaves behind (st = 4 unless scale 0)
+        if (last_chunk && is_s0(i)) L.misc[4] = (uint32_t)(rawd(i) + st - 4) | 0x80000000u;
+      }
     };
     // pass A: the segment as one map.  All 9 entry states are tracked only until the map's
     // image has shrunk to two values (smoothing halves differences: a few nodes), then only
@@ -956,7 +954,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       bool two = false;
       for (; i < i_hi && !two; ++i) {
         if (i == 0u) {
-          const int st0 = step(0u, last_dist_in);
+          const int st0 = step(0u, chunk_last);
 #pragma unroll
           for (int c = 0; c < 9; ++c) cur[c] = st0;
         } else {
@@ -1007,10 +1005,11 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       const unsigned long long other = ((unsigned long long)hi << 32) | lo;
       if ((int)lane_id() >= d) inc = compose(other, inc);
     }
-    if (lane_id() == 63) L.rawbits[wave_id()] = inc;  // (the sync bits are no longer needed)
+    unsigned long long *wmap = reinterpret_cast<unsigned long long *>(L.tmp);  // one map per wave
+    if (lane_id() == 63) wmap[wave_id()] = inc;
     __syncthreads();
     unsigned long long before = kIdent;  // everything in front of this wave
-    for (uint32_t w = 0; w < wave_id(); ++w) before = compose(before, L.rawbits[w]);
+    for (uint32_t w = 0; w < wave_id(); ++w) before = compose(before, wmap[w]);
     unsigned long long excl;
     {
       const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, 1, 64);
@@ -1023,12 +1022,15 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     int sp = (int)((excl >> (4 * 4)) & 15ull);
     // pass C: the (usually empty) head of the segment, with the true entry state
     for (uint32_t i = i_lo; i < min(i_open, i_hi); ++i) {
-      const int last = (i == 0u) ? last_dist_in : rawd(i - 1u) + sp - 4;
+      const int last = (i == 0u) ? chunk_last : rawd(i - 1u) + sp - 4;
       sp = step(i, last);
       patch(i, sp);
     }
     __syncthreads();
-    if (L.misc[4] & 0x80000000u) {
+    chunk_last = (int)L.misc[7];
+    if (!last_chunk) {
+      // (the next chunk's P3 overwrites the raw distances: every thread is past its walk here)
+    } else if (L.misc[4] & 0x80000000u) {
       last_dist_out = (int)(L.misc[4] & 0x7FFFFFFFu);
     } else {  // last node is not scale 0: _last_dist_q2 = its own distance (:1020)
       const uint32_t i = carry_nodes - 1u;
@@ -1042,6 +1044,25 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
                       : scale == 2u ? (int)((qds & 0x3FFCu) * 4u + (8187u << 2))
                                     : (int)((qds & 0x7FFCu) * 5u + (24567u << 2));
     }
+  }
+
+  }  // chunks
+
+  // ---- P4 (dense / ultra-dense): the sync-bit filter, s_i = r_i & ~s_{i-1} -------------------
+  if (FILTERED) {
+    __syncthreads();
+    if (!FUSE) {  // (FUSE: done in front of P3, the flags were set as the nodes were stored)
+      sync_filter([&](uint32_t i) {
+        if (i < n_out) {  // flag byte: sync | (!sync << 1) : 2 -> 1
+          uint2 v = out[i];
+          v.y = (v.y & 0x00FFFFFFu) | (1u << 24);
+          out[i] = v;
+          report_sync(i);
+        }
+      });
+      __syncthreads();
+    }
+    if (carry_nodes) last_sync_out = (int)L.misc[3];
   }
 
 #ifdef RPL_DEC_DBG

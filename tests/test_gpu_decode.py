@@ -82,25 +82,26 @@ def test_decode_sync_filter_runs(gpu, oracle, ans):
 def test_ultra_dense_smoothing_chains(gpu, oracle):
     """Scale-0 distances built to smooth over long chains, break chains at every distance,
     hit zero, and cross capsule boundaries (handler_capsules.cpp:997-1003)."""
-    rng = np.random.default_rng(5)
-    nfr = 60
-    f = cp.make_frames(0x86, nfr, 3, payload="random", first_sync=False)
-    walk = np.cumsum(rng.integers(-1, 2, nfr * 64)) + 500  # dist_q2 = 8 * walk: steps of 0 / 8
-    walk[rng.random(nfr * 64) < 0.05] += 40          # chain breaks
-    walk[rng.random(nfr * 64) < 0.03] = 0            # zeros
-    walk = np.clip(walk, 0, 0xFFC // 4).astype(np.uint32)
-    scale = np.where(rng.random(nfr * 64) < 0.1, rng.integers(1, 4, nfr * 64), 0).astype(np.uint32)
-    w = ((walk << 2) & 0xFFC) | scale | (rng.integers(0, 256, nfr * 64).astype(np.uint32) << 12)
-    w = w.reshape(nfr, 64)
-    e, o_ = w[:, 0::2], w[:, 1::2]
-    f[:, 10::5] = e & 0xFF
-    f[:, 11::5] = (e >> 8) & 0xFF
-    f[:, 12::5] = o_ & 0xFF
-    f[:, 13::5] = (o_ >> 8) & 0xFF
-    f[:, 14::5] = ((e >> 16) & 0xF) | (((o_ >> 16) & 0xF) << 4)
-    cp._seal_capsules(f)
-    for last in (0, 5, 8000, 8190):
-        _check_stream(gpu, oracle, 0x86, f.reshape(-1), 125, state=(0, last))
+    # (400 frames = 25 600 nodes: the kernel smooths in chunks of 8192 nodes, chains cross them)
+    for nfr in (60, 400):
+        rng = np.random.default_rng(5 + nfr)
+        f = cp.make_frames(0x86, nfr, 3, payload="random", first_sync=False)
+        walk = np.cumsum(rng.integers(-1, 2, nfr * 64)) + 500  # dist_q2 = 8 * walk: steps of 0 / 8
+        walk[rng.random(nfr * 64) < 0.05] += 40          # chain breaks
+        walk[rng.random(nfr * 64) < 0.03] = 0            # zeros
+        walk = np.clip(walk, 0, 0xFFC // 4).astype(np.uint32)
+        scale = np.where(rng.random(nfr * 64) < 0.1, rng.integers(1, 4, nfr * 64), 0).astype(np.uint32)
+        w = ((walk << 2) & 0xFFC) | scale | (rng.integers(0, 256, nfr * 64).astype(np.uint32) << 12)
+        w = w.reshape(nfr, 64)
+        e, o_ = w[:, 0::2], w[:, 1::2]
+        f[:, 10::5] = e & 0xFF
+        f[:, 11::5] = (e >> 8) & 0xFF
+        f[:, 12::5] = o_ & 0xFF
+        f[:, 13::5] = (o_ >> 8) & 0xFF
+        f[:, 14::5] = ((e >> 16) & 0xF) | (((o_ >> 16) & 0xF) << 4)
+        cp._seal_capsules(f)
+        for last in (0, 5, 8000, 8190):
+            _check_stream(gpu, oracle, 0x86, f.reshape(-1), 125, state=(0, last))
 
 
 def test_decode_state_carries_between_calls(gpu, oracle):
