@@ -157,6 +157,7 @@ def test_fuzz_decode_against_oracle(gpu, oracle, seed):
             assert len(nodes) == len(w_nodes), ctx
             assert nodes.tobytes() == w_nodes.tobytes(), ctx
             assert list(rst) == list(w_rst) and err == w_err and st == w_st, ctx
+            _fuzz_decode_scans(gpu, oracle, ans, data, dur, state, w_nodes, w_rst, w_err, w_st, rng, ctx)
             # the same recording in two pieces, state handed over (cut on a frame boundary of
             # the clean stream; for faulty streams the cut lands anywhere, which is the point)
             S = cp.FRAME_SIZE[ans]
@@ -166,3 +167,50 @@ def test_fuzz_decode_against_oracle(gpu, oracle, seed):
                 w1 = oracle.unpack(ans, data[:cut], dur, state=state)
                 assert n1.tobytes() == w1[0].tobytes() and list(r1) == list(w1[1]), ctx
                 assert e1 == w1[2] and s1 == w1[3], ctx
+
+
+def _fuzz_decode_scans(gpu, oracle, ans, data, dur, state, w_nodes, w_rst, w_err, w_st, rng, ctx):
+    """The same stream through rplgpu_decode_scans_dev (host framing; the fused decoder for express /
+    ultra / dense, the general path otherwise): completed scans in batch slots == oracle.segment of
+    the oracle's nodes, error count and carried state unchanged."""
+    import torch
+    from rplidar_ros2_driver_amd import NODE_DTYPE, abi
+    from rplidar_ros2_driver_amd import capsules as cp
+    dev = torch.device("cuda:0")
+    off, gap = abi.frame_stream(ans, data)
+    max_frames = abi.load_library().rplgpu_decode_max_frames(ans)
+    if len(off) == 0 or len(off) > max_frames:
+        return
+    nf = len(off)
+    max_count = int(rng.choice([8192, 37, 5]))
+    n_stride = int(rng.choice([4096, 64, 9]))
+    scan_cap = int(rng.choice([512, 4, 1]))
+    d_bytes = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+    d_off = torch.from_numpy(np.asarray(off, np.uint32).view(np.int32)).to(dev)
+    d_gap = torch.from_numpy(np.asarray(gap, np.uint8)).to(dev)
+    d_nf = torch.tensor([nf], dtype=torch.int32, device=dev)
+    d_sin = torch.tensor([state[0], state[1], 0, 0], dtype=torch.int32, device=dev)
+    d_sout = torch.zeros(4, dtype=torch.int32, device=dev)
+    d_batch = torch.zeros(scan_cap, n_stride * 8, dtype=torch.uint8, device=dev)
+    d_len = torch.full((scan_cap,), -1, dtype=torch.int32, device=dev)
+    d_ns = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_ne = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+    gpu.decode_scans_dev(ans, dur, d_bytes.data_ptr(), len(data), d_off.data_ptr(), d_gap.data_ptr(),
+                         d_nf.data_ptr(), nf, 1, d_sin.data_ptr(), d_sout.data_ptr(), max_count,
+                         d_batch.data_ptr(), n_stride, scan_cap, d_len.data_ptr(), d_ns.data_ptr(),
+                         d_ne.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    scans, w_off = oracle.segment(w_nodes, w_rst, max_count)
+    n_want = len(w_off) - 1
+    lens = d_len.cpu().numpy()
+    batch = d_batch.cpu().numpy().view(NODE_DTYPE).reshape(scan_cap, n_stride)
+    assert int(d_ne.item()) == w_err and int(d_ns.item()) == min(n_want, scan_cap), ctx
+    assert tuple(int(v) for v in d_sout.cpu().numpy()[:2]) == tuple(w_st), ctx
+    for s_ in range(scan_cap):
+        if s_ >= n_want:
+            assert lens[s_] == 0, ctx
+            continue
+        scan = scans[w_off[s_]: w_off[s_ + 1]]
+        keep = min(len(scan), n_stride)
+        assert lens[s_] == keep and batch[s_, :keep].tobytes() == scan[:keep].tobytes(), (ctx, s_)
