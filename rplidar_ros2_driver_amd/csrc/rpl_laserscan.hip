@@ -47,12 +47,15 @@ template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_laserscan_a(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, const float *__restrict__ inc_table, const float *__restrict__ rinc_table,
-    float *__restrict__ ranges, float *__restrict__ intens, uint32_t *__restrict__ beam_count) {
+    float *__restrict__ ranges, float *__restrict__ intens, uint32_t *__restrict__ beam_count,
+    uint32_t n_given) {
   __shared__ unsigned long long s_bins[kLsWin];
   __shared__ uint32_t s_cnt;
 
   const uint32_t b = blockIdx.x;
-  const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
+  // (single scan through pinned host memory: the length comes as an argument — reading it from
+  // the staging would be one more PCIe round trip in front of the node loads)
+  const uint32_t n = min(n_given != 0xFFFFFFFFu ? n_given : n_per_scan[b], min(n_stride, kMaxN));
   const uint2 *scan = nodes + (size_t)b * n_stride;
   float *out_r = ranges + (size_t)b * n_stride;
   float *out_i = intens + (size_t)b * n_stride;
@@ -93,8 +96,13 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
   if (count == 0) return;  // :611-613 nothing published
 
   const float *lut = p.inverted ? T.angle_inv : T.angle;  // :588-599, :646-651
-  const float inc = inc_table[count];                     // (float)(2*pi / (double)count), :635
-  const float rinc = rinc_table[count];
+  // (float)(2*pi / (double)count), :635, and its reciprocal: the IEEE operations the host used
+  // for inc_table / rinc_table (the values k_validate_idx checked), computed here instead of
+  // fetched — a dependent memory round trip less behind the count
+  const float inc = (float)(kTwoPi / (double)count);
+  const float rinc = 1.0f / inc;
+  (void)inc_table;
+  (void)rinc_table;
 
   const uint32_t ishift = p.is_new_protocol ? 16u : 18u;  // :591-592 quality or quality >> 2
   const uint32_t imask = p.is_new_protocol ? 0xFFu : 0x3Fu;
@@ -180,14 +188,18 @@ hipError_t launch_validate_idx(hipStream_t s, const Tables &T, const float *inc_
 hipError_t launch_laserscan_a(hipStream_t s, const void *nodes, uint32_t n_stride,
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                               const Tables &T, const float *inc_table, const float *rinc_table,
-                              bool fast, float *ranges, float *intens, uint32_t *beam_count) {
+                              bool fast, float *ranges, float *intens, uint32_t *beam_count,
+                              uint32_t n_given) {
   if (B == 0) return hipSuccess;
+  if (B != 1) n_given = 0xFFFFFFFFu;
   if (fast)
     hipLaunchKernelGGL(k_laserscan_a<true>, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes,
-                       n_stride, n_per_scan, p, T, inc_table, rinc_table, ranges, intens, beam_count);
+                       n_stride, n_per_scan, p, T, inc_table, rinc_table, ranges, intens, beam_count,
+                       n_given);
   else
     hipLaunchKernelGGL(k_laserscan_a<false>, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes,
-                       n_stride, n_per_scan, p, T, inc_table, rinc_table, ranges, intens, beam_count);
+                       n_stride, n_per_scan, p, T, inc_table, rinc_table, ranges, intens, beam_count,
+                       n_given);
   return hipGetLastError();
 }
 

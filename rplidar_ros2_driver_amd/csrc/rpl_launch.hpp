@@ -21,7 +21,8 @@ hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const ui
 hipError_t launch_laserscan_a(hipStream_t s, const void *nodes, uint32_t n_stride,
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                               const Tables &T, const float *inc_table, const float *rinc_table,
-                              bool fast, float *ranges, float *intens, uint32_t *beam_count);
+                              bool fast, float *ranges, float *intens, uint32_t *beam_count,
+                              uint32_t n_given = 0xFFFFFFFFu);
 hipError_t launch_validate_idx(hipStream_t s, const Tables &T, const float *inc_table,
                                const float *rinc_table, uint32_t max_count,
                                uint32_t *d_mismatches);

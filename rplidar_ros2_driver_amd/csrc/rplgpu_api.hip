@@ -304,7 +304,8 @@ int32_t validate_divisor(rplgpu_ctx *c, float d, uint32_t e_lo, uint32_t e_hi, b
 // every (beam count <= 32768, angle word, inverted or not) on this device, once per handle.
 int32_t run_laserscan(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride,
                       const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t &p,
-                      float *d_ranges, float *d_intens, uint32_t *d_beam_count) {
+                      float *d_ranges, float *d_intens, uint32_t *d_beam_count,
+                      uint32_t n_given = 0xFFFFFFFFu) {
   const rpl::KParams kp = to_kparams(p);
   if (!p.scan_processing) {
     RPL_HIP(c, rpl::launch_laserscan_raw(c->stream, d_nodes, n_stride, d_n_per_scan, B, kp, d_ranges,
@@ -325,7 +326,7 @@ int32_t run_laserscan(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride,
   }
   RPL_HIP(c, rpl::launch_laserscan_a(c->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(c),
                                      c->d_inc, c->d_rinc, c->idx_ok && c->div4000_ok, d_ranges,
-                                     d_intens, d_beam_count));
+                                     d_intens, d_beam_count, n_given));
   return RPLGPU_OK;
 }
 
@@ -781,7 +782,7 @@ int32_t rplgpu_scan_to_laserscan(rplgpu_handle_t h, const rplgpu_node_t *nodes, 
     float *d_r = reinterpret_cast<float *>(st.d_out);
     float *d_i = d_r + n;
     uint32_t *d_count = reinterpret_cast<uint32_t *>(d_i + n);
-    if (int32_t lrc = run_laserscan(h, st.d_nodes, (uint32_t)n, st.d_n, 1, *p, d_r, d_i, d_count))
+    if (int32_t lrc = run_laserscan(h, st.d_nodes, (uint32_t)n, st.d_n, 1, *p, d_r, d_i, d_count, (uint32_t)n))
       return lrc;
     if (int32_t wrc = wait_scan(h)) return wrc;
     uint32_t count;
@@ -1290,7 +1291,7 @@ int32_t rplgpu_scan_to_laserscan_msg(rplgpu_handle_t h, const rplgpu_node_t *nod
     float *d_r = reinterpret_cast<float *>(h->d_out);  // the arrays themselves stay in HBM
     float *d_i = d_r + n;
     uint32_t *d_count = reinterpret_cast<uint32_t *>(st.d_out);  // host-visible
-    if (int32_t lrc = run_laserscan(h, st.d_nodes, (uint32_t)n, st.d_n, 1, *p, d_r, d_i, d_count))
+    if (int32_t lrc = run_laserscan(h, st.d_nodes, (uint32_t)n, st.d_n, 1, *p, d_r, d_i, d_count, (uint32_t)n))
       return lrc;
     const uint32_t stride = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFCu) & ~3u;
     RPL_HIP(h, rpl::launch_msg_laserscan(h->stream, d_r, d_i, (uint32_t)n, d_count, 1,
