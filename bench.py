@@ -685,9 +685,10 @@ def main():
                 "kernel_ms_note": "avg = back-to-back launches between one event pair (this rank's "
                                   "block); min = best single launch bracketed by its own events",
                 "algorithmic_bytes": algo_bytes,
-                "note": "priced against HBM as SURVEY 8(d) asks; phase S of the kernel is bound by the "
-                        "CU's own memory pipeline (~33 k cycles per scan whatever the prefetch depth), "
-                        "phase R by vector issue + LDS latency: profiles/r02/voxel_phaseS_study.txt",
+                "note": "priced against HBM as SURVEY 8(d) asks; the kernel is vector-issue bound, not "
+                        "HBM bound: its streaming phase takes 35.5 k cycles per scan with the raw loads "
+                        "replaced by synthetic kept samples and 36.0 k with them "
+                        "(profiles/r02/voxel_phaseS_study.txt, section 8)",
             },
             "cpu_baseline": cpu,
             "variants": variants,
