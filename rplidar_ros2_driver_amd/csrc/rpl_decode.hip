@@ -828,8 +828,18 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       } else {
 #pragma unroll
         for (uint32_t j = 0; j + 1u < G; j += 2u) {
-          const uint4 v = make_uint4(nd[j].x, nd[j].y, nd[j + 1u].x, nd[j + 1u].y);
-          __builtin_memcpy(out + i + j, &v, 16);
+          // 32 bytes per lane as two streaming stores (non-temporal: the node stream is written
+          // once and read by a later kernel; -5 % dense, -13 % express, -6 % HQ).  Not for ultra:
+          // its 48 bytes per lane complete a cache line over three instructions, and streaming
+          // stores that leave lines half written cost it +46 %.
+          if (G == 4u) {
+            typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4), aligned(8)));
+            const nt_u32x4 v = {nd[j].x, nd[j].y, nd[j + 1u].x, nd[j + 1u].y};
+            __builtin_nontemporal_store(v, reinterpret_cast<nt_u32x4 *>(out + i + j));
+          } else {
+            const uint4 v = make_uint4(nd[j].x, nd[j].y, nd[j + 1u].x, nd[j + 1u].y);
+            __builtin_memcpy(out + i + j, &v, 16);
+          }
         }
       }
     } else {
