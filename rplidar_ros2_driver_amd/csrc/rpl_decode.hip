@@ -799,6 +799,31 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       // of the first sync node, in the scan still open at the end, in a scan a reset broke or
       // beyond scan_cap is not stored at all
       uint32_t j = g.scan_j;  // (-1: in front of the first sync node)
+      // the usual case: all G nodes inside one stored scan, none of them its (special) last
+      // slot -> 16-byte streaming stores, as in the unfused path
+      if (G >= 4u && j != 0xFFFFFFFFu && j + 1u < f_nsync && L.sslot[j] != 0xFFFFu &&
+          L.spos[j + 1u] >= i + G) {
+        const uint32_t s0 = L.spos[j], total = L.spos[j + 1u] - s0;
+        const uint32_t len = min(min(total, fz.max_count), fz.n_stride), off = i - s0;
+        if (off + G < len) {  // (strictly below the last slot)
+          uint2 *dst = fz.batch + ((size_t)b * fz.scan_cap + L.sslot[j]) * fz.n_stride + off;
+          uint2 n0 = nd[0];
+          if (FILTERED && off == 0u) n0.y = (n0.y & 0x00FFFFFFu) | (1u << 24);  // flag byte 2 -> 1
+          typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4), aligned(8)));
+          const nt_u32x4 va = {n0.x, n0.y, nd[G > 1 ? 1 : 0].x, nd[G > 1 ? 1 : 0].y};
+          const nt_u32x4 vb = {nd[G > 2 ? 2 : 0].x, nd[G > 2 ? 2 : 0].y, nd[G > 3 ? 3 : 0].x, nd[G > 3 ? 3 : 0].y};
+          if (G == 4u) {
+            __builtin_nontemporal_store(va, reinterpret_cast<nt_u32x4 *>(dst));
+            __builtin_nontemporal_store(vb, reinterpret_cast<nt_u32x4 *>(dst + 2));
+          } else {  // ultra: 48 bytes per lane (plain stores, see the unfused path)
+            const nt_u32x4 vc = {nd[G > 4 ? 4 : 0].x, nd[G > 4 ? 4 : 0].y, nd[G > 5 ? 5 : 0].x, nd[G > 5 ? 5 : 0].y};
+            *reinterpret_cast<nt_u32x4 *>(dst) = va;
+            *reinterpret_cast<nt_u32x4 *>(dst + 2) = vb;
+            *reinterpret_cast<nt_u32x4 *>(dst + 4) = vc;
+          }
+          return;
+        }
+      }
 #pragma unroll
       for (uint32_t jn = 0; jn < G; ++jn) {
         const uint32_t ii = i + jn;
@@ -1307,7 +1332,11 @@ __global__ __launch_bounds__(kDecBlock) void k_assemble(
     const uint32_t body = len ? len - 1u : 0u;  // the last slot may come from the scan's end
     const uint32_t n4 = body >> 1;
     auto ld = [&](uint32_t t) { uint4 v; __builtin_memcpy(&v, src + 2u * t, 16); return v; };
-    auto st16 = [&](uint32_t t, const uint4 &v) { __builtin_memcpy(dst + 2u * t, &v, 16); };
+    typedef uint32_t as_u32x4 __attribute__((ext_vector_type(4), aligned(8)));
+    auto st16 = [&](uint32_t t, const uint4 &v) {  // (streaming store)
+      const as_u32x4 w = {v.x, v.y, v.z, v.w};
+      __builtin_nontemporal_store(w, reinterpret_cast<as_u32x4 *>(dst + 2u * t));
+    };
     uint32_t t = tid;
     for (; t + 3u * kDecBlock < n4; t += 4u * kDecBlock) {
       const uint4 a = ld(t), c = ld(t + kDecBlock), d = ld(t + 2u * kDecBlock), e = ld(t + 3u * kDecBlock);

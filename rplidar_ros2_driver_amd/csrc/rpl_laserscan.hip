@@ -148,8 +148,9 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
       const unsigned long long k = s_bins[t];
       const uint32_t hi = (uint32_t)(k >> 32), low = (uint32_t)k;
       const bool empty = hi == 0xFFFFFFFFu;  // no dist_m has this bit pattern (:640-641)
-      out_r[lo + t] = __uint_as_float(empty ? 0x7F800000u : hi);
-      out_i[lo + t] = empty ? 0.0f : (float)((low >> 8) & 0xFFu);
+      // (streaming stores: the arrays are written once and read by a later kernel or the host)
+      __builtin_nontemporal_store(__uint_as_float(empty ? 0x7F800000u : hi), &out_r[lo + t]);
+      __builtin_nontemporal_store(empty ? 0.0f : (float)((low >> 8) & 0xFFu), &out_i[lo + t]);
     }
     __syncthreads();
   }

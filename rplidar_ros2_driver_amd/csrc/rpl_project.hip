@@ -84,7 +84,9 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_to_cloud(
       const float theta = 0.0f + (float)i * inc;
       double sn, cn;
       sincos_0_2pi((double)theta, &sn, &cn);
-      out[pos] = make_float4(r * (float)cn, r * (float)sn, 0.0f, i_in[i]);
+      typedef float nt_f4 __attribute__((ext_vector_type(4)));
+      const nt_f4 v = {r * (float)cn, r * (float)sn, 0.0f, i_in[i]};
+      __builtin_nontemporal_store(v, reinterpret_cast<nt_f4 *>(&out[pos]));  // (streamed once)
     }
     base_out += total;
     __syncthreads();  // s_wave is rewritten by the next chunk
