@@ -227,8 +227,8 @@ int32_t rplgpu_scans_to_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_seg_
                                   uint32_t *d_scan_base, rplgpu_node_t *d_batch, uint32_t n_stride,
                                   uint32_t max_scans, uint32_t *d_n_per_scan);
 /* The whole step before the path in ONE call: recorded streams -> completed scans, written
- * straight into the fixed-stride batch the *_batch_dev entry points take.  Express, ultra and
- * dense capsules: scan boundaries follow from the capsule headers, so the nodes of completed scans
+ * straight into the fixed-stride batch the *_batch_dev entry points take.  The four capsule
+ * types: scan boundaries follow from the capsule headers, so the nodes of completed scans
  * are decoded directly into their slots and the others not at all; the other types (and streams
  * with more than 256 sync nodes / 64 reset requests per call) are decoded to a node stream in
  * scratch first, with the decoder's own list of sync nodes.  Decoding as rplgpu_decode_batch_dev, assembly rules as rplgpu_segment_batch_dev

@@ -62,12 +62,13 @@ struct DecCfg {
                                                                         : 4u;
   // ultra: the triangulation angle correction is a function of k2 = 98361 / dist (0..491) alone
   static constexpr uint32_t kCorrSlots = ANS == RPLGPU_ANS_CAPSULED_ULTRA ? 496u : 1u;
-  // express / ultra / dense: the sync bit of a node follows from the capsule HEADERS alone, so
+  // the four capsule types: the sync bit of a node follows from the capsule HEADERS alone, so
   // scan boundaries are known before the payload is decoded and the nodes of completed scans
   // can be written straight into batch slots (k_decode<..., FUSE = true>); up to kFuseSyn sync
   // nodes and kFuseRst reset requests per stream and call, else the unfused path takes over
   static constexpr bool kFusable = ANS == RPLGPU_ANS_CAPSULED || ANS == RPLGPU_ANS_CAPSULED_ULTRA ||
-                                   ANS == RPLGPU_ANS_DENSE_CAPSULED;
+                                   ANS == RPLGPU_ANS_DENSE_CAPSULED ||
+                                   ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
   static constexpr uint32_t kFuseSyn = kFusable ? 256u : 1u, kFuseRst = kFusable ? 64u : 1u;
   static constexpr uint32_t kStageWords = ANS == RPLGPU_ANS_HQ ? (kDecBlock / 64) * 64 * 17 : 1u;
 };
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     uint32_t *__restrict__ n_nodes, uint32_t *__restrict__ reset_at, uint32_t reset_stride,
     uint32_t *__restrict__ n_reset, uint32_t *__restrict__ n_errors, uint32_t *__restrict__ status,
     uint32_t *__restrict__ sync_at, uint32_t sync_stride, uint32_t *__restrict__ n_sync, DecFuse fz) {
-  static_assert(!FUSE || DecCfg<ANS>::kFusable, "FUSE: express, ultra and dense capsules only");
+  static_assert(!FUSE || DecCfg<ANS>::kFusable, "FUSE: the four capsule types only");
   constexpr uint32_t S = dec_frame_size(ANS);
   constexpr uint32_t NPF = dec_nodes_per_frame(ANS);
   constexpr bool CAPS = ANS == RPLGPU_ANS_CAPSULED || ANS == RPLGPU_ANS_CAPSULED_ULTRA ||
@@ -510,8 +511,9 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       if (prev_q8 > cur_q8) diff_q8 += (360 << 8);
       const int inc = ANS == RPLGPU_ANS_CAPSULED         ? diff_q8 << 3
                       : ANS == RPLGPU_ANS_CAPSULED_ULTRA ? (diff_q8 << 3) / 3
-                                                         : (diff_q8 << 8) / 40;
-      const int lim = ANS == RPLGPU_ANS_DENSE_CAPSULED ? inc * 2 : inc;
+                      : ANS == RPLGPU_ANS_DENSE_CAPSULED ? (diff_q8 << 8) / 40
+                                                         : (diff_q8 << 8) / 64;
+      const int lim = FILTERED ? inc * 2 : inc;
       for (uint32_t pos = 0; pos < NPF; ++pos) {
         const int ang = (prev_q8 << 8) + (int)pos * inc;
         if (((ang + inc) % (360 << 16)) < lim) {
@@ -579,6 +581,26 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   __syncthreads();
   dbg_t[2] = __builtin_amdgcn_s_memtime();
 #endif
+  // FUSE: where node ii of the stream was stored (null: in no delivered scan) — the rule of the
+  // store loop in emit(), for the few nodes the ultra-dense smoothing patches afterwards
+  auto fused_dst = [&](uint32_t ii) -> uint2 * {
+    uint32_t j = 0xFFFFFFFFu;
+    for (uint32_t q = 0; q < f_nsync && L.spos[q] <= ii; ++q) j = q;
+    if (j == 0xFFFFFFFFu || j + 1u >= f_nsync) return nullptr;
+    const uint32_t slot = L.sslot[j];
+    if (slot == 0xFFFFu) return nullptr;
+    const uint32_t s0 = L.spos[j], total = L.spos[j + 1u] - s0;
+    const uint32_t full = min(total, fz.max_count), len = min(full, fz.n_stride);
+    const uint32_t off = ii - s0;
+    uint32_t pos = off;
+    if (off + 1u >= len) {
+      const uint32_t last_src = (len == full && total > full) ? total - 1u : len - 1u;
+      if (off != last_src) return nullptr;
+      pos = len - 1u;
+    }
+    return fz.batch + ((size_t)b * fz.scan_cap + slot) * fz.n_stride + pos;
+  };
+
   // ---- P3: the nodes ----------------------------------------------------------------------
   // A lane decodes G consecutive nodes of ONE frame: the per-frame arithmetic (table look-ups,
   // angle step, the divisions) is paid once per group, the payload arrives in one or two wide
@@ -618,7 +640,9 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       g.scan_j = j;
       const bool in_stored = j != 0xFFFFFFFFu && j + 1u < f_nsync && L.sslot[j] != 0xFFFFu;
       const bool crosses = j + 1u < f_nsync && L.spos[j + 1u] < i + G;  // (j = -1: first sync node)
-      g.live = in_stored || crosses;
+      // (ultra-dense decodes every group: the smoothing chain runs through the nodes of scans that
+      // are not delivered too; only their stores are skipped)
+      g.live = in_stored || crosses || ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
       if (!g.live) return;
     }
     const uint32_t k = DecCfg<ANS>::kTable ? (uint32_t)L.emit_frame[e] : e;
@@ -960,10 +984,13 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     auto patch = [&](uint32_t i, int st) {  // node i has state st: patch dist_mm_q2 if smoothed
       if (st != 4 && chunk0 + i < n_out) {  // (bits 16.. of the packed node)
         const uint32_t d = (uint32_t)(rawd(i) + st - 4);
-        uint2 v = out[chunk0 + i];
-        v.x = (v.x & 0xFFFFu) | (d << 16);
-        v.y = (v.y & 0xFFFF0000u) | (d >> 16);
-        out[chunk0 + i] = v;
+        uint2 *at = FUSE ? fused_dst(chunk0 + i) : out + chunk0 + i;
+        if (at) {
+          uint2 v = *at;
+          v.x = (v.x & 0xFFFFu) | (d << 16);
+          v.y = (v.y & 0xFFFF0000u) | (d >> 16);
+          *at = v;
+        }
       }
       if (i == N - 1u) {
         L.misc[7] = (uint32_t)(rawd(i) + st - 4);  // what this chunk leaves behind (st = 4 unless scale 0)
@@ -1434,7 +1461,8 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
 }
 
 bool decode_fusable(int ans) {
-  return ans == RPLGPU_ANS_CAPSULED || ans == RPLGPU_ANS_CAPSULED_ULTRA || ans == RPLGPU_ANS_DENSE_CAPSULED;
+  return ans == RPLGPU_ANS_CAPSULED || ans == RPLGPU_ANS_CAPSULED_ULTRA ||
+         ans == RPLGPU_ANS_DENSE_CAPSULED || ans == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
 }
 
 // The fused decoder (express / ultra / dense): completed scans straight into batch slots; d_todo[b]
@@ -1468,6 +1496,7 @@ hipError_t launch_decode_fused(hipStream_t s, int ans, const uint8_t *bytes, uin
     case RPLGPU_ANS_CAPSULED: RPL_LAUNCH_FUSED(RPLGPU_ANS_CAPSULED); break;
     case RPLGPU_ANS_CAPSULED_ULTRA: RPL_LAUNCH_FUSED(RPLGPU_ANS_CAPSULED_ULTRA); break;
     case RPLGPU_ANS_DENSE_CAPSULED: RPL_LAUNCH_FUSED(RPLGPU_ANS_DENSE_CAPSULED); break;
+    case RPLGPU_ANS_ULTRA_DENSE_CAPSULED: RPL_LAUNCH_FUSED(RPLGPU_ANS_ULTRA_DENSE_CAPSULED); break;
     default: return hipErrorInvalidValue;
   }
 #undef RPL_LAUNCH_FUSED
