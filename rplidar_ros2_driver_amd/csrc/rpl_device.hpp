@@ -52,7 +52,7 @@ struct KParams {
   double vox_scale;   // 2^K, K = 23 - ilogb(leaf)  (28 for 0.05f)
   float vox_scale_f;  // same, fp32
   int32_t vox_L;      // leaf * 2^K: the leaf's 24-bit significand, exact
-  int32_t vox_bias;   // 2^15 keeps every offset non-negative (|rounding slop| < L*2^-9)
+  int32_t vox_bias;   // 0 since round 3 (offsets are summed as wrapping two's complement)
   float inv_leaf;     // RN(1 / voxel_leaf)
   // E1 keep mask as an integer interval on dist_mm_q2 (host-derived, see make_keep_interval in
   // rplgpu_api.hip): keep <=> (dist_q2 - d_lo) <= d_span (unsigned) && quality >= q_min.

@@ -48,8 +48,14 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               // (vx, vy, wz, dt) and planar pose (r00 r01 tx r10 r11 ty), optional
                               uint32_t group = 1, const float *motion = nullptr,
                               const float *pose2d = nullptr);
-// record stores k_cloud_voxel needs: one per resident workgroup (two per CU), this many bytes each
+// record stores k_cloud_voxel needs: one per resident workgroup (two per CU) ...
 uint32_t voxel_max_workgroups(uint32_t n_cu);
+// ... of this many 16-byte entries for work items of `group` scans of `n_stride` samples: every
+// sample can end a run record, and every block of 128 samples adds one marker entry
+inline uint64_t voxel_store_need(uint32_t group, uint32_t n_stride) {
+  const uint64_t s = n_stride < kMaxN ? n_stride : kMaxN;
+  return (uint64_t)(group ? group : 1u) * (s + (s + 127u) / 128u + 1u);
+}
 hipError_t launch_ror_mask(hipStream_t s, const void *nodes, uint32_t n_stride,
                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                            const Tables &T, uint32_t *mask, uint32_t mask_stride);

@@ -2,41 +2,43 @@
 // (extensions E1 + E2 + E4 of SURVEY.md §8 a-ext) in ONE streaming pass over the packed
 // 8-byte nodes (reference layout src/sdk/include/sl_lidar_cmd.h:272-278).
 //
-// Geometry (round 2): one 512-thread workgroup (8 wave64) owns one scan and needs < 80 KiB of
-// LDS, so TWO workgroups live on a compute unit.  Phase S of one scan (its raw stream occupies
-// the CU's memory pipeline for ~33 k cycles per scan, a floor no prefetch depth lowered —
-// profiles/r02/voxel_phaseS_study.txt) then overlaps phase R of the other scan (vector ALU +
-// LDS only).  Same batch, same box: -15..19 % kernel time against one 1024-thread workgroup
-// per CU.
+// Geometry: persistent workgroups of RPL_VOXEL_THREADS threads (default 1024 = 16 wave64, one per
+// compute unit; 512 = two per compute unit with a 4096-record queue each), every workgroup owns
+// one scan (or one E8 group of scans) at a time and draws the next from a device-side counter.
 //
 // Phase S (streaming, straight-line code):
-//   * one buffer_load_dwordx4 per lane = TWO consecutive samples (A, B); the (cos, sin) table
-//     entries of the next round are fetched one round ahead, the raw pairs two rounds ahead;
-//   * keep mask = one unsigned interval test on dist_mm_q2 (host-derived, rpl_device.hpp);
+//   * a wave works on BLOCKS of 128 consecutive samples; one buffer_load_dwordx4 per lane = TWO
+//     consecutive samples; the (cos, sin) table entries of the next block are fetched one block
+//     ahead, the raw pairs two blocks ahead;
+//   * keep mask = one unsigned interval test on dist_mm_q2 (host-derived, rpl_device.hpp); a
+//     dropped sample is computed with dist 0, which yields zero offsets without any masking;
 //   * x/y arithmetic on packed fp32 pairs (v_pk_mul_f32 / v_pk_fma_f32): polar->XY, the two
 //     validated mul+FMA divides by the leaf, the exact in-cell remainder;
 //   * cell key without integer conversions: (floor + 2^23 + 32768) puts iy/ix + 32768 into
 //     the low mantissa bits, one v_perm_b32 packs (iy, ix) into the 32-bit sort key;
 //   * a smooth ring stays in a 5 cm cell for ~10-200 samples, so runs of equal keys are
-//     aggregated before anything is stored: A and B merge in the lane, lanes merge through
-//     three plain DPP prefix scans, and a lane whose run ends writes ONE 16-byte record
-//     {key, prefix_x, prefix_y, prefix_count|intensity|first-of-pass flag} to the record queue.  The record
-//     holds the wave-pass PREFIX, not the run sum: the run sum is prefix(this record) -
-//     prefix(previous record of the same wave-pass), recovered when the record is read,
-//     which removes every cross-lane gather (ds_bpermute) from the hot loop.
-// The record queue: the first kRecCap records of a scan live in LDS; whatever comes after them
+//     aggregated before anything is stored: the samples of a lane are summed, the lane totals go
+//     through three plain DPP prefix scans, and a lane writes ONE 16-byte record {key, prefix_x,
+//     prefix_y, prefix(count << 16 | intensity)} wherever a run ends.  The record holds the block
+//     PREFIX, not the run sum: the run sum is prefix(this record) - prefix(the queue entry before
+//     it), recovered when the record is read, which removes every cross-lane gather
+//     (ds_bpermute) from the hot loop.  Every block's records are preceded by one MARKER entry
+//     (empty key, zero prefix), so "the entry before it" is always right and no record carries a
+//     first-of-block flag (round 2: two compares, two selects and two ORs per block).
+// The record queue: the first kRecCap entries of a scan live in LDS; whatever comes after them
 // (noisy or random scans, very large rings) goes to a per-workgroup record store in global
-// memory (it stays in L2).  A scan is therefore streamed ONCE whatever its content (round 1
-// re-streamed the whole scan for every key band: 2-3 passes over a scan with 1 cm range noise).
-// Phase R (per key band, regular data-parallel passes over <= kRecCap run records):
+// memory (it stays in L2).  A scan is therefore streamed ONCE whatever its content.
+// Phase R (per key band, regular data-parallel passes over <= kRecCap queue entries):
 //   prefix -> run sums, counting sort by row + rank inside the row -> records in (iy, ix)
 //   order -> segmented integer sums over equal keys -> one output point per cell.
 // A scan whose records all fit the LDS queue is one band and never touches the record store.
 // Otherwise the LDS part joins the rest in the store and the key range is bisected until a band
 // fits; every band re-reads the RECORDS (16 B per run, from L2), not the scan.
 //
-// Fixed point: offset = (x - ix*leaf) * 2^K + 2^15 with 2^-K = ulp(leaf) (K = 28 for
-// 5 cm).  One fp32 FMA yields x - ix*leaf EXACTLY whenever x is a multiple of 2^-K
+// Fixed point: offset = (x - ix*leaf) * 2^K with 2^-K = ulp(leaf) (K = 28 for 5 cm), summed as
+// wrapping 32-bit integers (a block prefix stays below 2^32; the tiny negative offsets of a
+// quotient that rounded up to the next integer are recognised by their top bits when a run sum
+// is read).  One fp32 FMA yields x - ix*leaf EXACTLY whenever x is a multiple of 2^-K
 // (|x| >= 3 cm at K = 28), so the integer sums are exact and sum/count reproduces the
 // spec's fp64 running sum bit for bit; closer to the axes the per-point error is
 // <= 2^-K m (3.7e-9 m), far below the 1e-6 m bar.  Integer sums are order
@@ -67,6 +69,9 @@ static_assert(kRecCap * 2u <= 2u * kRowCap * 4u, "the cell-head list (u16) lives
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef RPL_VOXEL_AHEAD
+#define RPL_VOXEL_AHEAD 2
+#endif
 #ifndef RPL_RAW_AUX
 #define RPL_RAW_AUX 2  // cache policy of the raw-pair loads (bit 0 glc, bit 1 slc): streamed once
 #endif
@@ -141,9 +146,14 @@ __device__ __forceinline__ f2 div_by2(f2 a, float d, float rd) {
   return __builtin_elementwise_fma(e, rr, q);
 }
 
-// Per-sample arithmetic of phase S for one 8-byte node (lo, hi) and its table entry `c`.
-// Outputs the sort key (kEmptyKey when the sample is dropped) and the three quantities
-// that are summed per cell.  `flags` collects RPLGPU_SCAN_CELL_RANGE.
+// 16-byte stores the compiler must not merge or re-type (see voxel_block_pass)
+__device__ __forceinline__ void lds_store128(uint32_t lds_byte_addr, u32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(lds_byte_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void glb_store128(void *p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
 // E8 (include/rplgpu_msg.h): what happens to a point between polar->XY and the grid when a GROUP
 // of scans shares one grid — the scan's motion during its acquisition (E6 de-skew, same
 // operations in the same order as k_cloud) and its sensor's planar pose.  All zeros / identity
@@ -174,6 +184,14 @@ __device__ __forceinline__ f2 apply_xf(f2 xy, uint32_t sample_index, const ScanX
   return o;
 }
 
+// Per-sample arithmetic of phase S for one 8-byte node (lo, hi) and its table entry `c`: the sort
+// key and the three quantities that are summed per cell.  Straight-line: a dropped sample is
+// computed with dist 0 — x = y = 0, floor 0, remainder 0 — so its offsets are zero without any
+// masking (a wave issues in order: exec-mask regions and branches around an `if (kept)` cost it
+// more than the few instructions they skip on the ~10 % of dropped samples); only the count |
+// intensity word is selected.  The KEY of a dropped sample is whatever the zero point yields and is
+// never trusted (see voxel_block_pass).  With a transform (XF) or an unproven cell range (!SAFE)
+// the zero point does not stay in cell (0, 0) / the sample may be dropped late: offsets are masked.
 template <bool FAST_DIV, bool SAFE, bool HASQ, bool XF = false>
 __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c, const KParams &p,
                                              uint32_t q_min16, uint32_t ibfe_off,
@@ -181,14 +199,10 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
                                              uint32_t &qy, uint32_t &ci, uint32_t &flags,
                                              uint32_t sample_index = 0u,
                                              const ScanXf *xf = nullptr) {
-  // Straight-line: a dropped sample runs the same arithmetic on harmless operands (dist 0 or an
-  // out-of-range distance give finite values) and is masked at the end.  A wave issues in
-  // order, so the exec-mask regions and branches of an `if (kept)` cost it more than the few
-  // instructions they skip on the ~10 % of dropped samples.
   const uint32_t d = __builtin_amdgcn_alignbit(hi, lo, 16);  // unaligned u32 at byte 2
   bool kept = (d - p.d_lo) <= p.d_span;                      // E1 (and :584)
   if (HASQ) kept = kept & ((hi & 0x00FF0000u) >= q_min16);
-  const float df = __uint2float_rn(d);
+  const float df = __uint2float_rn(kept ? d : 0u);
   const float dm = FAST_DIV ? div_by(df, 4000.0f, 0.00025f) : df / 4000.0f;  // :590
   const f2 cv = {c.x, c.y};
   f2 xy = cv * dm;                                                             // E2
@@ -209,80 +223,145 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
   // iy + 32768 | ix + 32768 from the mantissas of f + (2^23 + 32768)
   const uint32_t kx = __float_as_uint(f.x + kKeyMagic);
   const uint32_t ky = __float_as_uint(f.y + kKeyMagic);
-  const uint32_t k = __builtin_amdgcn_perm(ky, kx, 0x05040100u);
+  key = __builtin_amdgcn_perm(ky, kx, 0x05040100u);
   const f2 lf = {p.voxel_leaf, p.voxel_leaf};
   const f2 r = __builtin_elementwise_fma(-f, lf, xy);  // x - ix*leaf, exact
   const f2 o = r * p.vox_scale_f;
-  const uint32_t m = kept ? 0xFFFFFFFFu : 0u;
-  key = kept ? k : kEmptyKey;
-  qx = (uint32_t)((int)o.x + p.vox_bias) & m;
-  qy = (uint32_t)((int)o.y + p.vox_bias) & m;
-  ci = ((1u << 16) | ((hi >> ibfe_off) & ibfe_w)) & m;  // count | intensity (:591-592)
+  qx = (uint32_t)(int)o.x;  // (wrapping two's complement: see the fixed-point note in the header)
+  qy = (uint32_t)(int)o.y;
+  if (!SAFE || XF) {
+    qx = kept ? qx : 0u;
+    qy = kept ? qy : 0u;
+  }
+  ci = kept ? ((1u << 16) | ((hi >> ibfe_off) & ibfe_w)) : 0u;  // count | intensity (:591-592)
   return kept;
 }
 
-// Cross-lane part of one wave-pass over 128 samples: lane l holds samples A = 2l, B = 2l+1
-// (okA / okB: the sample survived the keep mask and carries a real key).  The run records go
-// to the LDS queue while it has room and to the record store `G` (global) after that; either
-// way record i of the scan sits at position i.
-constexpr uint32_t kFirstOfPass = 1u << 24;  // record flag: no record of the same wave-pass before it
-__device__ __forceinline__ void voxel_pair_pass(VoxelLds &L, uint4 *__restrict__ G,
-                                                bool okA, uint32_t keyA, uint32_t xA, uint32_t yA,
-                                                uint32_t cA, bool okB, uint32_t keyB, uint32_t xB,
-                                                uint32_t yB, uint32_t cB) {
-  // lane l+1's first key; lane 63 sees a value no key can take (its run always ends)
-  const uint32_t nextA = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)keyA, 0x130,
-                                                               0xF, 0xF, false);  // wave_shl:1
-  // run-end masks built in scalar registers: (sample kept) & (key differs from the next one).
-  // Written with explicit compares because `ballot(a && b)` is materialised by the compiler as
-  // v_cndmask + v_cmp per mask; the per-lane predicates for the stores come back from the
-  // masks with inverse_ballot (one s_and_saveexec each).
-  uint64_t ne1, ne2;
-  asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(ne1) : "v"(keyA), "v"(keyB));
-  asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(ne2) : "v"(keyB), "v"(nextA));
-  const uint64_t m1 = __builtin_amdgcn_ballot_w64(okA) & ne1;  // a run ends at A
-  const uint64_t m2 = __builtin_amdgcn_ballot_w64(okB) & ne2;  // a run ends at B
-  const bool e1 = __builtin_amdgcn_inverse_ballot_w64(m1);
-  const bool e2 = __builtin_amdgcn_inverse_ballot_w64(m2);
-  const uint32_t total = (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
-  if (total == 0u) return;  // wave-uniform: nothing kept in this pass
-  // reserve queue slots: one LDS atomic by lane 0, its round trip overlaps the scans below
-  // (hand-placed so that the compiler's atomic optimiser does not wait for it right away)
+// Cross-lane part of one block of 64 * NS samples: lane l holds the NS consecutive samples
+// NS l .. NS l + NS - 1 (ok[j]: the sample survived the keep mask).  A record is written where a
+// run of equal keys ends; the records of a block go to consecutive queue entries in sample
+// order, behind one marker entry.  The queue is the LDS array while it has room and the record
+// store `G` (global) after that; either way entry i of the scan sits at position i.
+// FILL: a sample the quality filter or the E5 mask drops must not END the run it sits in (it
+// contributes nothing to it): inside the lane it takes its neighbour's key.  Without this a scan
+// filtered at q_min = 48 makes twice the run records (random drops cut every run).  The plain
+// instance does not need it: its drops come in runs (dist 0), a dropped sample never writes a
+// record (its own run-end bit is masked) and it ends the run in front of it by its mask bit.
+template <bool FILL, int NS>
+__device__ __forceinline__ void voxel_block_pass(VoxelLds &L, uint4 *__restrict__ G,
+                                                 const bool (&ok)[NS], uint32_t (&key)[NS],
+                                                 const uint32_t (&qx)[NS], const uint32_t (&qy)[NS],
+                                                 const uint32_t (&ci)[NS]) {
+  uint64_t okm[NS];
+  if (FILL) {
+    bool any = ok[0];
+    uint32_t kfirst = key[NS - 1];  // the lane's first kept key (selects, not an indexed array)
+#pragma unroll
+    for (int j = NS - 2; j >= 0; --j) kfirst = ok[j] ? key[j] : kfirst;
+    key[0] = kfirst;
+#pragma unroll
+    for (int j = 1; j < NS; ++j) {
+      any = any | ok[j];
+      key[j] = ok[j] ? key[j] : key[j - 1];
+    }
+    const uint64_t anym = __builtin_amdgcn_ballot_w64(any);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) okm[j] = anym;
+  } else {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) okm[j] = __builtin_amdgcn_ballot_w64(ok[j]);
+  }
+  // lane l+1's first key (lane 63: any value, its successor counts as dropped below)
+  const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)key[0], 0x130,
+                                                              0xF, 0xF, false);  // wave_shl:1
+  // run-end masks built in scalar registers: (sample kept) & (key differs from the next one, or
+  // the next one is dropped).  Written with explicit compares because `ballot(a && b)` is
+  // materialised by the compiler as v_cndmask + v_cmp per mask; the per-lane predicates for the
+  // stores come back from the masks with inverse_ballot (one s_and_saveexec each).
+  // A run also ends where the NEXT sample is dropped, whatever key the zero point gave it: if
+  // that key happened to match, no record would be written for the run and its sums would leak
+  // into the next record (lane 63's successor counts as dropped: its last run always ends).
+  uint64_t m[NS];
+  uint32_t total = 0;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const uint32_t nk = j + 1 < NS ? key[j + 1 < NS ? j + 1 : 0] : next;
+    asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m[j]) : "v"(key[j]), "v"(nk));
+    const uint64_t ok_next = j + 1 < NS ? okm[j + 1 < NS ? j + 1 : 0] : (okm[0] >> 1);
+    m[j] = okm[j] & (m[j] | ~ok_next);
+    total += (uint32_t)__popcll(m[j]);
+  }
+  if (total == 0u) return;  // wave-uniform: nothing kept in this block
+  // reserve queue entries (the records + their marker): one LDS atomic by lane 0, its round trip
+  // overlaps the scans below (hand-placed so that the compiler's atomic optimiser does not wait
+  // for it right away)
   uint32_t base = 0u;
   if (lane_id() == 0) {
     asm volatile("ds_add_rtn_u32 %0, %1, %2"
                  : "=v"(base)
-                 : "v"((uint32_t)(uintptr_t)&L.misc[0]), "v"(total)
+                 : "v"((uint32_t)(uintptr_t)&L.misc[0]), "v"(total + 1u)
                  : "memory");
   }
-  uint32_t Px = xA + xB, Py = yA + yB, Pc = cA + cB;
+  // lane totals -> inclusive block prefix of the lane's LAST sample; the others by subtraction
+  uint32_t Px = qx[0], Py = qy[0], Pc = ci[0];
+#pragma unroll
+  for (int j = 1; j < NS; ++j) {
+    Px += qx[j];
+    Py += qy[j];
+    Pc += ci[j];
+  }
   wave_incl_scan3_dpp(Px, Py, Pc);
+  // records written by the lanes before this one (all masks)
+  uint32_t before = 0u;
+#pragma unroll
+  for (int j = 0; j < NS; ++j)
+    before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[j] >> 32),
+                                       __builtin_amdgcn_mbcnt_lo((uint32_t)m[j], before));
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(base)::"memory");
   base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-  const uint32_t mb1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-  const uint32_t mb2 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
-  const uint32_t pos1 = base + mb1 + mb2;  // records are queued in sample order
-  uint32_t pos2;                           // pos1 + (e1 ? 1 : 0): the ballot is the carry-in
-  uint64_t carry_out;
-  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(pos2), "=s"(carry_out) : "v"(pos1), "s"(m1));
-  // the first record of the pass is flagged: its prefix is a run sum already (the reader subtracts
-  // the previous record's prefix from every other one)
-  const uint32_t f1 = pos1 == base ? kFirstOfPass : 0u, f2 = pos2 == base ? kFirstOfPass : 0u;
-  if (base + total <= kRecCap) {  // wave-uniform: the usual case, everything goes to LDS
-    if (e1) L.rec[pos1] = make_uint4(keyA, Px - xB, Py - yB, (Pc - cB) | f1);
-    if (e2) L.rec[pos2] = make_uint4(keyB, Px, Py, Pc | f2);
+  uint32_t pos[NS];
+  pos[0] = base + 1u + before;  // entries are queued in sample order behind the marker
+#pragma unroll
+  for (int j = 0; j + 1 < NS; ++j) {  // pos[j+1] = pos[j] + (a record ends at sample j): the mask is the carry-in
+    uint64_t carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(pos[j + 1]), "=s"(carry_out) : "v"(pos[j]), "s"(m[j]));
+  }
+  u32x4 rec[NS];
+  rec[NS - 1] = u32x4{key[NS - 1], Px, Py, Pc};
+#pragma unroll
+  for (int j = NS - 2; j >= 0; --j)
+    rec[j] = u32x4{key[j], rec[j + 1].y - qx[j + 1], rec[j + 1].z - qy[j + 1], rec[j + 1].w - ci[j + 1]};
+  const u32x4 marker = {kEmptyKey, 0u, 0u, 0u};
+  // The stores are written as ds_write / global_store instructions by hand: left to the compiler,
+  // the LDS and the record-store variants of a store are sunk into ONE flat store through a
+  // selected pointer, and a flat instruction anywhere in the loop makes every wait for the
+  // prefetched loads a vmcnt(0) (flat accesses return out of order).  The compiler does not see
+  // these stores: the stream loop ends with an explicit wait for them before its barrier.
+  const uint32_t lds_rec = (uint32_t)(uintptr_t)&L.rec[0];
+  if (base + 1u + total <= kRecCap) {  // wave-uniform: the usual case, everything goes to LDS
+    if (lane_id() == 0) lds_store128(lds_rec + base * 16u, marker);
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+      if (__builtin_amdgcn_inverse_ballot_w64(m[j])) lds_store128(lds_rec + pos[j] * 16u, rec[j]);
   } else {  // past (or across) the end of the LDS queue: the record store takes the rest
-    const uint4 rA = make_uint4(keyA, Px - xB, Py - yB, (Pc - cB) | f1);
-    const uint4 rB = make_uint4(keyB, Px, Py, Pc | f2);
-    if (e1) {
-      if (pos1 < kRecCap) L.rec[pos1] = rA; else G[pos1] = rA;
+    if (lane_id() == 0) {
+      if (base < kRecCap) lds_store128(lds_rec + base * 16u, marker); else glb_store128(G + base, marker);
     }
-    if (e2) {
-      if (pos2 < kRecCap) L.rec[pos2] = rB; else G[pos2] = rB;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      if (__builtin_amdgcn_inverse_ballot_w64(m[j])) {
+        if (pos[j] < kRecCap) lds_store128(lds_rec + pos[j] * 16u, rec[j]); else glb_store128(G + pos[j], rec[j]);
+      }
     }
   }
+}
+
+// Run sums are differences of wrapping 32-bit block prefixes: non-negative and below 2^32 - 2^28
+// except for the tiny negative offsets of samples whose quotient rounded up to the next integer.
+__device__ __forceinline__ double run_sum_f64(uint32_t u) {
+  double s = (double)u;
+  if (u >= 0xF0000000u) s -= 4294967296.0;
+  return s;
 }
 
 // Where a scan's cells go.  Legacy: a fixed region per scan (xyzi + b*out_stride).  Arena: all
@@ -330,7 +409,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
   auto flush_dbg = [&]() {
     if (DBG && p.dbg && threadIdx.x == 0) {
 #pragma unroll
-      for (int i = 1; i < 8; ++i) atomicAdd(&p.dbg[8 * b + i], pc.acc[i]);
+      for (int i = 1; i < 8; ++i) atomicAdd(&p.dbg[16 * b + i], pc.acc[i]);
     }
   };
   uint32_t *const rowstart = L.rows, *const rowfill = L.rows + kRowCap;
@@ -348,11 +427,13 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
     // whole 64-record slices beyond the queue tail are skipped (wave-uniform); the previous
     // record comes from the lane to the left
     if ((idx & ~63u) < nrec) {
-      const bool ok = idx < nrec;
       const uint4 raw = L.rec[idx];  // idx < kRecCap always
+      // (a marker entry carries the empty key: it is the zero prefix in front of a block's
+      // records and nothing else)
+      const bool ok = idx < nrec && raw.x != kEmptyKey;
       m = raw;
       if (!normalised) {
-        uint4 pr;
+        uint4 pr;  // the queue entry before this one: the lane to the left holds it
         pr.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw.y, 0x138, 0xF, 0xF, false);
         pr.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw.z, 0x138, 0xF, 0xF, false);
         pr.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw.w, 0x138, 0xF, 0xF, false);
@@ -360,10 +441,9 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
           const uint4 t = L.rec[idx - 1u];
           pr.y = t.y; pr.z = t.z; pr.w = t.w;
         }
-        const bool same = ok && idx > 0u && !(raw.w & kFirstOfPass);
-        m.y -= same ? pr.y : 0u;
-        m.z -= same ? pr.z : 0u;
-        m.w = (raw.w & 0x00FFFFFFu) - (same ? (pr.w & 0x00FFFFFFu) : 0u);
+        m.y -= pr.y;  // (entry 0 of a queue is a marker: a record always has a predecessor)
+        m.z -= pr.z;
+        m.w -= pr.w;
       }
       if (!ok) m = make_uint4(kEmptyKey, 0u, 0u, 0u);
       if (ok) {
@@ -391,7 +471,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
       return 1u;
     }
     uint32_t *bucket = reinterpret_cast<uint32_t *>(L.rec);  // (ix << 16 | record index) by row
-    uint32_t pad_total;
+    uint32_t pad_total, nreal;
     {  // exclusive scan over the kRowCap rows in row order (2 per thread); a row iy lives at
        // iy mod kRowCap, so scan position j is the physical row (j + rmin) mod kRowCap.  Two
        // sums in one word: compact positions (low half) and positions with every row padded
@@ -408,6 +488,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
       rowfill[p0] = ex >> 16;
       rowfill[p1] = (ex + w0) >> 16;
       pad_total = tot >> 16;
+      nreal = tot & 0xFFFFu;  // records of the band (the queue entries minus the markers)
     }
     // padding entries compare as "not smaller than anything"
     for (uint32_t i = threadIdx.x * 4u; i < pad_total; i += kVB * 4u)
@@ -480,12 +561,12 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
     // heads of equal-key groups -> cell index; thread t owns sorted records [8t, 8t+8)
     const uint32_t r_lo = threadIdx.x * kRecPerThread;
     uint32_t headbits = 0, nheads = 0;
-    uint32_t prevkey = (r_lo > 0 && r_lo <= nrec) ? L.rec[r_lo - 1].x : kEmptyKey;
+    uint32_t prevkey = (r_lo > 0 && r_lo <= nreal) ? L.rec[r_lo - 1].x : kEmptyKey;
 #pragma unroll
     for (int k = 0; k < (int)kRecPerThread; ++k) {
       const uint32_t r = r_lo + k;
-      const uint32_t key = (r < nrec) ? L.rec[r].x : kEmptyKey;
-      if (r < nrec && key != prevkey) {
+      const uint32_t key = (r < nreal) ? L.rec[r].x : kEmptyKey;
+      if (r < nreal && key != prevkey) {
         headbits |= 1u << k;
         ++nheads;
       }
@@ -527,21 +608,21 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
       const uint4 q1 = L.rec[min(r + 1u, kRecCap - 1u)];
       const uint4 q2 = L.rec[min(r + 2u, kRecCap - 1u)];
       const uint32_t key = q0.x;
-      const bool m1 = (r + 1u < nrec) && (q1.x == key);
-      const bool m2 = m1 && (r + 2u < nrec) && (q2.x == key);
-      double sx = (double)q0.y, sy = (double)q0.z;
+      const bool m1 = (r + 1u < nreal) && (q1.x == key);
+      const bool m2 = m1 && (r + 2u < nreal) && (q2.x == key);
+      double sx = run_sum_f64(q0.y), sy = run_sum_f64(q0.z);
       // count and intensity sum are packed per RECORD (<= 128 samples: 16 bits each suffice);
       // per CELL they are summed apart -- a large or close cell collects thousands of samples
       // and its intensity sum passes 2^16 (found by tests/test_gpu_fuzz.py)
       uint32_t cnt = q0.w >> 16, isum = q0.w & 0xFFFFu;
-      if (m1) { sx += (double)q1.y; sy += (double)q1.z; cnt += q1.w >> 16; isum += q1.w & 0xFFFFu; }
+      if (m1) { sx += run_sum_f64(q1.y); sy += run_sum_f64(q1.z); cnt += q1.w >> 16; isum += q1.w & 0xFFFFu; }
       if (m2) {
-        sx += (double)q2.y; sy += (double)q2.z; cnt += q2.w >> 16; isum += q2.w & 0xFFFFu;
-        for (r += 3u; r < nrec; ++r) {  // segmented sum over the rest of this cell's records
+        sx += run_sum_f64(q2.y); sy += run_sum_f64(q2.z); cnt += q2.w >> 16; isum += q2.w & 0xFFFFu;
+        for (r += 3u; r < nreal; ++r) {  // segmented sum over the rest of this cell's records
           const uint4 q = L.rec[r];
           if (q.x != key) break;
-          sx += (double)q.y;
-          sy += (double)q.z;
+          sx += run_sum_f64(q.y);
+          sy += run_sum_f64(q.z);
           cnt += q.w >> 16;
           isum += q.w & 0xFFFFu;
         }
@@ -584,8 +665,8 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   __shared__ VoxelLds L;
 
   if (threadIdx.x < 256) L.rcp[threadIdx.x] = T.rcp[threadIdx.x];  // (first barrier below publishes it)
-  // this workgroup's record store (T.voxel_store_recs >= group * kMaxN records: every sample of
-  // the work item could end a run)
+  // this workgroup's record store (T.voxel_store_recs entries, voxel_store_need(): every sample
+  // of the work item could end a run, plus the block markers)
   uint4 *G = store + (size_t)blockIdx.x * T.voxel_store_recs;
   // persistent workgroups, two per CU; the first scan is blockIdx.x, the next ones come from a
   // shared counter, so a workgroup that drew cheap scans simply takes more of them
@@ -644,17 +725,18 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const bool use_xf = (group > 1u) || motion || pose2d;  // block-uniform
       const uint32_t s_lo = b * group, s_hi = min(n_scans, s_lo + group);
       for (uint32_t sc = s_lo; sc < s_hi; ++sc) {
-        const uint32_t n = min(n_per_scan[sc], min(n_stride, kMaxN));  // never past the slot
+        // (readfirstlane: the value is wave-uniform, and must live in scalar registers for the
+        // buffer resource below — a min3 in vector registers makes every load a waterfall loop)
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)min(n_per_scan[sc], min(n_stride, kMaxN)));  // never past the slot
         const uint2 *scan = nodes + (size_t)sc * n_stride;
-        // lane l of a round owns the sample pair (2i, 2i+1), i = round * kVB + thread
-        const uint32_t npairs = (n + 1u) >> 1;
-        // Bounds-checked buffer resource over this scan's n*8 bytes: a pair (or its second
-        // node) beyond the scan reads as zero, i.e. dist 0, which the keep test drops.  Every
-        // lane always issues the load, so the compiler's vmcnt bookkeeping is exact.
+        // Bounds-checked buffer resource over this scan's n*8 bytes: a node beyond the scan reads
+        // as zero, i.e. dist 0, which the keep test drops.  Every lane always issues the load, so
+        // the compiler's vmcnt bookkeeping is exact.
         const __amdgpu_buffer_rsrc_t scan_rsrc =
             __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
-        auto load_pair = [&](uint32_t i) -> uint4 {
-          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)(i * 16u), 0, RPL_RAW_AUX);
+        auto load_pair = [&](uint32_t byte_off) -> uint4 {
+          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)byte_off, 0, RPL_RAW_AUX);
           return make_uint4(t.x, t.y, t.z, t.w);
         };
         const uint32_t *ror_bits = keepmask ? keepmask + (size_t)sc * mask_stride : nullptr;
@@ -668,43 +750,88 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         constexpr bool HASQ = decltype(hasq_tag)::value;
         constexpr bool HASMASK = decltype(mask_tag)::value;
         constexpr bool XF = decltype(xf_tag)::value;
-        uint4 w1 = load_pair(threadIdx.x);
-        uint4 w2 = load_pair(kVB + threadIdx.x);
-        float2 cA1 = cs[w1.x & 0xFFFFu], cB1 = cs[w1.z & 0xFFFFu];
-        for (uint32_t base = 0; base < npairs; base += kVB) {
-          const uint4 w0 = w1;
-          const float2 cA = cA1, cB = cB1;
-          w1 = w2;
-          cA1 = cs[w1.x & 0xFFFFu];
-          cB1 = cs[w1.z & 0xFFFFu];
-          w2 = load_pair(base + 2u * kVB + threadIdx.x);
-          uint4 w = w0;
-          if (HASMASK) {  // E5 mask (one bit per sample): a dropped sample gets dist 0
-            const uint32_t pi = base + threadIdx.x;  // pair index -> bits 2*pi, 2*pi + 1
-            const uint32_t word = pi >> 4;
-            const uint32_t bits = (word < mask_stride) ? ror_bits[word] : 0u;
-            const uint32_t two = (bits >> ((pi & 15u) * 2u)) & 3u;
-            if (!(two & 1u)) { w.x &= 0x0000FFFFu; w.y &= 0xFFFF0000u; }
-            if (!(two & 2u)) { w.z &= 0x0000FFFFu; w.w &= 0xFFFF0000u; }
+        // block k of the scan = its samples [128 k, 128 k + 128), i.e. one contiguous KiB; wave w
+        // takes the blocks w, w + kVW, ...; lane l of a block owns the sample pair 128 k + 2 l, + 1
+        // (one buffer_load_dwordx4).
+        // What bounds this loop (profiles/r03/voxel_phaseS_r03.txt): with ~100 vector instructions
+        // per block the vector ALU needs ~25 k cycles per scan, but a compute unit that keeps only
+        // ONE raw load per wave in flight (16 KiB) cannot pull 256 KiB through a ~2 k-cycle memory
+        // latency in less than ~33 k cycles, whatever the instruction count (Little's law; the
+        // loop of rounds 1-2 looked two blocks ahead by name but needed the newest load at the
+        // top of the next trip).  So the raw pairs run THREE blocks ahead in a ring of four
+        // register buffers, unrolled four times so that the ring costs no register moves, and
+        // the compiler's wait at the top of a block leaves the newest raw load in flight
+        // (s_waitcnt vmcnt(1)); the table entries stay one block ahead (they come from L2).
+        // (Also tried in round 3: four samples per lane.  Read directly — 32 bytes per lane,
+        // table gathers at a stride of 8 entries — the texture addresser became the bottleneck,
+        // phase S 46 k cycles; transposed through LDS each block waits for two LDS round trips on
+        // top of the loads and the slot reservation, which four waves per SIMD do not hide: 41 k.)
+        const uint32_t nblocks = (n + 127u) >> 7;
+        const uint32_t lane_off = lane_id() * 16u;
+        const uint32_t blk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
+        if (blk0 >= nblocks) return;  // wave-uniform (no barrier inside the stream)
+        uint4 w[4];
+        float2 cA[2], cB[2];
+        constexpr int kAhead = RPL_VOXEL_AHEAD;  // blocks the raw pairs run ahead (2 or 3)
+        w[0] = load_pair(blk0 * 1024u + lane_off);
+        w[1] = load_pair((blk0 + kVW) * 1024u + lane_off);
+        if (kAhead == 3) w[2] = load_pair((blk0 + 2u * kVW) * 1024u + lane_off);
+        cA[0] = cs[w[0].x & 0xFFFFu];
+        cB[0] = cs[w[0].z & 0xFFFFu];
+        unsigned long long sub[5] = {0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0ull;
+        for (uint32_t blk4 = blk0; blk4 < nblocks; blk4 += 4u * kVW) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t blk = blk4 + (uint32_t)k * kVW;
+            // (the loads are issued whether or not the block exists — beyond the scan they return
+            // zeros — so that every path through the loop has the same loads in flight and the
+            // compiler's waits stay exact)
+            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            if (DBG) t0 = clock64();
+            cA[(k + 1) & 1] = cs[w[(k + 1) & 3].x & 0xFFFFu];
+            cB[(k + 1) & 1] = cs[w[(k + 1) & 3].z & 0xFFFFu];
+            w[(k + kAhead) & 3] = load_pair((blk + (uint32_t)kAhead * kVW) * 1024u + lane_off);
+            if (DBG) {  // [8] issue of the loads (incl. the wait for the raw pair the gathers need)
+              asm volatile("" : "+v"(cA[(k + 1) & 1].x), "+v"(cB[(k + 1) & 1].x)::"memory");
+              t1 = clock64();
+            }
+            if (blk < nblocks) {  // wave-uniform
+              const uint4 w0 = w[k];
+              const float2 c0[2] = {cA[k & 1], cB[k & 1]};
+              uint32_t lo[2] = {w0.x, w0.z}, hi[2] = {w0.y, w0.w};
+              if (HASMASK) {  // E5 mask (one bit per sample): a dropped sample gets dist 0
+                const uint32_t word = blk * 4u + (lane_id() >> 4);  // sample 128 blk + 2 l -> bit 2 (l & 15)
+                const uint32_t bits = (word < mask_stride) ? ror_bits[word] : 0u;
+                const uint32_t two = bits >> ((lane_id() & 15u) * 2u);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                  if (!((two >> j) & 1u)) { lo[j] &= 0x0000FFFFu; hi[j] &= 0xFFFF0000u; }
+              }
+              const uint32_t i0 = blk * 128u + lane_id() * 2u;  // sample index inside the scan
+              bool ok[2];
+              uint32_t key[2], qx[2], qy[2], ci[2];
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                ok[j] = voxel_sample<FAST_DIV, SAFE, HASQ, XF>(lo[j], hi[j], c0[j], p, q_min16,
+                                                              ibfe_off, ibfe_w, key[j], qx[j], qy[j],
+                                                              ci[j], flags, i0 + (uint32_t)j, &xf);
+              if (DBG) {  // [9] wait for this block's table entries + sample arithmetic
+                asm volatile("" : "+v"(qx[1]), "+v"(qy[0]), "+v"(ci[1]), "+v"(key[1])::"memory");
+                t2 = clock64();
+              }
+              voxel_block_pass<HASQ || HASMASK, 2>(L, G, ok, key, qx, qy, ci);
+              if (DBG) {  // [10] block pass (issue only: its stores are not waited for)
+                t3 = clock64();
+                if (p.dbg && threadIdx.x == 0) {
+                  sub[0] += t1 - t0; sub[1] += t2 - t1; sub[2] += t3 - t2; sub[3] += t0 - tprev; sub[4] += 1;
+                }
+                tprev = t3;
+              }
+            }
           }
-          const uint32_t iA = 2u * (base + threadIdx.x);  // sample index inside the scan
-          uint32_t keyA, xA, yA, ciA, keyB, xB, yB, ciB;
-          const bool okA = voxel_sample<FAST_DIV, SAFE, HASQ, XF>(
-              w.x, w.y, cA, p, q_min16, ibfe_off, ibfe_w, keyA, xA, yA, ciA, flags, iA, &xf);
-          const bool okB = voxel_sample<FAST_DIV, SAFE, HASQ, XF>(
-              w.z, w.w, cB, p, q_min16, ibfe_off, ibfe_w, keyB, xB, yB, ciB, flags, iA + 1u, &xf);
-          bool vA = okA, vB = okB;
-          if (HASQ || HASMASK) {
-            // A sample the quality filter or the E5 mask drops must not END the run it sits in
-            // (it contributes nothing to it): inside the lane it takes its neighbour's key.
-            // Without this a scan filtered at q_min = 48 made twice the run records (random
-            // drops cut every run) and left the LDS queue: 0.81 ms instead of 0.46 ms per batch.
-            vA = vB = okA | okB;
-            keyA = okA ? keyA : keyB;
-            keyB = okB ? keyB : keyA;
-          }
-          voxel_pair_pass(L, G, vA, keyA, xA, yA, ciA, vB, keyB, xB, yB, ciB);
         }
+        if (DBG && p.dbg && threadIdx.x == 0)
+          for (int i = 0; i < 5; ++i) atomicAdd(&p.dbg[16 * b + 8 + i], sub[i]);
       };
       {
         using T_ = std::true_type;
@@ -718,6 +845,8 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
       }  // scans of the group
       first_band = false;
+      // the record stores of phase S are hand-written instructions the compiler does not track
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();  // (workgroup-scope release / acquire: covers the record store too)
       pc.lap(0);
       n_all = L.misc[0];
@@ -759,11 +888,10 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           pr.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw[j].z, 0x138, 0xF, 0xF, false);
           pr.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw[j].w, 0x138, 0xF, 0xF, false);
           if (lane_id() == 0u) { pr.y = prl[j].y; pr.z = prl[j].z; pr.w = prl[j].w; }
-          const bool same = i > 0u && !(raw[j].w & kFirstOfPass);
-          m[j] = raw[j];
-          m[j].y -= same ? pr.y : 0u;
-          m[j].z -= same ? pr.z : 0u;
-          m[j].w = (raw[j].w & 0x00FFFFFFu) - (same ? (pr.w & 0x00FFFFFFu) : 0u);
+          m[j] = raw[j];  // (markers: empty key, outside every band; entry 0 is a marker)
+          m[j].y -= pr.y;
+          m[j].z -= pr.z;
+          m[j].w -= pr.w;
           in[j] = (i < n_all) && ((raw[j].x - klo) <= (khi - klo));
           if (in[j]) {
             kmin = min(kmin, raw[j].x);
@@ -872,8 +1000,8 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
   }
   if (DBG && p.dbg && threadIdx.x == 0) {
-    atomicAdd(&p.dbg[8 * b], pc.acc[0]);
-    atomicAdd(&p.dbg[8 * b + 2], pc.acc[2]);  // band selection passes over the record store
+    atomicAdd(&p.dbg[16 * b], pc.acc[0]);
+    atomicAdd(&p.dbg[16 * b + 2], pc.acc[2]);  // band selection passes over the record store
   }
 
   if (flags) atomicOr(&L.misc[1], flags);
@@ -943,11 +1071,12 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               uint32_t group, const float *motion, const float *pose2d) {
   if (B == 0) return hipSuccess;
   if (group == 0) group = 1;
+  group = std::min(group, B);  // (a group larger than the batch is the whole batch)
   if (kVB == 512 && group > 1) return hipErrorInvalidValue;  // (groups: 16-wave geometry only)
   const uint32_t n_scans = B;
   B = (B + group - 1u) / group;  // work items
   if (!T.voxel_store || T.voxel_store_wgs == 0) return hipErrorInvalidValue;
-  if ((uint64_t)group * std::min(n_stride, kMaxN) > T.voxel_store_recs) return hipErrorInvalidValue;
+  if (voxel_store_need(group, n_stride) > T.voxel_store_recs) return hipErrorInvalidValue;
   VoxelArena ar;
   ar.base = (float4 *)arena;
   ar.cursor = arena_cursor;

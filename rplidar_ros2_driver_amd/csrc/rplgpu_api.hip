@@ -131,7 +131,7 @@ rpl::KParams to_kparams(const rplgpu_params_t &p) {
   k.vox_scale = 1.0;
   k.vox_scale_f = 1.0f;
   k.vox_L = 1;
-  k.vox_bias = 32768;
+  k.vox_bias = 0;  // (round 3: offsets are summed as wrapping two's complement, no bias)
   k.inv_leaf = 1.0f;
   k.fast_div = 0;
   k.dbg = nullptr;
@@ -497,7 +497,7 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   // the voxel kernel's record stores (overflow of its LDS queue; 512 KiB per resident workgroup,
   // at most two workgroups per CU and never more than scans in a batch)
   c->vstore_wgs = std::min<uint32_t>(c->max_b, rpl::voxel_max_workgroups(c->n_cu));
-  c->vstore_recs = rpl::kMaxN;
+  c->vstore_recs = (uint32_t)rpl::voxel_store_need(1u, rpl::kMaxN);
   if (hipMalloc(&c->d_vstore, (size_t)c->vstore_wgs * c->vstore_recs * 16u) != hipSuccess) {
     c->err = "record store allocation failed";
     return fail(RPLGPU_ERR_HIP);
@@ -674,7 +674,8 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
     return RPLGPU_ERR_INVALID_ARG;
   // Every sample of a group can end a run record: the record stores grow (only ever grow, and
   // only here — the first call with a larger group pays one reallocation) to group x stride.
-  const uint64_t need = (uint64_t)std::min(group, B) * std::min(n_stride, rpl::kMaxN);
+  group = std::min(group, B);  // "all sensors in one grid" may be asked for with any group >= B
+  const uint64_t need = rpl::voxel_store_need(group, n_stride);
   if (need > h->vstore_recs) {
     if (need > (1ull << 24)) {
       h->err = "rplgpu_cloud_fused_voxel_dev: group x n_stride above 2^24 samples";

@@ -17,7 +17,7 @@ d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
 d_xyzi = torch.empty(B, 8192, 4, dtype=torch.float32, device=dev)
 d_np = torch.zeros(B, dtype=torch.int32, device=dev)
 d_st = torch.zeros(B, dtype=torch.int32, device=dev)
-d_dbg = torch.zeros(B, 8, dtype=torch.int64, device=dev)
+d_dbg = torch.zeros(B, 16, dtype=torch.int64, device=dev)
 gpu = RplGpu(0, 32768, B)
 lib = abi.load_library()
 lib.rplgpu_debug_set_cycle_buffer(gpu._h, C.c_void_p(d_dbg.data_ptr()))
@@ -39,7 +39,9 @@ print("records/scan mean %.0f p50 %.0f p90 %.0f p99 %.0f max %d" % (nrec.mean(),
 names = ["stream", "load+rowminmax", "select(store)", "rowscan", "scatter", "rank+permute", "heads+scan", "emit"]
 for i, nm in enumerate(names):
     print("  %-16s mean %8.0f  p50 %8.0f  p99 %8.0f" % (nm, dbg[:, i].mean(), np.median(dbg[:, i]), np.percentile(dbg[:, i], 99)))
-print("  total mean %.0f" % dbg.sum(1).mean())
+print("  total mean %.0f" % dbg[:, :8].sum(1).mean())
+nb = np.maximum(dbg[:, 12], 1)
+print("  wave 0, cycles per block: issue loads %.0f  wait entries + arithmetic %.0f  block pass %.0f  loop overhead %.0f  (blocks/scan %.1f)" % (
+    (dbg[:, 8] / nb).mean(), (dbg[:, 9] / nb).mean(), (dbg[:, 10] / nb).mean(), (dbg[:, 11] / nb).mean(), dbg[:, 12].mean()))
 npts = d_np.cpu().numpy()
 print("cells mean", npts.mean(), "status", int(d_st.max()))
-
