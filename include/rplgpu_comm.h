@@ -86,6 +86,44 @@ int32_t rplgpu_unpack_gathered_dev(rplgpu_handle_t h, const float *d_points_all,
                                    uint64_t *d_scan_start_all, uint32_t *d_n_points_all,
                                    uint32_t *d_status);
 
+/* ---- the compact exchange: 12-byte points (x, y, intensity) --------------------------------
+ * z is 0.0 for every point this path produces (a planar sensor: E2 sets z = 0, the E6 / E8
+ * transforms are planar), so it need not travel: a quarter fewer bytes per link.
+ *   rplgpu_pack_cloud_xyi_dev        arena (16-byte points) -> this rank's 12-byte slot; the first
+ *                                    min(*d_cursor, slot_points) points (device-side count)
+ *   rplgpu_allgather_clouds_xyi_dev  as rplgpu_allgather_clouds_dev for slots of slot_points * 3
+ *                                    floats (META blocks unchanged)
+ *   rplgpu_unpack_gathered_xyi_dev   gathered 12-byte slots -> ONE contiguous cloud of 16-byte
+ *                                    points (z = 0 put back) + the per-scan tables */
+int32_t rplgpu_pack_cloud_xyi_dev(rplgpu_handle_t h, const float *d_arena, const uint64_t *d_cursor,
+                                  uint64_t slot_points, float *d_slot);
+int32_t rplgpu_allgather_clouds_xyi_dev(rplgpu_handle_t h, const float *d_slot_local,
+                                        uint64_t slot_points, const uint32_t *d_meta_local,
+                                        uint32_t meta_words, float *d_slots_all,
+                                        uint32_t *d_meta_all);
+int32_t rplgpu_unpack_gathered_xyi_dev(rplgpu_handle_t h, const float *d_slots_all,
+                                       uint64_t slot_points, const uint32_t *d_meta_all,
+                                       uint32_t meta_words, uint32_t world, uint32_t max_scans,
+                                       float *d_packed, uint64_t *d_total,
+                                       uint64_t *d_scan_start_all, uint32_t *d_n_points_all,
+                                       uint32_t *d_status);
+
+/* ---- host twins of the layout functions ------------------------------------------------------
+ * The same rules as the device kernels (one source: csrc/rpl_comm_layout.hpp), plain host loops,
+ * no device and no handle: for transports other than RCCL and for world-size > 1 tests without
+ * GPUs (tests/test_sharding_gloo.py moves the slots with gloo and calls these).
+ * point_floats: 4 (x, y, z, intensity slots) or 3 (the compact slots above). */
+int32_t rplgpu_pack_cloud_meta_host(uint64_t cursor, const uint64_t *scan_start,
+                                    const uint32_t *n_points, uint32_t B, uint64_t slot_points,
+                                    uint32_t max_scans, uint32_t *meta);
+int32_t rplgpu_pack_cloud_xyi_host(const float *arena, uint64_t cursor, uint64_t slot_points,
+                                   float *slot);
+int32_t rplgpu_unpack_gathered_host(const float *points_all, uint64_t slot_points,
+                                    uint32_t point_floats, const uint32_t *meta_all,
+                                    uint32_t meta_words, uint32_t world, uint32_t max_scans,
+                                    float *packed, uint64_t *total, uint64_t *scan_start_all,
+                                    uint32_t *n_points_all, uint32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,12 @@ ABI_SYMBOLS = [
     "rplgpu_comm_fence",
     "rplgpu_comm_fence_lag",
     "rplgpu_unpack_gathered_dev",
+    "rplgpu_pack_cloud_xyi_dev",
+    "rplgpu_allgather_clouds_xyi_dev",
+    "rplgpu_unpack_gathered_xyi_dev",
+    "rplgpu_pack_cloud_meta_host",
+    "rplgpu_pack_cloud_xyi_host",
+    "rplgpu_unpack_gathered_host",
 ]
 
 
@@ -263,6 +269,12 @@ def load_library() -> C.CDLL:
     lib.rplgpu_comm_fence.argtypes = [vp]
     lib.rplgpu_comm_fence_lag.argtypes = [vp, u32]
     lib.rplgpu_unpack_gathered_dev.argtypes = [vp, vp, u64, vp, u32, u32, u32, vp, vp, vp, vp, vp]
+    lib.rplgpu_pack_cloud_xyi_dev.argtypes = [vp, vp, vp, u64, vp]
+    lib.rplgpu_allgather_clouds_xyi_dev.argtypes = [vp, vp, u64, vp, u32, vp, vp]
+    lib.rplgpu_unpack_gathered_xyi_dev.argtypes = [vp, vp, u64, vp, u32, u32, u32, vp, vp, vp, vp, vp]
+    lib.rplgpu_pack_cloud_meta_host.argtypes = [u64, vp, vp, u32, u64, u32, vp]
+    lib.rplgpu_pack_cloud_xyi_host.argtypes = [vp, u64, u64, vp]
+    lib.rplgpu_unpack_gathered_host.argtypes = [vp, u64, u32, vp, u32, u32, u32, vp, vp, vp, vp, vp]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int:  # default
@@ -519,6 +531,22 @@ class RplGpu:
         self._check(self._lib.rplgpu_allgather_clouds_dev(
             self._h, d_points_local, slot_points, d_meta_local, meta_words, d_points_all, d_meta_all))
 
+    def pack_cloud_xyi_dev(self, d_arena: int, d_cursor: int, slot_points: int, d_slot: int):
+        self._check(self._lib.rplgpu_pack_cloud_xyi_dev(self._h, d_arena, d_cursor, slot_points, d_slot))
+
+    def allgather_clouds_xyi_dev(self, d_slot_local: int, slot_points: int, d_meta_local: int,
+                                 meta_words: int, d_slots_all: int, d_meta_all: int):
+        self._check(self._lib.rplgpu_allgather_clouds_xyi_dev(
+            self._h, d_slot_local, slot_points, d_meta_local, meta_words, d_slots_all, d_meta_all))
+
+    def unpack_gathered_xyi_dev(self, d_slots_all: int, slot_points: int, d_meta_all: int,
+                                meta_words: int, world: int, max_scans: int, d_packed: int,
+                                d_total: int, d_scan_start_all: int, d_n_points_all: int,
+                                d_status: int = 0):
+        self._check(self._lib.rplgpu_unpack_gathered_xyi_dev(
+            self._h, d_slots_all, slot_points, d_meta_all, meta_words, world, max_scans, d_packed,
+            d_total, d_scan_start_all, d_n_points_all, d_status))
+
     def comm_fence(self, lag: int = 0):
         self._check(self._lib.rplgpu_comm_fence_lag(self._h, lag))
 
@@ -652,3 +680,53 @@ def frame_stream(ans_type: int, data: np.ndarray):
     nf = lib.rplgpu_frame_stream(ans_type, data.ctypes.data, len(data), off.ctypes.data,
                                  gap.ctypes.data, cap)
     return off[:nf], gap[:nf]
+
+
+# -- host twins of the exchange layout (include/rplgpu_comm.h; no device, no handle) -----------
+def pack_cloud_meta_host(cursor: int, scan_start: np.ndarray, n_points: np.ndarray, slot_points: int,
+                         max_scans: int) -> np.ndarray:
+    """META block of a rank's arena, as ``rplgpu_pack_cloud_meta_dev`` writes it."""
+    lib = load_library()
+    ss = np.ascontiguousarray(scan_start, np.uint64)
+    npnt = np.ascontiguousarray(n_points, np.uint32)
+    words = int(lib.rplgpu_cloud_meta_words(max_scans))
+    meta = np.zeros(words, np.uint32)
+    rc = lib.rplgpu_pack_cloud_meta_host(int(cursor), ss.ctypes.data, npnt.ctypes.data, len(npnt),
+                                         int(slot_points), int(max_scans), meta.ctypes.data)
+    if rc:
+        raise RplGpuError(rc, "rplgpu_pack_cloud_meta_host")
+    return meta
+
+
+def pack_cloud_xyi_host(arena: np.ndarray, cursor: int, slot_points: int) -> np.ndarray:
+    """A rank's compact slot (slot_points x 3 float32) from its arena ((cap, 4) float32)."""
+    a = np.ascontiguousarray(arena, np.float32)
+    slot = np.zeros((int(slot_points), 3), np.float32)
+    rc = load_library().rplgpu_pack_cloud_xyi_host(a.ctypes.data, int(cursor), int(slot_points),
+                                                   slot.ctypes.data)
+    if rc:
+        raise RplGpuError(rc, "rplgpu_pack_cloud_xyi_host")
+    return slot
+
+
+def unpack_gathered_host(points_all: np.ndarray, slot_points: int, meta_all: np.ndarray, world: int,
+                         max_scans: int):
+    """Gathered slots ((world, slot_points, 3 | 4) float32) + META blocks ((world, words) uint32) ->
+    (packed (total, 4), scan_start_all (world, max_scans) uint64, n_points_all (world, max_scans)
+    uint32, status (world,) uint32), by the library's own layout code."""
+    lib = load_library()
+    pts = np.ascontiguousarray(points_all, np.float32)
+    point_floats = int(pts.shape[-1])
+    meta = np.ascontiguousarray(meta_all, np.uint32).reshape(world, -1)
+    packed = np.zeros((world * int(slot_points), 4), np.float32)
+    total = np.zeros(1, np.uint64)
+    starts = np.zeros((world, max_scans), np.uint64)
+    npts = np.zeros((world, max_scans), np.uint32)
+    status = np.zeros(world, np.uint32)
+    rc = lib.rplgpu_unpack_gathered_host(pts.ctypes.data, int(slot_points), point_floats,
+                                         meta.ctypes.data, int(meta.shape[1]), int(world),
+                                         int(max_scans), packed.ctypes.data, total.ctypes.data,
+                                         starts.ctypes.data, npts.ctypes.data, status.ctypes.data)
+    if rc:
+        raise RplGpuError(rc, "rplgpu_unpack_gathered_host")
+    return packed[: int(total[0])], starts, npts, status

@@ -5,80 +5,66 @@
 
 #include "rpl_device.hpp"
 #include "rpl_launch.hpp"
+#include "rpl_comm_layout.hpp"
 
 namespace rpl {
 
-// meta = [count lo, count hi, B, flags, B x {start lo, start hi, n_points}] (words)
+// meta = [count lo, count hi, B, flags, B x {start lo, start hi, n_points}] (words): the rules live in
+// rpl_comm_layout.hpp, shared with the host entry points the CPU tests drive
 __global__ __launch_bounds__(256) void k_pack_meta(const unsigned long long *__restrict__ cursor,
                                                    const unsigned long long *__restrict__ scan_start,
                                                    const uint32_t *__restrict__ n_points, uint32_t B,
                                                    unsigned long long slot_points, uint32_t max_scans,
                                                    uint32_t *__restrict__ meta) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) {
-    const unsigned long long c = *cursor;
-    const unsigned long long k = c < slot_points ? c : slot_points;
-    meta[0] = (uint32_t)k;
-    meta[1] = (uint32_t)(k >> 32);
-    meta[2] = B;
-    meta[3] = c > slot_points ? 1u : 0u;
-  }
-  if (t < max_scans) {
-    unsigned long long st = 0ull;
-    uint32_t np = 0u;
-    if (t < B) {
-      st = scan_start[t];
-      np = n_points[t];
-      // a scan (partly) beyond the slot is cut like the slot is
-      if (st >= slot_points) { np = 0u; st = 0ull; }
-      else if (st + np > slot_points) np = (uint32_t)(slot_points - st);
-    }
-    meta[4 + 3 * t] = (uint32_t)st;
-    meta[5 + 3 * t] = (uint32_t)(st >> 32);
-    meta[6 + 3 * t] = np;
+  if (t == 0) layout::meta_head(*cursor, B, slot_points, meta);
+  if (t < max_scans) layout::meta_scan(t, B, scan_start, n_points, slot_points, meta);
+}
+
+// The exchanged point: 12 bytes (x, y, intensity).  z is 0.0 for every point this path makes (a
+// planar sensor, planar de-skew and poses), so it does not travel: a quarter less on the links.
+// Compaction of a rank's arena (16-byte points) into its 12-byte slot; count = min(cursor, slot).
+__global__ __launch_bounds__(256) void k_pack_xyi(const float4 *__restrict__ arena,
+                                                  const unsigned long long *__restrict__ cursor,
+                                                  unsigned long long slot_points,
+                                                  float *__restrict__ slot) {
+  const unsigned long long c = *cursor, n = c < slot_points ? c : slot_points;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const float4 p = arena[i];
+    slot[3 * i] = p.x;
+    slot[3 * i + 1] = p.y;
+    slot[3 * i + 2] = p.w;
   }
 }
 
 // one block per (rank, piece): copies the valid part of rank r's slot to its place in the
-// contiguous cloud and writes rank r's rows of the per-scan tables
+// contiguous cloud and writes rank r's rows of the per-scan tables.  XYI: the slots hold 12-byte
+// points, z = 0 is put back.
+template <bool XYI>
 __global__ __launch_bounds__(256) void k_unpack_gathered(
-    const float4 *__restrict__ points_all, unsigned long long slot_points,
+    const float *__restrict__ points_all, unsigned long long slot_points,
     const uint32_t *__restrict__ meta_all, uint32_t meta_words, uint32_t world, uint32_t max_scans,
     float4 *__restrict__ packed, unsigned long long *__restrict__ total,
     unsigned long long *__restrict__ scan_start_all, uint32_t *__restrict__ n_points_all,
     uint32_t *__restrict__ status) {
   const uint32_t r = blockIdx.y;
-  // offset of rank r = sum of the counts before it (world is small: every block adds them up)
-  unsigned long long off = 0ull, mine = 0ull, all = 0ull;
-  for (uint32_t q = 0; q < world; ++q) {
-    const uint32_t *m = meta_all + (size_t)q * meta_words;
-    unsigned long long c = ((unsigned long long)m[1] << 32) | m[0];
-    if (c > slot_points) c = slot_points;
-    if (q < r) off += c;
-    if (q == r) mine = c;
-    all += c;
-  }
+  unsigned long long off, mine, all;  // (world is small: every block adds the counts up)
+  layout::rank_extent(meta_all, meta_words, world, slot_points, r, &off, &mine, &all);
   const uint32_t *m = meta_all + (size_t)r * meta_words;
   if (blockIdx.x == 0) {
     if (r == 0 && threadIdx.x == 0) *total = all;
     if (status && threadIdx.x == 0) status[r] = (m[3] & 1u) ? RPLGPU_SCAN_OUT_TRUNCATED : 0u;
-    const uint32_t B = min(m[2], max_scans);
-    for (uint32_t s = threadIdx.x; s < max_scans; s += blockDim.x) {
-      unsigned long long st = 0ull;
-      uint32_t np = 0u;
-      if (s < B) {
-        st = (((unsigned long long)m[5 + 3 * s] << 32) | m[4 + 3 * s]) + off;
-        np = m[6 + 3 * s];
-      }
-      scan_start_all[(size_t)r * max_scans + s] = np ? st : 0ull;
-      n_points_all[(size_t)r * max_scans + s] = np;
-    }
+    for (uint32_t s = threadIdx.x; s < max_scans; s += blockDim.x)
+      layout::scan_row(m, s, max_scans, off, &scan_start_all[(size_t)r * max_scans + s],
+                       &n_points_all[(size_t)r * max_scans + s]);
   }
-  const float4 *src = points_all + (size_t)r * slot_points;
+  const float *src = points_all + (size_t)r * slot_points * (XYI ? 3u : 4u);
   float4 *dst = packed + off;
   for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < mine;
        i += (unsigned long long)gridDim.x * blockDim.x)
-    dst[i] = src[i];
+    dst[i] = XYI ? make_float4(src[3 * i], src[3 * i + 1], 0.0f, src[3 * i + 2])
+                 : reinterpret_cast<const float4 *>(src)[i];
 }
 
 // completion flag of a single-scan call (rplgpu_api.hip wait_scan): everything queued before this
@@ -101,17 +87,29 @@ hipError_t launch_pack_meta(hipStream_t s, const unsigned long long *cursor,
   return hipGetLastError();
 }
 
+hipError_t launch_pack_xyi(hipStream_t s, const float *arena, const unsigned long long *cursor,
+                           unsigned long long slot_points, float *slot, uint32_t n_cu) {
+  hipLaunchKernelGGL(k_pack_xyi, dim3(8u * (n_cu ? n_cu : 256u)), dim3(256), 0, s,
+                     (const float4 *)arena, cursor, slot_points, slot);
+  return hipGetLastError();
+}
+
 hipError_t launch_unpack_gathered(hipStream_t s, const float *points_all,
                                   unsigned long long slot_points, const uint32_t *meta_all,
                                   uint32_t meta_words, uint32_t world, uint32_t max_scans,
                                   float *packed, unsigned long long *total,
                                   unsigned long long *scan_start_all, uint32_t *n_points_all,
-                                  uint32_t *status, uint32_t n_cu) {
+                                  uint32_t *status, uint32_t n_cu, bool xyi) {
   if (world == 0) return hipSuccess;
   const uint32_t per_rank = std::max<uint32_t>(1u, (4u * (n_cu ? n_cu : 256u) + world - 1u) / world);
-  hipLaunchKernelGGL(k_unpack_gathered, dim3(per_rank, world), dim3(256), 0, s,
-                     (const float4 *)points_all, slot_points, meta_all, meta_words, world, max_scans,
-                     (float4 *)packed, total, scan_start_all, n_points_all, status);
+  if (xyi)
+    hipLaunchKernelGGL(k_unpack_gathered<true>, dim3(per_rank, world), dim3(256), 0, s, points_all,
+                       slot_points, meta_all, meta_words, world, max_scans, (float4 *)packed, total,
+                       scan_start_all, n_points_all, status);
+  else
+    hipLaunchKernelGGL(k_unpack_gathered<false>, dim3(per_rank, world), dim3(256), 0, s, points_all,
+                       slot_points, meta_all, meta_words, world, max_scans, (float4 *)packed, total,
+                       scan_start_all, n_points_all, status);
   return hipGetLastError();
 }
 

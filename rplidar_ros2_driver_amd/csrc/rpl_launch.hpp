@@ -81,7 +81,9 @@ hipError_t launch_unpack_gathered(hipStream_t s, const float *points_all,
                                   uint32_t meta_words, uint32_t world, uint32_t max_scans,
                                   float *packed, unsigned long long *total,
                                   unsigned long long *scan_start_all, uint32_t *n_points_all,
-                                  uint32_t *status, uint32_t n_cu);
+                                  uint32_t *status, uint32_t n_cu, bool xyi = false);
+hipError_t launch_pack_xyi(hipStream_t s, const float *arena, const unsigned long long *cursor,
+                           unsigned long long slot_points, float *slot, uint32_t n_cu);
 
 // decode stage (rpl_decode.hip)
 hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,

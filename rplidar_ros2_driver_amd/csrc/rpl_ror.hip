@@ -107,12 +107,14 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   const int trips = (int)((n + kSpan - 1u) / kSpan);  // block-uniform
   // software pipeline: raw nodes two trips ahead, points (the table gather) one trip ahead; the
   // eight halo samples are a third slot of threads 0..7 and ride the same pipeline
+  // (thread 3's offset base - 1 is 0xFFFFFFFF as a number: "no halo duty" is a flag of its own,
+  // not a sentinel value of the offset)
+  const bool has_halo = threadIdx.x < 2u * kRorNear;
   const uint32_t halo_q = threadIdx.x < (uint32_t)kRorNear ? threadIdx.x - (uint32_t)kRorNear  // base - 4 + t
-                          : threadIdx.x < 2u * kRorNear    ? kSpan + threadIdx.x - (uint32_t)kRorNear
-                                                           : 0xFFFFFFFFu;  // no halo duty
+                                                           : kSpan + threadIdx.x - (uint32_t)kRorNear;
   auto halo_index = [&](uint32_t base) -> uint32_t {
     // (first trip: base - 4 + t wraps below 0 and fails q < n; no duty: always out of range)
-    return halo_q == 0xFFFFFFFFu ? 0xFFFFFFFFu : base + halo_q;
+    return has_halo ? base + halo_q : 0xFFFFFFFFu;
   };
   float2 p0 = point_of(load_node(threadIdx.x)), p1 = point_of(load_node(kBlock + threadIdx.x));
   float2 ph = point_of(load_node(halo_index(0u)));

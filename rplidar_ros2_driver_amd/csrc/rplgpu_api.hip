@@ -15,12 +15,14 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rplgpu.h"
 #include "rplgpu_msg.h"
 #include "rpl_launch.hpp"
 #include "rpl_msg.hpp"
+#include "rpl_comm_layout.hpp"
 
 struct rplgpu_ctx {
   int device = -1;
@@ -361,7 +363,11 @@ int32_t wait_scan(rplgpu_ctx *c) {
   RPL_HIP(c, rpl::launch_signal(c->stream, reinterpret_cast<uint32_t *>(c->d_pin + c->flag_off), seq));
   for (uint32_t spins = 0; spins < 400000u; ++spins) {
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return RPLGPU_OK;
+#if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
   }
   RPL_HIP(c, hipStreamSynchronize(c->stream));
   return RPLGPU_OK;
@@ -1656,12 +1662,22 @@ int32_t rplgpu_comm_init(rplgpu_handle_t h, int32_t rank, int32_t world,
     return RPLGPU_ERR_INVALID_ARG;
   }
   RPL_HIP(h, hipSetDevice(h->device));
-  RPL_HIP(h, hipStreamCreateWithFlags(&h->xstream, hipStreamNonBlocking));
-  RPL_HIP(h, hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
-  for (auto &e : h->ev_x) RPL_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  rplgpu_nccl_id_t uid;
-  std::memcpy(&uid, id, sizeof(uid));
-  RPL_NCCL(h, rccl().CommInitRank(&h->comm, world, uid, rank));
+  // (every failure below releases what was created so far: a retry starts from nothing)
+  auto init = [&]() -> int32_t {
+    RPL_HIP(h, hipStreamCreateWithFlags(&h->xstream, hipStreamNonBlocking));
+    RPL_HIP(h, hipEventCreateWithFlags(&h->ev_main, hipEventDisableTiming));
+    for (auto &e : h->ev_x) RPL_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    rplgpu_nccl_id_t uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    RPL_NCCL(h, rccl().CommInitRank(&h->comm, world, uid, rank));
+    return RPLGPU_OK;
+  };
+  const int32_t rc = init();
+  if (rc != RPLGPU_OK) {
+    h->comm = nullptr;  // (not a communicator teardown can destroy)
+    comm_teardown(h);
+    return rc;
+  }
   h->comm_rank = rank;
   h->comm_world = world;
   return RPLGPU_OK;
@@ -1691,10 +1707,29 @@ int32_t rplgpu_pack_cloud_meta_dev(rplgpu_handle_t h, const uint64_t *d_cursor,
   return RPLGPU_OK;
 }
 
+namespace {
+int32_t allgather_slots(rplgpu_handle_t h, const float *d_points_local, uint64_t slot_points,
+                        uint32_t point_floats, const uint32_t *d_meta_local, uint32_t meta_words,
+                        float *d_points_all, uint32_t *d_meta_all);
+}
 int32_t rplgpu_allgather_clouds_dev(rplgpu_handle_t h, const float *d_points_local,
                                     uint64_t slot_points, const uint32_t *d_meta_local,
                                     uint32_t meta_words, float *d_points_all,
                                     uint32_t *d_meta_all) {
+  return allgather_slots(h, d_points_local, slot_points, 4u, d_meta_local, meta_words, d_points_all,
+                         d_meta_all);
+}
+int32_t rplgpu_allgather_clouds_xyi_dev(rplgpu_handle_t h, const float *d_slot_local,
+                                        uint64_t slot_points, const uint32_t *d_meta_local,
+                                        uint32_t meta_words, float *d_slots_all,
+                                        uint32_t *d_meta_all) {
+  return allgather_slots(h, d_slot_local, slot_points, 3u, d_meta_local, meta_words, d_slots_all,
+                         d_meta_all);
+}
+namespace {
+int32_t allgather_slots(rplgpu_handle_t h, const float *d_points_local, uint64_t slot_points,
+                        uint32_t point_floats, const uint32_t *d_meta_local, uint32_t meta_words,
+                        float *d_points_all, uint32_t *d_meta_all) {
   if (!h || !d_points_local || !d_meta_local || !d_points_all || !d_meta_all || meta_words == 0)
     return RPLGPU_ERR_INVALID_ARG;
   if (!h->comm) {
@@ -1712,16 +1747,21 @@ int32_t rplgpu_allgather_clouds_dev(rplgpu_handle_t h, const float *d_points_loc
   RPL_HIP(h, hipStreamWaitEvent(h->xstream, h->ev_main, 0));
   RPL_NCCL(h, rccl().GroupStart());
   int r1 = rccl().AllGather(d_meta_local, d_meta_all, meta_words, kNcclUint32, h->comm, h->xstream);
-  int r2 = slot_points ? rccl().AllGather(d_points_local, d_points_all, (size_t)slot_points * 4u,
-                                          kNcclFloat32, h->comm, h->xstream)
+  int r2 = slot_points ? rccl().AllGather(d_points_local, d_points_all,
+                                          (size_t)slot_points * point_floats, kNcclFloat32, h->comm,
+                                          h->xstream)
                        : 0;
-  RPL_NCCL(h, rccl().GroupEnd());
-  RPL_NCCL(h, r1);
-  RPL_NCCL(h, r2);
+  const int r3 = rccl().GroupEnd();
+  // the ring event is recorded whatever RCCL said, so that a later fence waits for what was
+  // really queued on the exchange stream and never for an event of an older exchange
   RPL_HIP(h, hipEventRecord(h->ev_x[h->n_exchanges & 3u], h->xstream));
   ++h->n_exchanges;
+  RPL_NCCL(h, r1);
+  RPL_NCCL(h, r2);
+  RPL_NCCL(h, r3);
   return RPLGPU_OK;
 }
+}  // namespace
 
 int32_t rplgpu_comm_fence_lag(rplgpu_handle_t h, uint32_t lag) {
   if (!h || lag > 3u) return RPLGPU_ERR_INVALID_ARG;
@@ -1750,7 +1790,99 @@ int32_t rplgpu_unpack_gathered_dev(rplgpu_handle_t h, const float *d_points_all,
                  h->stream, d_points_all, slot_points, d_meta_all, meta_words, world, max_scans, d_packed,
                  reinterpret_cast<unsigned long long *>(d_total),
                  reinterpret_cast<unsigned long long *>(d_scan_start_all), d_n_points_all, d_status,
-                 h->n_cu));
+                 h->n_cu, false));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_unpack_gathered_xyi_dev(rplgpu_handle_t h, const float *d_slots_all,
+                                       uint64_t slot_points, const uint32_t *d_meta_all,
+                                       uint32_t meta_words, uint32_t world, uint32_t max_scans,
+                                       float *d_packed, uint64_t *d_total,
+                                       uint64_t *d_scan_start_all, uint32_t *d_n_points_all,
+                                       uint32_t *d_status) {
+  if (!h || !d_slots_all || !d_meta_all || !d_packed || !d_total || !d_scan_start_all ||
+      !d_n_points_all || world == 0 || world > 4096 || meta_words < rplgpu_cloud_meta_words(max_scans))
+    return RPLGPU_ERR_INVALID_ARG;
+  if (!device_readable(h, d_slots_all, "d_slots_all") || !device_readable(h, d_meta_all, "d_meta_all") ||
+      !device_readable(h, d_packed, "d_packed"))
+    return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_unpack_gathered(
+                 h->stream, d_slots_all, slot_points, d_meta_all, meta_words, world, max_scans, d_packed,
+                 reinterpret_cast<unsigned long long *>(d_total),
+                 reinterpret_cast<unsigned long long *>(d_scan_start_all), d_n_points_all, d_status,
+                 h->n_cu, true));
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_pack_cloud_xyi_dev(rplgpu_handle_t h, const float *d_arena, const uint64_t *d_cursor,
+                                  uint64_t slot_points, float *d_slot) {
+  if (!h || !d_arena || !d_cursor || !d_slot) return RPLGPU_ERR_INVALID_ARG;
+  if (!device_readable(h, d_arena, "d_arena") || !device_readable(h, d_cursor, "d_cursor") ||
+      !device_readable(h, d_slot, "d_slot"))
+    return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, rpl::launch_pack_xyi(h->stream, d_arena,
+                                  reinterpret_cast<const unsigned long long *>(d_cursor), slot_points,
+                                  d_slot, h->n_cu));
+  return RPLGPU_OK;
+}
+
+/* Host twins of the layout kernels: the same rules (rpl_comm_layout.hpp), plain loops, no device —
+ * what a world-size-2 test over a CPU transport (gloo) drives. */
+int32_t rplgpu_pack_cloud_meta_host(uint64_t cursor, const uint64_t *scan_start,
+                                    const uint32_t *n_points, uint32_t B, uint64_t slot_points,
+                                    uint32_t max_scans, uint32_t *meta) {
+  if (!meta || (B && (!scan_start || !n_points)) || B > max_scans) return RPLGPU_ERR_INVALID_ARG;
+  rpl::layout::meta_head(cursor, B, slot_points, meta);
+  for (uint32_t t = 0; t < max_scans; ++t)
+    rpl::layout::meta_scan(t, B, reinterpret_cast<const unsigned long long *>(scan_start), n_points,
+                           slot_points, meta);
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_pack_cloud_xyi_host(const float *arena, uint64_t cursor, uint64_t slot_points,
+                                   float *slot) {
+  if (!arena || !slot) return RPLGPU_ERR_INVALID_ARG;
+  const uint64_t n = cursor < slot_points ? cursor : slot_points;
+  for (uint64_t i = 0; i < n; ++i) {
+    slot[3 * i] = arena[4 * i];
+    slot[3 * i + 1] = arena[4 * i + 1];
+    slot[3 * i + 2] = arena[4 * i + 3];
+  }
+  return RPLGPU_OK;
+}
+
+int32_t rplgpu_unpack_gathered_host(const float *points_all, uint64_t slot_points,
+                                    uint32_t point_floats, const uint32_t *meta_all,
+                                    uint32_t meta_words, uint32_t world, uint32_t max_scans,
+                                    float *packed, uint64_t *total, uint64_t *scan_start_all,
+                                    uint32_t *n_points_all, uint32_t *status) {
+  if (!points_all || !meta_all || !packed || !total || !scan_start_all || !n_points_all ||
+      world == 0 || world > 4096 || (point_floats != 3u && point_floats != 4u) ||
+      meta_words < rplgpu_cloud_meta_words(max_scans))
+    return RPLGPU_ERR_INVALID_ARG;
+  for (uint32_t r = 0; r < world; ++r) {
+    unsigned long long off, mine, all;
+    rpl::layout::rank_extent(meta_all, meta_words, world, slot_points, r, &off, &mine, &all);
+    const uint32_t *m = meta_all + (size_t)r * meta_words;
+    if (r == 0) *total = all;
+    if (status) status[r] = (m[3] & 1u) ? RPLGPU_SCAN_OUT_TRUNCATED : 0u;
+    for (uint32_t s = 0; s < max_scans; ++s) {
+      unsigned long long st;
+      rpl::layout::scan_row(m, s, max_scans, off, &st, &n_points_all[(size_t)r * max_scans + s]);
+      scan_start_all[(size_t)r * max_scans + s] = st;
+    }
+    const float *src = points_all + (size_t)r * slot_points * point_floats;
+    float *dst = packed + 4u * off;
+    for (unsigned long long i = 0; i < mine; ++i) {
+      if (point_floats == 3u) {
+        dst[4 * i] = src[3 * i]; dst[4 * i + 1] = src[3 * i + 1]; dst[4 * i + 2] = 0.0f; dst[4 * i + 3] = src[3 * i + 2];
+      } else {
+        std::memcpy(dst + 4 * i, src + 4 * i, 16);
+      }
+    }
+  }
   return RPLGPU_OK;
 }
 

@@ -173,12 +173,13 @@ def unpack_gathered(points_all: torch.Tensor, meta_all: torch.Tensor, slot_point
 
 class CloudExchange:
     """bench.py's N > 1 step through the library's own exchange: the rank's block of scans is cut
-    into `chunks`; chunk c is voxelised STRAIGHT INTO this rank's slot of chunk c's receive buffer
-    (the arena is the slot: RCCL's in-place all-gather then moves no local bytes at all) on the
-    handle's main stream and all-gathered on the exchange stream while chunk c + 1 is being
-    voxelised.  Every chunk has its own receive buffer, so nothing is reused inside a step and the
+    into `chunks`; chunk c is voxelised into the rank's arena, compacted to 12-byte points
+    (x, y, intensity: z is 0 for every point of this path and does not travel) STRAIGHT INTO this
+    rank's slot of chunk c's receive buffer (RCCL's in-place all-gather then moves no local
+    bytes) on the handle's main stream, and all-gathered on the exchange stream while chunk c + 1
+    is being voxelised.  Every chunk has its own receive buffer, so nothing is reused inside a step and the
     step needs no fence but the last.  Slot sizes are fixed after one calibration pass (max cells
-    per chunk over all ranks + 15 % head room; a cloud that outgrows its slot is cut and flagged,
+    per chunk over all ranks + 5 % head room; a cloud that outgrows its slot is cut and flagged,
     never overrun), so a timed step has no host synchronisation: counts travel in the META blocks
     on the device."""
 
@@ -205,23 +206,32 @@ class CloudExchange:
             except Exception as e:  # (the broadcast below still has to happen on every rank)
                 ok, self.backend = 0, f"torch.distributed (rplgpu_comm_unique_id failed: {e})"
             self.dist.broadcast(uid, src=0)
+            # rplgpu_comm_init is a collective: agree on "the id is good" BEFORE any rank enters it
+            # (rank 0 failing to make the id must not leave the others waiting inside RCCL)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+            if ok and int(flag.item()) == 0:
+                self.backend = "torch.distributed (rank 0 could not make a communicator id)"
+            ok = int(flag.item())
             if ok:
                 try:
                     gpu.comm_init(rank, world, uid.cpu().numpy())
                 except Exception as e:
                     ok, self.backend = 0, f"torch.distributed (rplgpu_comm_init failed: {e})"
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
-            if ok and int(flag.item()) == 0:
-                self.backend = "torch.distributed (a peer's communicator did not come up)"
-            ok = int(flag.item())
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+                if ok and int(flag.item()) == 0:
+                    self.backend = "torch.distributed (a peer's communicator did not come up)"
+                    gpu.comm_destroy()
+                ok = int(flag.item())
         self.native = bool(ok)
         self.cursor = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.chunks)]
         self.start = [torch.zeros(self.Bc, dtype=torch.int64, device=dev) for _ in range(self.chunks)]
         self.npts = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(self.chunks)]
         self.stat = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(self.chunks)]
         self.slot = None
-        self.recv_pts = None
+        self.arena = None     # per chunk: this rank's voxelised cloud (16-byte points)
+        self.recv_pts = None  # per chunk: every rank's compact slot (12-byte points: x, y, intensity)
         self.recv_meta = torch.zeros(self.chunks, world, self.mw, dtype=torch.int32, device=dev)
 
     def _chunk(self, c):
@@ -245,8 +255,10 @@ class CloudExchange:
         del tmp
         t = torch.tensor([worst], dtype=torch.int64, device=self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        self.slot = min(cap, int(int(t.item()) * 1.15) + 1024)
-        self.recv_pts = torch.empty(self.chunks, self.world, self.slot, 4, dtype=torch.float32,
+        # head room 5 % + 256 points: the slot travels whole (an all-gather moves equal pieces)
+        self.slot = min(cap, int(int(t.item()) * 1.05) + 256)
+        self.arena = torch.empty(self.chunks, self.slot, 4, dtype=torch.float32, device=self.dev)
+        self.recv_pts = torch.empty(self.chunks, self.world, self.slot, 3, dtype=torch.float32,
                                     device=self.dev)
 
     def step(self, d_nodes, d_len, params):
@@ -257,11 +269,13 @@ class CloudExchange:
             lo, nb = self._chunk(c)
             if nb <= 0:
                 continue
-            mine = self.recv_pts[c, r]      # this rank's slot of chunk c: the arena
+            mine = self.recv_pts[c, r]      # this rank's slot of chunk c (in place in the receive buffer)
             meta = self.recv_meta[c, r]
             g.cloud_arena_dev(d_nodes.data_ptr() + lo * self.n * 8, self.n, d_len.data_ptr() + lo * 4, nb,
-                              params, mine.data_ptr(), self.slot, self.cursor[c].data_ptr(),
+                              params, self.arena[c].data_ptr(), self.slot, self.cursor[c].data_ptr(),
                               self.start[c].data_ptr(), self.npts[c].data_ptr(), self.stat[c].data_ptr())
+            g.pack_cloud_xyi_dev(self.arena[c].data_ptr(), self.cursor[c].data_ptr(), self.slot,
+                                 mine.data_ptr())
             g.pack_cloud_meta_dev(self.cursor[c].data_ptr(), self.start[c].data_ptr(),
                                   self.npts[c].data_ptr(), nb, self.slot, self.Bc, meta.data_ptr())
             self._gather(c, mine, meta)
@@ -270,9 +284,11 @@ class CloudExchange:
 
     def _gather(self, c, mine, meta):
         if self.native:
-            self.gpu.allgather_clouds_dev(mine.data_ptr(), self.slot, meta.data_ptr(), self.mw,
-                                          self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
-        else:  # fallback: torch.distributed (its own stream handling; a send copy to be safe)
+            self.gpu.allgather_clouds_xyi_dev(mine.data_ptr(), self.slot, meta.data_ptr(), self.mw,
+                                              self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
+        else:  # fallback: torch.distributed on torch's current stream — the handle's stream (which
+            # the kernels above were queued on) must be drained first; a send copy to be safe
+            self.gpu.synchronize()
             self.dist.all_gather_into_tensor(self.recv_pts[c].view(-1), mine.reshape(-1).clone())
             self.dist.all_gather_into_tensor(self.recv_meta[c].view(-1), meta.reshape(-1).clone())
 
@@ -285,7 +301,13 @@ class CloudExchange:
 
     def last_bytes(self):
         """bytes this rank RECEIVES from its peers per step"""
-        return int(self.chunks * (self.world - 1) * (self.slot or 0) * 16)
+        return int(self.chunks * (self.world - 1) * (self.slot or 0) * 12)
+
+    def unpack(self, c, d_packed, d_total, d_start_all, d_np_all, d_status=0):
+        """chunk c's gathered slots -> one contiguous cloud of 16-byte points + per-scan tables"""
+        self.gpu.unpack_gathered_xyi_dev(self.recv_pts[c].data_ptr(), self.slot,
+                                         self.recv_meta[c].data_ptr(), self.mw, self.world, self.Bc,
+                                         d_packed, d_total, d_start_all, d_np_all, d_status)
 
     def close(self):
         if self.native:

@@ -162,14 +162,34 @@ def _c5_worker(rank, world, port, per_rank, n, q):
             starts[j] = at
             arena[at: at + counts[j]] = torch.from_numpy(mine[j])
             at += counts[j]
-        meta = sh.pack_cloud_meta(at, starts, counts, slot, per_rank)
+        # the layout is the PRODUCT's: the C ABI's host entry points (include/rplgpu_comm.h, the
+        # same rules the device kernels compile: csrc/rpl_comm_layout.hpp); the torch twins of
+        # sharding.py are only cross-checked against them
+        from rplidar_ros2_driver_amd import abi
+        meta_np = abi.pack_cloud_meta_host(at, starts, counts, slot, per_rank)
+        meta = torch.from_numpy(meta_np.view(np.int32).copy())
+        ok = torch.equal(meta, sh.pack_cloud_meta(at, starts, counts, slot, per_rank))
         pts_all = torch.empty(world * slot * 4)
         dist.all_gather_into_tensor(pts_all, arena.view(-1))
         meta_all = torch.empty(world * sh.meta_words(per_rank), dtype=torch.int32)
         dist.all_gather_into_tensor(meta_all, meta)
-        packed, st_all, np_all, status = sh.unpack_gathered(pts_all.view(-1, 4), meta_all, slot, world,
+        packed_np, st_np, npn_np, status_np = abi.unpack_gathered_host(
+            pts_all.view(world, slot, 4).numpy(), slot, meta_all.numpy().view(np.uint32), world, per_rank)
+        packed, st_all, np_all, status = (torch.from_numpy(packed_np.copy()), st_np.astype(np.int64),
+                                          npn_np.astype(np.int64), status_np.astype(np.int64))
+        t_packed, t_st, t_np, t_status = sh.unpack_gathered(pts_all.view(-1, 4), meta_all, slot, world,
                                                             per_rank)
-        ok = int(status.sum()) == 0 and len(packed) == int(np_all.sum())
+        ok = ok and torch.equal(packed, t_packed) and np.array_equal(st_all, t_st.numpy()) \
+            and np.array_equal(np_all, t_np.numpy()) and np.array_equal(status, t_status.numpy())
+        ok = ok and int(status.sum()) == 0 and len(packed) == int(np_all.sum())
+        # the compact exchange: 12-byte points (x, y, intensity) travel, z = 0 comes back
+        slot12 = torch.from_numpy(abi.pack_cloud_xyi_host(arena.numpy(), at, slot))
+        s12_all = torch.empty(world * slot * 3)
+        dist.all_gather_into_tensor(s12_all, slot12.view(-1))
+        packed12, st12, np12, status12 = abi.unpack_gathered_host(
+            s12_all.view(world, slot, 3).numpy(), slot, meta_all.numpy().view(np.uint32), world, per_rank)
+        ok = ok and packed12.tobytes() == packed_np.tobytes() and np.array_equal(st12, st_np) \
+            and np.array_equal(np12, npn_np) and int(status12.sum()) == 0
         # per-sensor transform into the common frame, then one serialised PointCloud2
         fused = packed.numpy().copy()
         for r in range(world):
@@ -187,8 +207,15 @@ def _c5_worker(rank, world, port, per_rank, n, q):
         ok = ok and msg == ref_msg
         # a slot that is too small truncates and flags instead of overrunning
         small = max(1, at // 2)
-        meta_s = sh.pack_cloud_meta(at, starts, counts, small, per_rank)
+        meta_s = abi.pack_cloud_meta_host(at, starts, counts, small, per_rank)
         ok = ok and int(meta_s[3]) == 1 and int(meta_s[0]) == small
+        ok = ok and torch.equal(torch.from_numpy(meta_s.view(np.int32).copy()),
+                                sh.pack_cloud_meta(at, starts, counts, small, per_rank))
+        cut, _, np_cut, st_cut = abi.unpack_gathered_host(
+            np.stack([abi.pack_cloud_xyi_host(arena.numpy(), at, small)] * world), small,
+            np.stack([meta_s] * world), world, per_rank)
+        ok = ok and len(cut) == world * small and int(np_cut.sum()) == world * small \
+            and all(int(x) == 8 for x in st_cut)  # RPLGPU_SCAN_OUT_TRUNCATED
         q.put((rank, bool(ok), len(packed)))
     finally:
         dist.destroy_process_group()
