@@ -88,6 +88,59 @@ def test_meta_and_unpack_kernels_match_their_twins(gpu):
         assert bool(w_stat.any()) == (slot < total)
 
 
+def test_compact_exchange_kernels_match_the_host_entry_points(gpu):
+    """12-byte slots: rplgpu_pack_cloud_xyi_dev / rplgpu_unpack_gathered_xyi_dev against
+    rplgpu_pack_cloud_xyi_host / rplgpu_unpack_gathered_host (one layout source for both)."""
+    import torch
+    dev = torch.device("cuda:0")
+    S, n = 5, 7000
+    batch = synth.make_batch(43, S, n)
+    p = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
+    t = _arena(gpu, torch, dev, batch, p, S * 4096)
+    gpu.synchronize()
+    total = int(t["cur"].item())
+    arena_h = t["arena"].cpu().numpy()
+    assert np.all(arena_h[:total, 2] == 0.0)  # z is 0 for every point this path makes
+    max_scans, world = 6, 3
+    mw = abi.cloud_meta_words(max_scans)
+    for slot in (total + 300, total, total // 3):
+        d_slot = torch.full((slot, 3), -5.0, dtype=torch.float32, device=dev)
+        gpu.pack_cloud_xyi_dev(t["arena"].data_ptr(), t["cur"].data_ptr(), slot, d_slot.data_ptr())
+        gpu.synchronize()
+        want = abi.pack_cloud_xyi_host(arena_h, total, slot)
+        k = min(total, slot)
+        assert d_slot.cpu().numpy()[:k].tobytes() == want[:k].tobytes()
+        assert np.all(d_slot.cpu().numpy()[k:] == -5.0)
+        meta = abi.pack_cloud_meta_host(total, t["start"].cpu().numpy(), t["npts"].cpu().numpy(), slot, max_scans)
+        d_meta = torch.zeros(mw, dtype=torch.int32, device=dev)
+        gpu.pack_cloud_meta_dev(t["cur"].data_ptr(), t["start"].data_ptr(), t["npts"].data_ptr(), S,
+                                slot, max_scans, d_meta.data_ptr())
+        gpu.synchronize()
+        assert d_meta.cpu().numpy().view(np.uint32).tolist() == meta.tolist()
+        metas = np.stack([meta] * world)
+        metas[2, 0] = max(int(metas[2, 0]) - 11, 0)
+        slots = np.stack([want + np.float32(r) for r in range(world)])
+        d_slots, d_metas = torch.from_numpy(slots).to(dev), torch.from_numpy(metas.view(np.int32)).to(dev)
+        d_packed = torch.full((world * slot + 4, 4), -3.0, dtype=torch.float32, device=dev)
+        d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_sa = torch.zeros(world, max_scans, dtype=torch.int64, device=dev)
+        d_na = torch.zeros(world, max_scans, dtype=torch.int32, device=dev)
+        d_stat = torch.zeros(world, dtype=torch.int32, device=dev)
+        gpu.unpack_gathered_xyi_dev(d_slots.data_ptr(), slot, d_metas.data_ptr(), mw, world, max_scans,
+                                    d_packed.data_ptr(), d_total.data_ptr(), d_sa.data_ptr(),
+                                    d_na.data_ptr(), d_stat.data_ptr())
+        gpu.synchronize()
+        h_pk, h_st, h_np, h_status = abi.unpack_gathered_host(slots, slot, metas, world, max_scans)
+        assert int(d_total.item()) == len(h_pk)
+        got = d_packed.cpu().numpy()
+        assert got[: len(h_pk)].tobytes() == h_pk.tobytes() and np.all(got[len(h_pk):] == -3.0)
+        assert np.all(h_pk[:, 2] == 0.0)
+        assert np.array_equal(d_sa.cpu().numpy(), h_st.astype(np.int64))
+        assert np.array_equal(d_na.cpu().numpy(), h_np.astype(np.int32))
+        assert d_stat.cpu().numpy().tolist() == h_status.astype(np.int32).tolist()
+        assert bool(h_status.any()) == (slot < total)
+
+
 def test_c5_exchange_transform_fused_message_single_rank_rccl(oracle):
     """arena -> META -> RCCL all-gather -> unpack -> transform -> fused message, against the same
     chain without the exchange and against the oracle clouds."""
@@ -185,10 +238,23 @@ def test_chunked_overlapped_exchange_equals_plain_launch():
             torch.cuda.synchronize()
             Bc = ex.Bc
             for c in range(chunks):
-                meta = ex.recv_meta[c, 0].cpu()
-                pk, st, npx, status = sh.unpack_gathered(ex.recv_pts[c, 0].cpu().view(-1, 4), meta, ex.slot,
-                                                         1, Bc)
-                assert int(status.sum()) == 0
+                # the gathered slots hold 12-byte points; the device unpack puts z = 0 back, and the
+                # host entry point (same layout source) must agree with it
+                d_pk = torch.zeros(ex.slot, 4, dtype=torch.float32, device=dev)
+                d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
+                d_sa = torch.zeros(1, Bc, dtype=torch.int64, device=dev)
+                d_na = torch.zeros(1, Bc, dtype=torch.int32, device=dev)
+                d_stt = torch.zeros(1, dtype=torch.int32, device=dev)
+                ex.unpack(c, d_pk.data_ptr(), d_tot.data_ptr(), d_sa.data_ptr(), d_na.data_ptr(),
+                          d_stt.data_ptr())
+                gpu.synchronize()
+                h_pk, h_st, h_np, h_status = abi.unpack_gathered_host(
+                    ex.recv_pts[c].cpu().numpy(), ex.slot, ex.recv_meta[c].cpu().numpy().view(np.uint32), 1, Bc)
+                assert int(d_tot.item()) == len(h_pk) and int(d_stt.item()) == 0 == int(h_status.sum())
+                assert d_pk.cpu().numpy()[: len(h_pk)].tobytes() == h_pk.tobytes()
+                assert np.array_equal(d_sa.cpu().numpy(), h_st.astype(np.int64))
+                assert np.array_equal(d_na.cpu().numpy(), h_np.astype(np.int32))
+                pk, st, npx = torch.from_numpy(h_pk), h_st.astype(np.int64), h_np.astype(np.int64)
                 t = _arena(gpu, torch, dev, batch[c * Bc: (c + 1) * Bc], p, Bc * out_stride)
                 gpu.synchronize()
                 ref_a, ref_s, ref_n = t["arena"].cpu().numpy(), t["start"].cpu().numpy(), t["npts"].cpu().numpy()
