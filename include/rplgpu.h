@@ -262,6 +262,16 @@ int32_t rplgpu_decode_stream(rplgpu_handle_t h, uint8_t ans_type, uint32_t sampl
 void rplgpu_fill_meta(const rplgpu_params_t *p, uint32_t count, double scan_duration,
                       rplgpu_scan_meta_t *meta);
 
+/* Optional second output of the voxel grid (E4): the CELL of every output point.  While a buffer is
+ * set, every launch of the voxel path (rplgpu_cloud_batch_dev / rplgpu_cloud_arena_dev /
+ * rplgpu_cloud_fused_voxel_dev with voxel_enable) also writes one 32-bit word per output point,
+ * at the point's own index in the output buffer (per-scan region or arena):
+ *     (iy + 32768) << 16 | (ix + 32768),   (ix, iy) = (floor(x / leaf), floor(y / leaf)) of SURVEY 8(a-ext) E4
+ * i.e. the key the points of a scan are ordered by.  d_cell_keys needs as many words as the
+ * output buffer has points; NULL switches the output off (the default).  The buffer is the
+ * caller's and must stay valid until the launches that use it have completed. */
+int32_t rplgpu_set_cell_key_output(rplgpu_handle_t h, uint32_t *d_cell_keys);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,7 @@ ABI_SYMBOLS = [
     "rplgpu_laserscan_to_cloud_batch_dev",
     "rplgpu_laserscan_to_cloud",
     "rplgpu_cloud_fused_voxel_dev",
+    "rplgpu_set_cell_key_output",
     # include/rplgpu_comm.h
     "rplgpu_comm_unique_id",
     "rplgpu_comm_init",
@@ -259,6 +260,7 @@ def load_library() -> C.CDLL:
                                               C.POINTER(u32)]
     lib.rplgpu_cloud_fused_voxel_dev.argtypes = [vp, vp, u32, vp, u32, u32, C.POINTER(Params), vp, vp, vp,
                                                  u64, vp, vp, vp, vp]
+    lib.rplgpu_set_cell_key_output.argtypes = [vp, vp]
     lib.rplgpu_comm_unique_id.argtypes = [vp]
     lib.rplgpu_comm_init.argtypes = [vp, i32, i32, vp]
     lib.rplgpu_comm_destroy.argtypes = [vp]
@@ -502,6 +504,10 @@ class RplGpu:
         self._check(self._lib.rplgpu_cloud_fused_voxel_dev(
             self._h, d_nodes, n_stride, d_n_per_scan, B, group, C.byref(params), d_motion, d_pose2d,
             d_arena, arena_capacity, d_cursor, d_group_start, d_n_points, d_status))
+
+    def set_cell_key_output(self, d_cell_keys: int = 0):
+        """Optional voxel output: one u32 per output point, (iy + 32768) << 16 | (ix + 32768)."""
+        self._check(self._lib.rplgpu_set_cell_key_output(self._h, d_cell_keys or None))
 
     # -- multi-GPU exchange (include/rplgpu_comm.h) ------------------------------------------
     @staticmethod

@@ -62,6 +62,8 @@ struct KParams {
   uint32_t d_span;
   int32_t cell_range_safe;  // 1: host proved |cell index| < 32767 for every kept sample
   unsigned long long *dbg;  // optional per-block phase cycle counters (developer aid), or null
+  uint32_t *cell_keys;      // optional: one word per output cell, (iy + 32768) << 16 | (ix + 32768), at
+                            // the cell's index in the output buffer (rplgpu_set_cell_key_output)
   int32_t fast_div;   // 1: the mul+2*FMA divides by 4000 and by leaf were validated on this
                       //    device to be bit-identical to the IEEE divide (see k_validate_div)
 };

@@ -403,7 +403,8 @@ template <bool DBG>
 __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
                                                  float4 *__restrict__ out, uint32_t out_stride,
                                                  uint32_t b, uint32_t *ncell_out, int mode,
-                                                 const VoxelArena &arena, bool normalised) {
+                                                 const VoxelArena &arena, bool normalised,
+                                                 const float4 *out_buffer) {
   PhaseClock<DBG> pc;
   pc.start();
   auto flush_dbg = [&]() {
@@ -413,6 +414,8 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
     }
   };
   uint32_t *const rowstart = L.rows, *const rowfill = L.rows + kRowCap;
+  // optional cell-key output: the word of a cell sits at the cell's own index in the output buffer
+  uint32_t *cell_keys = p.cell_keys ? p.cell_keys + (out - out_buffer) : nullptr;
   const int vbias = p.vox_bias;
   const uint32_t nrec = L.misc[0];
   if (DBG && p.dbg && threadIdx.x == 0) pc.acc[7] += (unsigned long long)nrec << 40;
@@ -596,6 +599,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
       __syncthreads();
       const unsigned long long at = ((unsigned long long)L.tmp[29] << 32) | L.tmp[28];
       out = arena.base + at;
+      if (cell_keys) cell_keys = p.cell_keys + at;
       nemit = at >= arena.capacity ? 0u : (uint32_t)min((unsigned long long)ncell, arena.capacity - at);
     } else if (mode == kEmitCountOnly) {
       nemit = 0u;  // several bands: first learn the total, the cells are written in a second go
@@ -643,6 +647,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
       qi = fma(fma(-qi, dc, si), rc, qi);
       out[out_base + c] = make_float4((float)(qx * inv_scale), (float)(qy * inv_scale), 0.0f,
                                       (float)qi);
+      if (cell_keys) cell_keys[out_base + c] = key;  // (block-uniform pointer, usually null)
     }
   }
   __syncthreads();
@@ -964,7 +969,8 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     } else if (emit_mode != kEmitLegacy) {
       out_limit = 0xFFFFFFFFu;  // (first band: bounded inside, at the reservation)
     }
-    if (voxel_reduce<DBG>(L, p, out, out_limit, b, &ncell, emit_mode, arena, from_store)) {
+    if (voxel_reduce<DBG>(L, p, out, out_limit, b, &ncell, emit_mode, arena, from_store,
+                          arena.base ? arena.base : xyzi)) {
       if (!from_store) {  // the LDS queue spans too many rows: cut bands from the record store
         for (uint32_t i = threadIdx.x; i < n_all; i += kVB) G[i] = L.rec[i];
         from_store = true;

@@ -53,6 +53,7 @@ struct rplgpu_ctx {
   bool leaf_ok = false;
   bool idx_checked = false, idx_ok = false;  // Mode A bin-index divide, see k_validate_idx
   unsigned long long *dbg = nullptr;  // developer aid: per-block phase cycle counters
+  uint32_t *cell_keys = nullptr;      // optional cell-key output of the voxel kernel (rplgpu_set_cell_key_output)
   uint32_t n_cu = 0;                  // compute units of `device`
   void *d_vstore = nullptr;           // k_cloud_voxel record stores (one per resident workgroup)
   uint32_t vstore_wgs = 0;
@@ -137,6 +138,7 @@ rpl::KParams to_kparams(const rplgpu_params_t &p) {
   k.inv_leaf = 1.0f;
   k.fast_div = 0;
   k.dbg = nullptr;
+  k.cell_keys = nullptr;
   k.d_lo = 1u;  // :584 alone: dist_mm_q2 != 0
   k.d_span = 0xFFFFFFFEu;
   k.cell_range_safe = 0;
@@ -557,6 +559,13 @@ int32_t rplgpu_set_stream(rplgpu_handle_t h, void *hip_stream) {
   return RPLGPU_OK;
 }
 
+int32_t rplgpu_set_cell_key_output(rplgpu_handle_t h, uint32_t *d_cell_keys) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  if (d_cell_keys && !device_readable(h, d_cell_keys, "d_cell_keys")) return RPLGPU_ERR_INVALID_ARG;
+  h->cell_keys = d_cell_keys;
+  return RPLGPU_OK;
+}
+
 // Developer aid (not part of rplgpu.h): device buffer of 2*B u64 receiving, per scan, the
 // shader cycles k_cloud_voxel spent in its streaming and ranking phases.  0 = fast divides
 // rejected, 1 = accepted, via rplgpu_debug_fast_div.
@@ -626,6 +635,7 @@ static int32_t prepare_cloud(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, ui
     kp.fast_div = (h->div4000_ok && h->leaf_ok) ? 1 : 0;
   }
   kp.dbg = h->dbg;
+  kp.cell_keys = h->cell_keys;
   *mask_out = nullptr;
   if (p->ror_enable) {  // E5 before E4: per-sample keep bits, then the cloud kernels apply them
     RPL_HIP(h, rpl::launch_ror_mask(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,

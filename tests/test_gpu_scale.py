@@ -35,17 +35,24 @@ def _run_arena(gpu, batch, p, cap_per_scan):
     d_start = torch.zeros(B, dtype=torch.int64, device=dev)
     d_np = torch.zeros(B, dtype=torch.int32, device=dev)
     d_st = torch.zeros(B, dtype=torch.int32, device=dev)
-    gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_arena.data_ptr(), cap,
-                        d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
-    gpu.synchronize()
+    # the optional cell-key output (include/rplgpu.h): one word per output point, same index
+    d_keys = torch.zeros(cap, dtype=torch.int32, device=dev)
+    gpu.set_cell_key_output(d_keys.data_ptr())
+    try:
+        gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_arena.data_ptr(), cap,
+                            d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+        gpu.synchronize()
+    finally:
+        gpu.set_cell_key_output(0)
     total = int(d_cur.item())
     return (d_arena[:total].cpu().numpy(), d_start.cpu().numpy(),
-            d_np.cpu().numpy().astype(np.int64), d_st.cpu().numpy(), total)
+            d_np.cpu().numpy().astype(np.int64), d_st.cpu().numpy(), total,
+            d_keys[:total].cpu().numpy().view(np.uint32))
 
 
 def _check_batch(gpu, oracle, batch, p, every, cap_per_scan):
     B, n = batch.shape
-    arena, start, npts, st, total = _run_arena(gpu, batch, p, cap_per_scan)
+    arena, start, npts, st, total, keys = _run_arena(gpu, batch, p, cap_per_scan)
     assert int(st.max()) == 0, "status_bits"
     assert total == int(npts.sum())
     # the reservations tile [0, total) without gaps or overlaps
@@ -59,7 +66,6 @@ def _check_batch(gpu, oracle, batch, p, every, cap_per_scan):
     want_total = int(oracle.lib.orc_batch_cloud(nodes.ctypes.data, n, lens.ctypes.data, B,
                                                 C.byref(op), os.cpu_count() or 1))
     assert total == want_total
-    leaf = np.float32(p.voxel_leaf)
     worst = 0.0
     for b in range(0, B, every):
         want, wcells, wcounts = oracle.cloud_pipeline(batch[b], op)
@@ -72,12 +78,12 @@ def _check_batch(gpu, oracle, batch, p, every, cap_per_scan):
         assert err <= XYZ_TOL, (b, err)
         assert np.all(got[:, 2] == 0.0)
         assert got[:, 3].tobytes() == want[:, 3].tobytes(), b  # mean intensity: bit-exact
-        # cell list: re-derived from the centroids it equals the oracle's, except where a
-        # centroid sits within the tolerance of a cell face
-        gx = np.floor(got[:, 0] / leaf).astype(np.int32)
-        gy = np.floor(got[:, 1] / leaf).astype(np.int32)
-        bad = (gx != wcells[:, 0]) | (gy != wcells[:, 1])
-        assert bad.mean() < 0.01, b  # (a centroid may round onto a cell face; err above bounds it)
+        # cell indices: bit-exact.  The kernel's optional cell-key output carries the (iy, ix) every
+        # output point was reduced under; it must be the oracle's cell list, in the oracle's order
+        k = keys[start[b]: start[b] + npts[b]]
+        wkey = ((wcells[:, 1].astype(np.int64) + 32768) << 16 | (wcells[:, 0].astype(np.int64) + 32768))
+        assert np.array_equal(k.astype(np.int64), wkey), b
+        assert np.all(np.diff(k.astype(np.int64)) > 0), b  # strictly ascending (iy, ix)
     return total, worst
 
 
