@@ -67,7 +67,31 @@ def gen_cases():
     cases["full_32768_unsorted"] = synth.make_scan(11, 5, 32768, kind="uniform", jitter=2000,
                                                    rotate=True, invalid_p=0.3)
     cases.update(random_scans())
+    cases.update(duplicate_angle_scans())
     return cases
+
+
+def duplicate_angle_scans():
+    """Large scans whose angle words repeat — what real scans look like: ascendScanData's fill pass
+    (src/sdk/src/sl_lidar_driver.cpp:171-178) gives every invalid node an interpolated angle that
+    often lands on a neighbour's word, and a fast-spinning sensor repeats words by itself.  Inside a
+    run of equal angles the reference's order is its unstable std::sort's; the golden digests
+    (tests/golden/large_golden.npz) therefore pin the MULTISET of every run — tests/canon.py —
+    for ascendScanData and Mode B, the ranges for Mode A, and Mode A's intensities wherever no
+    two tied samples differ in intensity.  These cases make that contract a test."""
+    out = {}
+    rng = np.random.default_rng(20260924)
+    a = synth.make_scan(13, 0, 8192, invalid_p=0.15)
+    a["angle_z_q14"] = (np.sort(rng.integers(0, 2048, 8192)) * 32).astype(np.uint16)  # ~4 per word
+    out["dup_angles_8192"] = a
+    b = synth.make_scan(13, 1, 32000, invalid_p=0.25, jitter=3)
+    b["angle_z_q14"] = (b["angle_z_q14"].astype(np.uint32) & 0xFFF0).astype(np.uint16)  # runs of ~8
+    out["dup_angles_32000"] = b
+    c = synth.make_scan(13, 2, 12000, kind="uniform", invalid_p=0.3, rotate=True)
+    c["angle_z_q14"] = rng.integers(0, 3000, 12000).astype(np.uint16) * 21  # unsorted, heavy ties
+    c["quality"] = (rng.integers(0, 4, 12000) * 64).astype(np.uint8)      # and few intensity values
+    out["dup_angles_unsorted_12000"] = c
+    return out
 
 
 def random_scans():
