@@ -1,0 +1,148 @@
+"""The genuine reference node, PATCHED with integration/rplidar_node_gpu.patch, against the same
+node unpatched (the drop-in claim as a test).
+
+oracle/_ref/libnoderef.so      = /root/reference's rplidar_node.cpp as it is        (CPU loop)
+oracle/_ref/libnoderef_gpu.so  = the same file with the patch applied, linked with librplgpu.so:
+                                 RPlidarNode::publish_scan hands the scan to the C ABI
+                                 (rplgpu_host::ScanPath::fill_laser_scan) and publishes what it fills
+Both are compiled by `make -C oracle ref` where the reference tree exists and travel to the GPU
+box as built libraries.  Every {driver kind, inverted, scan_processing} combination, the Dummy
+driver's own scans and the golden cases: what the two nodes publish must be the same bytes —
+modulo the order inside equal-angle runs, which is the reference's unstable std::sort's
+(tests/canon.py; Mode A ranges are tie-free, Mode A intensities are compared wherever no two tied
+samples differ in intensity).  A scan above the configured capacity makes the device path fail:
+the patched node must then publish through its untouched CPU loop, bit for bit."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from tests import canon, oracle_lib
+from tests.cases import CASES
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+GPU_LIB = ROOT / "oracle" / "_ref" / "libnoderef_gpu.so"
+
+
+class PatchedNode:
+    def __init__(self):
+        self.lib = C.CDLL(str(GPU_LIB))
+        self.lib.refgpu_last_error.restype = C.c_char_p
+        self.lib.refgpu_publish_scan.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                                 C.c_float, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+
+    def open(self, use_gpu=True):
+        return self.lib.refgpu_open(int(use_gpu))
+
+    def close(self):
+        self.lib.refgpu_close()
+
+    def last_error(self):
+        return self.lib.refgpu_last_error().decode()
+
+    def publish_scan(self, nodes, *, driver_kind, inverted, scan_processing, range_max=12.0,
+                     scan_duration=0.1):
+        nodes = np.ascontiguousarray(nodes)
+        n = len(nodes)
+        r = np.full(max(n, 1), np.nan, np.float32)
+        i = np.full(max(n, 1), np.nan, np.float32)
+        m = oracle_lib.OMeta()
+        rc = self.lib.refgpu_publish_scan(nodes.ctypes.data, n, driver_kind, inverted, scan_processing,
+                                          range_max, scan_duration, r.ctypes.data, i.ctypes.data,
+                                          C.byref(m))
+        assert rc >= 0
+        return r[: m.count], i[: m.count], m
+
+
+@pytest.fixture(scope="module")
+def nodes_pair(reflibs):
+    if reflibs is None or not GPU_LIB.exists():
+        pytest.skip("oracle/_ref/libnoderef(.so|_gpu.so) not built (make -C oracle ref needs /root/reference)")
+    pn = PatchedNode()
+    assert pn.open(True) == 1, pn.last_error()
+    yield reflibs, pn
+    pn.close()
+
+
+def _same_publication(name, nodes, plain, patched, kind, inv, sp):
+    r0, i0, m0 = plain.publish_scan(nodes, driver_kind=kind, inverted=inv, scan_processing=sp,
+                                    range_max=40.0, scan_duration=0.125)
+    r1, i1, m1 = patched.publish_scan(nodes, driver_kind=kind, inverted=inv, scan_processing=sp,
+                                      range_max=40.0, scan_duration=0.125)
+    tag = f"{name} k{kind} i{inv} s{sp}"
+    assert bytes(m1) == bytes(m0), tag  # angle_min .. range_max, count, published
+    if not m0.published:
+        return
+    if sp:
+        assert r1.tobytes() == r0.tobytes(), tag
+        if not canon.has_intensity_tie(nodes, int(kind == 2)):
+            assert i1.tobytes() == i0.tobytes(), tag
+    else:
+        c0, c1 = canon.canon_mode_b(nodes, r0, i0, inv), canon.canon_mode_b(nodes, r1, i1, inv)
+        assert c1[0].tobytes() == c0[0].tobytes() and c1[1].tobytes() == c0[1].tobytes(), tag
+        if canon.valid_angles_unique(nodes):
+            assert r1.tobytes() == r0.tobytes() and i1.tobytes() == i0.tobytes(), tag
+
+
+def test_patched_node_publishes_what_the_unpatched_node_publishes(nodes_pair):
+    plain, patched = nodes_pair
+    cases = {k: v for k, v in CASES.items() if len(v) <= 8192}
+    assert len(cases) >= 20
+    for name, nodes in cases.items():
+        for kind in (0, 1, 2):
+            for inv in (0, 1):
+                for sp in (0, 1):
+                    _same_publication(name, nodes, plain, patched, kind, inv, sp)
+        assert patched.last_error() == "", name  # every scan went through the device path
+
+
+def test_patched_node_dummy_driver_scans(nodes_pair):
+    """Config 1: the reference's own synthetic source, three consecutive scans."""
+    plain, patched = nodes_pair
+    g = np.load(ROOT / "tests" / "golden" / "dummy_golden.npz")
+    for k in range(3):
+        scan = g[f"scan{k}"]
+        for inv in (0, 1):
+            for sp in (0, 1):
+                _same_publication(f"dummy{k}", scan, plain, patched, 0, inv, sp)
+                r, i, m = patched.publish_scan(scan, driver_kind=0, inverted=inv, scan_processing=sp,
+                                               range_max=40.0, scan_duration=0.1)
+                tag = f"scan{k}__i{inv}_s{sp}"
+                assert r.tobytes() == g[tag + "__ranges"].tobytes()  # and the committed golden bytes
+                assert i.tobytes() == g[tag + "__intens"].tobytes()
+    assert patched.last_error() == ""
+
+
+def test_device_error_falls_back_to_the_cpu_loop(nodes_pair):
+    """A scan above the handle's capacity (8192, the SDK's cap) is refused by the device path; the
+    patched node then runs the reference's own loop: identical bytes, identical order."""
+    plain, patched = nodes_pair
+    nodes = CASES["c2_32000"]
+    for kind, inv, sp in ((1, 0, 1), (2, 1, 0), (0, 0, 0)):
+        r0, i0, m0 = plain.publish_scan(nodes, driver_kind=kind, inverted=inv, scan_processing=sp,
+                                        range_max=40.0, scan_duration=0.125)
+        r1, i1, m1 = patched.publish_scan(nodes, driver_kind=kind, inverted=inv, scan_processing=sp,
+                                          range_max=40.0, scan_duration=0.125)
+        assert "capacity" in patched.last_error()
+        assert bytes(m1) == bytes(m0) and r1.tobytes() == r0.tobytes() and i1.tobytes() == i0.tobytes()
+    # ... and the device path keeps working afterwards
+    small = CASES["ring_8192"]
+    _same_publication("after_error", small, plain, patched, 1, 0, 1)
+
+
+def test_unconfigured_patched_node_is_the_reference(reflibs):
+    """use_gpu = false (the default): the patched node never touches the device."""
+    if reflibs is None or not GPU_LIB.exists():
+        pytest.skip("oracle/_ref not built")
+    pn = PatchedNode()
+    assert pn.open(False) == 0
+    try:
+        for name in ("dup_angles", "lead_trail_runs", "kat2"):
+            nodes = CASES[name]
+            r0, i0, m0 = reflibs.publish_scan(nodes, driver_kind=1, inverted=0, scan_processing=1, range_max=40.0)
+            r1, i1, m1 = pn.publish_scan(nodes, driver_kind=1, inverted=0, scan_processing=1, range_max=40.0)
+            assert bytes(m1) == bytes(m0) and r1.tobytes() == r0.tobytes() and i1.tobytes() == i0.tobytes()
+    finally:
+        pn.close()
