@@ -177,6 +177,18 @@ __device__ __forceinline__ uint32_t deg_to_q14(float v) {  // setAngle, :107-110
 // sorting; SORT = true runs after it, returns at once for unflagged scans and does the whole
 // job including the sort for the others.  Keeping the sort (32 keys per thread in registers)
 // out of the first kernel keeps its register allocation spill-free.
+// (Round 3: the SORT = false instance is no longer launched — k_ascend_stream below does its job —
+// and the SORT = true instance is a persistent grid over the LIST of flagged scans that
+// k_ascend_stream appends to: need_sort[0] = how many, need_sort[1 ..] = which.  Launching one
+// 1024-thread, 128 KiB workgroup per scan only to find its flag clear cost more than the
+// streaming kernel itself.)
+template <bool SORT>
+__device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes, uint32_t n_stride,
+                                           const uint32_t *__restrict__ n_per_scan,
+                                           uint32_t *__restrict__ status,
+                                           uint32_t *__restrict__ need_sort, uint32_t *s_keys,
+                                           uint32_t *s_misc, SortLds &s_sort);
+
 template <bool SORT>
 __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, uint32_t n_stride,
                                                    const uint32_t *__restrict__ n_per_scan,
@@ -185,8 +197,24 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
   __shared__ uint32_t s_keys[kMaxN];
   __shared__ uint32_t s_misc[8];
   __shared__ SortLds s_sort;
-  const uint32_t b = blockIdx.x;
-  if (SORT && need_sort[b] == 0u) return;
+  if (SORT) {
+    const uint32_t count = need_sort[0];
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+      ascend_one<SORT>(need_sort[1u + k], nodes, n_stride, n_per_scan, status, need_sort, s_keys,
+                       s_misc, s_sort);
+      __syncthreads();  // LDS is reused by the next scan
+    }
+  } else {
+    ascend_one<SORT>(blockIdx.x, nodes, n_stride, n_per_scan, status, need_sort, s_keys, s_misc, s_sort);
+  }
+}
+
+template <bool SORT>
+__device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes, uint32_t n_stride,
+                                           const uint32_t *__restrict__ n_per_scan,
+                                           uint32_t *__restrict__ status,
+                                           uint32_t *__restrict__ need_sort, uint32_t *s_keys,
+                                           uint32_t *s_misc, SortLds &s_sort) {
   const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   uint2 *scan = nodes + (size_t)b * n_stride;
 
@@ -289,6 +317,124 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
       if (pos != i || ((changed >> j) & 1u)) scan[pos] = v[j];
     }
   }
+}
+
+// ------------------------------------------------------------------------------
+// k_ascend_stream — the usual case of ascendScanData as a STREAMING kernel (round 3).
+// k_ascend<false> above keeps a whole scan in registers and its keys in 128 KiB of LDS: one
+// workgroup per compute unit, and the load of a scan, the work on it and its stores never
+// overlap (0.32 ms per 4096 x 32 000 samples, 41 % of the roofline).  What the usual case needs is
+// far less: the first valid sample, the head chain (:135-148) when that is not sample 0, and
+// then one elementwise pass — the interpolated angle of an invalid sample i depends on (front, i,
+// inc) only (:171-178) — that also checks that the angle words come out non-descending.  So:
+// 256-thread workgroups (eight per compute unit), 16-byte loads four deep, 8-byte stores of the
+// changed samples only, neighbours compared in registers / by DPP / through 2 words of LDS per
+// 128-sample chunk.  A scan that is not ascending is flagged for k_ascend<true> exactly as before;
+// that kernel recomputes every filled angle from the same (front, i, inc), so the fills this
+// kernel already wrote in place do not disturb it.
+// ------------------------------------------------------------------------------
+constexpr int kAscT = 256;
+typedef uint32_t asc_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nodes, uint32_t n_stride,
+                                                         const uint32_t *__restrict__ n_per_scan,
+                                                         uint32_t *__restrict__ status,
+                                                         uint32_t *__restrict__ need_sort) {
+  __shared__ uint32_t s_misc[4];                  // 0 first valid, 1 front word, 2 not ascending
+  __shared__ uint32_t s_edge[2 * (kMaxN / 128)];  // first / last angle word of every 128-sample chunk
+  const uint32_t b = blockIdx.x;
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)min(n_per_scan[b], min(n_stride, kMaxN)));  // never past the slot
+  uint2 *scan = nodes + (size_t)b * n_stride;
+  // bounds-checked 16-byte loads (dword alignment suffices; beyond the scan: zeros = invalid)
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
+  auto load_pair = [&](uint32_t pair) -> uint4 {
+    const asc_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(pair * 16u), 0, 0);
+    return make_uint4(t.x, t.y, t.z, t.w);
+  };
+  const uint32_t npairs = (n + 1u) >> 1;
+  if (threadIdx.x == 0) { s_misc[0] = 0xFFFFFFFFu; s_misc[2] = 0u; }
+  __syncthreads();
+  // ---- first valid sample (block-uniform loop; found in the first round for any real scan)
+  for (uint32_t base = 0; base < npairs; base += kAscT) {
+    const uint4 w = load_pair(base + threadIdx.x);
+    const uint32_t i = 2u * (base + threadIdx.x);
+    uint32_t cand = 0xFFFFFFFFu;
+    if (i + 1u < n && nd_dist(make_uint2(w.z, w.w)) != 0u) cand = i + 1u;
+    if (i < n && nd_dist(make_uint2(w.x, w.y)) != 0u) cand = i;
+    const uint64_t any = __builtin_amdgcn_ballot_w64(cand != 0xFFFFFFFFu);
+    if (any && lane_id() == (uint32_t)__builtin_ctzll(any)) atomicMin(&s_misc[0], cand);
+    __syncthreads();
+    if (s_misc[0] != 0xFFFFFFFFu) break;
+  }
+  const uint32_t first = s_misc[0];
+  if (first == 0xFFFFFFFFu) {  // :151 all invalid -> SL_RESULT_OPERATION_FAIL, buffer untouched
+    if (threadIdx.x == 0 && status) status[b] = RPLGPU_SCAN_ALL_INVALID;
+    return;
+  }
+  const float inc = 360.f / (float)n;  // :131
+  if (threadIdx.x == 0) {
+    if (status) status[b] = 0u;
+    // head chain (:135-148), see k_ascend: only sample 0's value survives the fill pass
+    uint32_t q = nd_q14(scan[first]);
+    for (uint32_t s = first; s > 0; --s) {
+      float e = q14_to_deg(q) - inc;
+      if (e < 0.0f) e = 0.0f;
+      q = deg_to_q14(e);
+    }
+    s_misc[1] = q;
+  }
+  __syncthreads();
+  const uint32_t front_q = s_misc[1];
+  const float front = q14_to_deg(front_q);  // :171
+  // ---- the fill pass (:171-178) + "is it ascending?" (:181 would not move anything then)
+  auto new_angle = [&](uint2 v, uint32_t i) -> uint32_t {
+    uint32_t nq = nd_q14(v);
+    if (nd_dist(v) == 0u) {
+      if (i == 0u) {
+        nq = front_q;
+      } else {  // :172-178
+        float e = front + (float)i * inc;
+        if (e > 360.0f) e -= 360.0f;
+        nq = deg_to_q14(e);
+      }
+    }
+    return nq;
+  };
+  uint32_t bad = 0u;
+  constexpr int kDeep = 4;  // loads in flight per thread
+  for (uint32_t base = 0; base < npairs; base += kDeep * kAscT) {
+    uint4 w[kDeep];
+#pragma unroll
+    for (int k = 0; k < kDeep; ++k) w[k] = load_pair(base + (uint32_t)k * kAscT + threadIdx.x);
+#pragma unroll
+    for (int k = 0; k < kDeep; ++k) {
+      const uint32_t pair = base + (uint32_t)k * kAscT + threadIdx.x, i = 2u * pair;
+      const uint2 a = make_uint2(w[k].x, w[k].y), c = make_uint2(w[k].z, w[k].w);
+      // (samples beyond the scan compare as "larger than any angle word": never out of order)
+      const uint32_t qa = i < n ? new_angle(a, i) : 0x10000u;
+      const uint32_t qc = i + 1u < n ? new_angle(c, i + 1u) : 0x10000u;
+      if (i < n && qa != nd_q14(a)) scan[i] = make_uint2((a.x & 0xFFFF0000u) | qa, a.y);
+      if (i + 1u < n && qc != nd_q14(c)) scan[i + 1u] = make_uint2((c.x & 0xFFFF0000u) | qc, c.y);
+      // the sample before this pair: the lane to the left (lane 0: the chunk before, via LDS)
+      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qc, 0x138, 0xF, 0xF, false);
+      bad |= (qa > qc) | (prev > qa);
+      const uint32_t chunk = pair >> 6;  // wave-uniform: 64 pairs = 128 samples
+      if (pair < npairs) {
+        if (lane_id() == 0u) s_edge[2u * chunk] = qa;
+        if (lane_id() == 63u) s_edge[2u * chunk + 1u] = qc;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t nchunks = (npairs + 63u) >> 6;
+  for (uint32_t c = threadIdx.x; c + 1u < nchunks; c += kAscT)
+    bad |= s_edge[2u * c + 1u] > s_edge[2u * c + 2u];
+  if (__builtin_amdgcn_ballot_w64(bad != 0u) && lane_id() == 0u) atomicOr(&s_misc[2], 1u);
+  __syncthreads();
+  // not ascending: queue the scan for the sorting kernel (need_sort[0] = count, then the list)
+  if (threadIdx.x == 0 && s_misc[2]) need_sort[1u + atomicAdd(&need_sort[0], 1u)] = b;
 }
 
 // ------------------------------------------------------------------------------
@@ -471,10 +617,11 @@ __global__ __launch_bounds__(256) void k_pack(const float4 *__restrict__ xyzi, u
 hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
                          uint32_t B, uint32_t *status, uint32_t *need_sort) {
   if (B == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_ascend<false>, dim3(B), dim3(kBlock), 0, s, (uint2 *)nodes, n_stride,
-                     n_per_scan, status, need_sort);
-  hipLaunchKernelGGL(k_ascend<true>, dim3(B), dim3(kBlock), 0, s, (uint2 *)nodes, n_stride,
-                     n_per_scan, status, need_sort);
+  if (hipError_t e = hipMemsetAsync(need_sort, 0, 4, s); e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_ascend_stream, dim3(B), dim3(kAscT), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
+                     status, need_sort);
+  hipLaunchKernelGGL(k_ascend<true>, dim3(std::min<uint32_t>(B, 256u)), dim3(kBlock), 0, s,
+                     (uint2 *)nodes, n_stride, n_per_scan, status, need_sort);
   return hipGetLastError();
 }
 

@@ -14,7 +14,7 @@ struct Prefix;
 
 namespace rpl {
 
-// `need_sort`: B words of scratch (which scans the second, sorting kernel has to redo)
+// `need_sort`: B + 1 words of scratch (how many / which scans the second, sorting kernel has to redo)
 hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
                          uint32_t B, uint32_t *status, uint32_t *need_sort);
 // publish_scan Mode A (rpl_laserscan.hip); `fast`: the mul+2*FMA divides were validated

@@ -44,7 +44,7 @@ struct rplgpu_ctx {
   std::vector<Pinned> pinned;      // buffers handed out by rplgpu_host_alloc (device-addressable)
   unsigned char *d_nodes = nullptr, *d_out = nullptr;
   uint32_t *d_rormask = nullptr;  // E5 keep bits, max_b scans x kMaskStride words
-  uint32_t *d_need_sort = nullptr;  // ascend: scans the sorting kernel must redo (B words)
+  uint32_t *d_need_sort = nullptr;  // ascend: [0] how many scans the sorting kernel must redo, [1..] which (B + 1 words)
   uint32_t need_sort_cap = 0;
   uint32_t *d_small = nullptr;  // [0]=n, [1]=count, [2]=status, [8]=divide-validation mismatches
   // fast-divide validation cache (see k_validate_div)
@@ -496,7 +496,7 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
       hipMalloc((void **)&c->d_small, 128) != hipSuccess ||
       // per-call scratch of the batch entry points, sized once for max_batch (no allocation on
       // the per-call paths): ascend's "needs the sorting kernel" list and the E5 keep bits
-      hipMalloc((void **)&c->d_need_sort, (size_t)c->max_b * 4u) != hipSuccess ||
+      hipMalloc((void **)&c->d_need_sort, ((size_t)c->max_b + 1u) * 4u) != hipSuccess ||
       hipMalloc((void **)&c->d_rormask, (size_t)c->max_b * kMaskStride * 4u) != hipSuccess) {
     c->err = "staging allocation failed";
     return fail(RPLGPU_ERR_HIP);
