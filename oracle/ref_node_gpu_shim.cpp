@@ -70,6 +70,10 @@ void refgpu_close(void) {
   if (g_node) g_node->gpu_path_.cleanup();
   g_node.reset();
 }
+/* ScanPath::set_min_samples: scans shorter than n are declined and take the node's CPU loop */
+void refgpu_set_min_samples(unsigned n) {
+  if (g_node) g_node->gpu_path_.set_min_samples(n);
+}
 int refgpu_ready(void) { return g_node && g_node->gpu_path_.ready() ? 1 : 0; }
 const char *refgpu_last_error(void) {
   if (g_node) g_err = g_node->gpu_path_.last_error();

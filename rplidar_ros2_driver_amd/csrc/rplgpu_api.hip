@@ -1005,7 +1005,11 @@ int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
   RPL_HIP(h, hipSetDevice(h->device));
   if (!device_readable(h, d_bytes, "d_bytes") || !device_readable(h, d_n_frames, "d_n_frames") ||
       (d_frame_off && !device_readable(h, d_frame_off, "d_frame_off")) ||
-      !device_readable(h, d_batch, "d_batch"))
+      !device_readable(h, d_batch, "d_batch") || !device_readable(h, d_n_per_scan, "d_n_per_scan") ||
+      !device_readable(h, d_n_scans, "d_n_scans") || !device_readable(h, d_status, "d_status") ||
+      (d_n_errors && !device_readable(h, d_n_errors, "d_n_errors")) ||
+      (d_state_in && !device_readable(h, d_state_in, "d_state_in")) ||
+      (d_state_out && !device_readable(h, d_state_out, "d_state_out")))
     return RPLGPU_ERR_INVALID_ARG;
   // scratch kept in the handle (grows when a larger call arrives, never shrinks): the decoded
   // node streams, the decoder's sync-node and reset lists, three counters per stream

@@ -121,6 +121,13 @@ class ScanPath {
     h_ = nullptr;
   }
   bool ready() const { return h_ != nullptr; }
+  // One scan per call pays a fixed ~21 us (launch + completion flag over PCIe) whatever its size;
+  // the reference's loop needs ~7 us for the 360 samples of an A1 and overtakes the device path
+  // below ~3000 samples.  Scans shorter than `n` are DECLINED:
+  // fill_laser_scan / fill_point_cloud2 return false with last_error() set, i.e. the caller's own
+  // CPU loop runs, exactly as after a device error.  0 (the default) declines nothing.
+  void set_min_samples(uint32_t n) { min_samples_ = n; }
+  uint32_t min_samples() const { return min_samples_; }
   const std::string &last_error() const { return last_error_; }
 
   // == sl::ILidarDriver::ascendScanData (src/sdk/include/sl_lidar_driver.h:477): in place,
@@ -145,6 +152,8 @@ class ScanPath {
                        double scan_duration, LaserScanT &scan_msg) {
     if (nodes.empty()) return false;  // :561-563
     if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
+    if (nodes.size() < min_samples_) return fail("scan below the configured minimum (CPU loop is faster)");
+    last_error_.clear();
     const rplgpu_params_t p = cfg.to_params();
     rplgpu_scan_meta_t meta;
     if (rplgpu_scan_to_laserscan(h_, as_nodes(nodes.data()), nodes.size(), &p, scan_duration,
@@ -175,6 +184,7 @@ class ScanPath {
                                   uint32_t nanosec, SerializedT &out) {
     if (nodes.empty()) return false;  // :561-563
     if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
+    if (nodes.size() < min_samples_) return fail("scan below the configured minimum (CPU loop is faster)");
     rplgpu_laserscan_layout_t L;
     if (rplgpu_msg_laserscan_layout(frame_id.size(), static_cast<uint32_t>(nodes.size()), &L))
       return fail("frame_id too long");
@@ -198,6 +208,7 @@ class ScanPath {
                                     SerializedT &out) {
     if (nodes.empty()) return false;
     if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
+    if (nodes.size() < min_samples_) return fail("scan below the configured minimum (CPU loop is faster)");
     rplgpu_cloud_layout_t L;
     if (rplgpu_msg_cloud_layout(frame_id.size(), static_cast<uint32_t>(nodes.size()), &L))
       return fail("frame_id too long");
@@ -260,6 +271,7 @@ class ScanPath {
                          PointCloud2T &cloud_msg) {
     if (nodes.empty()) return false;
     if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
+    if (nodes.size() < min_samples_) return fail("scan below the configured minimum (CPU loop is faster)");
     const rplgpu_params_t p = cfg.to_params();
     uint32_t n_points = 0, status = 0;
     const int32_t rc = rplgpu_scan_to_cloud(h_, as_nodes(nodes.data()), nodes.size(), &p,
@@ -302,6 +314,7 @@ class ScanPath {
   std::vector<rplgpu_node_t> dec_nodes_;
   std::vector<uint32_t> dec_resets_;
   std::string last_error_;
+  uint32_t min_samples_ = 0;
 };
 
 // == ScanDataHolder<T> as SlamtecLidarDriver drives it (src/sdk/src/sl_lidar_driver.cpp:236-360,

@@ -132,6 +132,23 @@ def test_device_error_falls_back_to_the_cpu_loop(nodes_pair):
     _same_publication("after_error", small, plain, patched, 1, 0, 1)
 
 
+def test_small_scans_can_be_left_to_the_cpu_loop(nodes_pair):
+    """ScanPath::set_min_samples (INTEGRATION.md 2c): below the break-even size the device path
+    declines and the node's own loop publishes — for an A1-sized scan that is the faster choice."""
+    plain, patched = nodes_pair
+    patched.lib.refgpu_set_min_samples(3000)
+    try:
+        g = np.load(ROOT / "tests" / "golden" / "dummy_golden.npz")
+        r0, i0, m0 = plain.publish_scan(g["scan0"], driver_kind=0, inverted=0, scan_processing=1, range_max=40.0)
+        r1, i1, m1 = patched.publish_scan(g["scan0"], driver_kind=0, inverted=0, scan_processing=1, range_max=40.0)
+        assert "minimum" in patched.last_error()
+        assert bytes(m1) == bytes(m0) and r1.tobytes() == r0.tobytes() and i1.tobytes() == i0.tobytes()
+        _same_publication("above_min", CASES["ring_8192"], plain, patched, 2, 1, 1)
+        assert patched.last_error() == ""
+    finally:
+        patched.lib.refgpu_set_min_samples(0)
+
+
 def test_unconfigured_patched_node_is_the_reference(reflibs):
     """use_gpu = false (the default): the patched node never touches the device."""
     if reflibs is None or not GPU_LIB.exists():
