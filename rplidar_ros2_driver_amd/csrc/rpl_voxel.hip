@@ -375,7 +375,12 @@ struct VoxelArena {
   unsigned long long capacity;   // points the arena holds
   unsigned long long *scan_start;
 };
-enum : int { kEmitLegacy = 0, kEmitArenaFirst = 1, kEmitCountOnly = 2, kEmitArenaKnown = 3 };
+// kEmitArenaTemp (round 3): a scan of several bands writes its cells to the workgroup's temporary
+// cell area (behind its record store) band after band and copies them into the arena once their
+// total is known — ONE pass over the bands.  (Rounds 1-2 went through the bands twice, counting
+// then writing: +70 % on every multi-band scan.)  kEmitCountOnly / kEmitArenaKnown remain for the
+// optional cell-key output, whose words must land at arena indices.
+enum : int { kEmitLegacy = 0, kEmitArenaFirst = 1, kEmitCountOnly = 2, kEmitArenaKnown = 3, kEmitArenaTemp = 4 };
 
 // Developer aid: phase cycle counters (tools/voxdbg.py); empty unless the kernel is a DBG build.
 template <bool DBG>
@@ -672,7 +677,7 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (threadIdx.x < 256) L.rcp[threadIdx.x] = T.rcp[threadIdx.x];  // (first barrier below publishes it)
   // this workgroup's record store (T.voxel_store_recs entries, voxel_store_need(): every sample
   // of the work item could end a run, plus the block markers)
-  uint4 *G = store + (size_t)blockIdx.x * T.voxel_store_recs;
+  uint4 *G = store + (size_t)blockIdx.x * 2u * T.voxel_store_recs;  // records, then the cell area
   // persistent workgroups, two per CU; the first scan is blockIdx.x, the next ones come from a
   // shared counter, so a workgroup that drew cheap scans simply takes more of them
   for (uint32_t b = blockIdx.x; b < B;) {
@@ -954,9 +959,18 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
       __syncthreads();
     };
+    auto leave_single_band_mode = [&]() {  // block-uniform
+      if (emit_mode != kEmitArenaFirst) return;
+      if (p.cell_keys) {
+        emit_mode = kEmitCountOnly;
+      } else {
+        emit_mode = kEmitArenaTemp;
+        out = reinterpret_cast<float4 *>(G + T.voxel_store_recs);  // the workgroup's cell area
+      }
+    };
     if (L.misc[2]) {
       bisect();
-      if (emit_mode == kEmitArenaFirst) emit_mode = kEmitCountOnly;
+      leave_single_band_mode();
       continue;
     }
 
@@ -966,6 +980,8 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (emit_mode == kEmitArenaKnown) {
       const unsigned long long room = arena_at >= arena.capacity ? 0ull : arena.capacity - arena_at;
       out_limit = (uint32_t)min(room, 0xFFFFFFFFull);
+    } else if (emit_mode == kEmitArenaTemp) {
+      out_limit = T.voxel_store_recs;  // (cells <= queue entries <= the area's size)
     } else if (emit_mode != kEmitLegacy) {
       out_limit = 0xFFFFFFFFu;  // (first band: bounded inside, at the reservation)
     }
@@ -977,7 +993,7 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         __syncthreads();
       }
       bisect();
-      if (emit_mode == kEmitArenaFirst) emit_mode = kEmitCountOnly;
+      leave_single_band_mode();
       continue;
     }
     if (emit_mode == kEmitArenaFirst)  // (the reservation made inside voxel_reduce)
@@ -1003,6 +1019,22 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       arena_at = ((unsigned long long)L.tmp[29] << 32) | L.tmp[28];
       out = arena.base + arena_at;
       emit_mode = kEmitArenaKnown;
+    }
+    if (emit_mode == kEmitArenaTemp && L.misc[3] == 0u) {
+      // every band is in the cell area: reserve the scan's place in the arena, copy
+      const uint32_t total = L.misc[7];
+      if (threadIdx.x == 0) {
+        const unsigned long long at = atomicAdd(arena.cursor, (unsigned long long)total);
+        L.tmp[28] = (uint32_t)at;
+        L.tmp[29] = (uint32_t)(at >> 32);
+      }
+      __syncthreads();  // (also: the cells written by all threads are visible workgroup-wide)
+      arena_at = ((unsigned long long)L.tmp[29] << 32) | L.tmp[28];
+      const unsigned long long room = arena_at >= arena.capacity ? 0ull : arena.capacity - arena_at;
+      const uint32_t ncopy = (uint32_t)min((unsigned long long)total, room);
+      const float4 *src = reinterpret_cast<const float4 *>(G + T.voxel_store_recs);
+      float4 *dst = arena.base + arena_at;
+      for (uint32_t i = threadIdx.x; i < ncopy; i += kVB) dst[i] = src[i];
     }
   }
   if (DBG && p.dbg && threadIdx.x == 0) {
@@ -1082,6 +1114,7 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   const uint32_t n_scans = B;
   B = (B + group - 1u) / group;  // work items
   if (!T.voxel_store || T.voxel_store_wgs == 0) return hipErrorInvalidValue;
+  // (the handle allocates 2 x voxel_store_recs entries per workgroup: records, then the cell area)
   if (voxel_store_need(group, n_stride) > T.voxel_store_recs) return hipErrorInvalidValue;
   VoxelArena ar;
   ar.base = (float4 *)arena;

@@ -506,7 +506,8 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   // at most two workgroups per CU and never more than scans in a batch)
   c->vstore_wgs = std::min<uint32_t>(c->max_b, rpl::voxel_max_workgroups(c->n_cu));
   c->vstore_recs = (uint32_t)rpl::voxel_store_need(1u, rpl::kMaxN);
-  if (hipMalloc(&c->d_vstore, (size_t)c->vstore_wgs * c->vstore_recs * 16u) != hipSuccess) {
+  // (x 2: every workgroup's record store is followed by its temporary cell area of the same size)
+  if (hipMalloc(&c->d_vstore, (size_t)c->vstore_wgs * c->vstore_recs * 32u) != hipSuccess) {
     c->err = "record store allocation failed";
     return fail(RPLGPU_ERR_HIP);
   }
@@ -700,7 +701,7 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
     RPL_HIP(h, hipSetDevice(h->device));
     RPL_HIP(h, hipStreamSynchronize(h->stream));
     void *bigger = nullptr;
-    if (hipMalloc(&bigger, (size_t)h->vstore_wgs * need * 16u) != hipSuccess) {
+    if (hipMalloc(&bigger, (size_t)h->vstore_wgs * need * 32u) != hipSuccess) {
       h->err = "record store allocation failed";
       (void)hipGetLastError();
       return RPLGPU_ERR_HIP;
