@@ -34,6 +34,9 @@ struct Tables {
   void *voxel_store;       // k_cloud_voxel's record stores: voxel_store_wgs x voxel_store_recs x 16 B
   uint32_t voxel_store_wgs;
   uint32_t voxel_store_recs;  // records per workgroup (>= kMaxN; group x kMaxN for an E8 group)
+  unsigned long long *voxel_stats;  // [0] queue entries, [1] work items of the launch (device; may be null)
+  unsigned long long *voxel_stats_host;  // pinned copy of voxel_stats, refreshed behind every launch (or null)
+  int32_t voxel_split;     // host decision from the previous launch's statistics: the noisy-batch instance
 };
 
 struct KParams {

@@ -247,8 +247,20 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
 // filtered at q_min = 48 makes twice the run records (random drops cut every run).  The plain
 // instance does not need it: its drops come in runs (dist 0), a dropped sample never writes a
 // record (its own run-end bit is masked) and it ends the run in front of it by its mask bit.
-template <bool FILL, int NS>
-__device__ __forceinline__ void voxel_block_pass(VoxelLds &L, uint4 *__restrict__ G,
+// kPassSplit: when the block makes more than kSplitAbove records (range noise: neighbouring samples
+// alternate between two adjacent cells and every sample or two ends a run) nothing is written and
+// the function returns true; the caller then aggregates the block in two CLASSES — the cells of
+// either colour of a checkerboard, (ix + iy) & 1 — each blind to the other's samples (FILL), so
+// that A B A B A becomes one run of A and one of B instead of five (voxel_block_split).
+#ifndef RPL_VOXEL_SPLIT_ABOVE
+#define RPL_VOXEL_SPLIT_ABOVE 26  // clean rings: <= ~21 runs per 128 samples at r = 30 m
+#endif
+constexpr uint32_t kSplitAbove = RPL_VOXEL_SPLIT_ABOVE;
+// Only the kernel instance the launcher picks for batches known to be noisy compiles kPassSplit:
+// inlined next to the plain path it costs a clean batch 1.5-2.7 % (profiles/r03/voxel_split_r03.txt).
+enum : int { kPassPlain = 0, kPassSplit = 2 };
+template <bool FILL, int NS, int MODE = kPassPlain>
+__device__ __forceinline__ bool voxel_block_pass(VoxelLds &L, uint4 *__restrict__ G,
                                                  const bool (&ok)[NS], uint32_t (&key)[NS],
                                                  const uint32_t (&qx)[NS], const uint32_t (&qy)[NS],
                                                  const uint32_t (&ci)[NS]) {
@@ -291,7 +303,8 @@ __device__ __forceinline__ void voxel_block_pass(VoxelLds &L, uint4 *__restrict_
     m[j] = okm[j] & (m[j] | ~ok_next);
     total += (uint32_t)__popcll(m[j]);
   }
-  if (total == 0u) return;  // wave-uniform: nothing kept in this block
+  if (total == 0u) return false;  // wave-uniform: nothing kept in this block
+  if (MODE == kPassSplit && total > kSplitAbove) return true;  // wave-uniform: the caller splits the block
   // reserve queue entries (the records + their marker): one LDS atomic by lane 0, its round trip
   // overlaps the scans below (hand-placed so that the compiler's atomic optimiser does not wait
   // for it right away)
@@ -353,6 +366,30 @@ __device__ __forceinline__ void voxel_block_pass(VoxelLds &L, uint4 *__restrict_
         if (pos[j] < kRecCap) lds_store128(lds_rec + pos[j] * 16u, rec[j]); else glb_store128(G + pos[j], rec[j]);
       }
     }
+  }
+  return false;
+}
+
+// A noisy block in two classes (see kPassSplit): class c keeps the samples whose cell has
+// (ix + iy) & 1 == c, the others count as dropped (zero contribution, neighbour's key).
+template <int NS>
+__device__ __forceinline__ void voxel_block_split(VoxelLds &L, uint4 *__restrict__ G,
+                                                  const bool (&ok)[NS], const uint32_t (&key)[NS],
+                                                  const uint32_t (&qx)[NS], const uint32_t (&qy)[NS],
+                                                  const uint32_t (&ci)[NS]) {
+#pragma unroll
+  for (uint32_t cls = 0; cls < 2u; ++cls) {
+    bool okc[NS];
+    uint32_t keyc[NS], qxc[NS], qyc[NS], cic[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      okc[j] = ok[j] && (((key[j] >> 16) ^ key[j]) & 1u) == cls;
+      keyc[j] = key[j];
+      qxc[j] = okc[j] ? qx[j] : 0u;
+      qyc[j] = okc[j] ? qy[j] : 0u;
+      cic[j] = okc[j] ? ci[j] : 0u;
+    }
+    voxel_block_pass<true, NS, kPassPlain>(L, G, okc, keyc, qxc, qyc, cic);
   }
 }
 
@@ -662,7 +699,10 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
   return 0u;
 }
 
-template <bool FAST_DIV, bool SAFE, bool DBG>
+// SPLIT: the instance for batches known to be noisy (its blocks may be aggregated in two classes,
+// voxel_block_split); the launcher picks it from the queue statistics of the handle's previous
+// launch (T.voxel_stats), so a clean batch runs code without a trace of that path.
+template <bool FAST_DIV, bool SAFE, bool DBG, bool SPLIT>
 __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cloud_voxel(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
@@ -829,7 +869,9 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 asm volatile("" : "+v"(qx[1]), "+v"(qy[0]), "+v"(ci[1]), "+v"(key[1])::"memory");
                 t2 = clock64();
               }
-              voxel_block_pass<HASQ || HASMASK, 2>(L, G, ok, key, qx, qy, ci);
+              uint32_t key0[2] = {key[0], key[1]};  // (the FILL instance rewrites dropped samples' keys)
+              if (voxel_block_pass<HASQ || HASMASK, 2, SPLIT ? kPassSplit : kPassPlain>(L, G, ok, key, qx, qy, ci))
+                voxel_block_split<2>(L, G, ok, key0, qx, qy, ci);
               if (DBG) {  // [10] block pass (issue only: its stores are not waited for)
                 t3 = clock64();
                 if (p.dbg && threadIdx.x == 0) {
@@ -860,6 +902,10 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       __syncthreads();  // (workgroup-scope release / acquire: covers the record store too)
       pc.lap(0);
       n_all = L.misc[0];
+      if (threadIdx.x == 0 && T.voxel_stats) {  // queue statistics of the launch (see SPLIT)
+        atomicAdd(&T.voxel_stats[0], (unsigned long long)n_all);
+        atomicAdd(&T.voxel_stats[1], 1ull);
+      }
       if (n_all > kRecCap) {
         // the scan did not fit the LDS queue: its first kRecCap records join the others in the
         // record store, and the bands below are cut from the store
@@ -1131,20 +1177,32 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
     if (g > 0) grid = std::min<uint32_t>(grid, (uint32_t)g);
   }
   if (hipError_t e = hipMemsetAsync(T.work_ctr, 0, 4, s); e != hipSuccess) return e;
-#define RPL_LAUNCH_VOXEL(FD, SF, DB)                                                              \
-  hipLaunchKernelGGL((k_cloud_voxel<FD, SF, DB>), dim3(grid), dim3(kVB), 0, s, (const uint2 *)nodes, \
-                     n_stride, n_per_scan, p, T, keepmask, mask_stride, (float4 *)xyzi, out_stride, \
+  // queue statistics of the launch (they pick the NEXT launch's instance): batches only
+  const bool with_stats = T.voxel_stats && T.voxel_stats_host && B >= 64u;
+  Tables Tk = T;
+  if (!with_stats) Tk.voxel_stats = nullptr;
+  if (with_stats)
+    if (hipError_t e = hipMemsetAsync(T.voxel_stats, 0, 16, s); e != hipSuccess) return e;
+#define RPL_LAUNCH_VOXEL(FD, SF, DB, SP)                                                          \
+  hipLaunchKernelGGL((k_cloud_voxel<FD, SF, DB, SP>), dim3(grid), dim3(kVB), 0, s, (const uint2 *)nodes, \
+                     n_stride, n_per_scan, p, Tk, keepmask, mask_stride, (float4 *)xyzi, out_stride, \
                      n_points, status, B, ar, (uint4 *)T.voxel_store, group, n_scans, motion, pose2d)
-  if (p.dbg) {  // developer aid: the instrumented build of the kernel
-    if (p.fast_div) {
-      if (p.cell_range_safe) RPL_LAUNCH_VOXEL(true, true, true); else RPL_LAUNCH_VOXEL(true, false, true);
-    } else {
-      if (p.cell_range_safe) RPL_LAUNCH_VOXEL(false, true, true); else RPL_LAUNCH_VOXEL(false, false, true);
-    }
-  } else if (p.fast_div) {
-    if (p.cell_range_safe) RPL_LAUNCH_VOXEL(true, true, false); else RPL_LAUNCH_VOXEL(true, false, false);
+#define RPL_LAUNCH_VOXEL_SF(FD, DB, SP)                                                           \
+  do {                                                                                             \
+    if (p.cell_range_safe) RPL_LAUNCH_VOXEL(FD, true, DB, SP); else RPL_LAUNCH_VOXEL(FD, false, DB, SP); \
+  } while (0)
+  if (p.dbg) {  // developer aid: the instrumented build of the kernel (plain instance only)
+    if (p.fast_div) RPL_LAUNCH_VOXEL_SF(true, true, false); else RPL_LAUNCH_VOXEL_SF(false, true, false);
+  } else if (T.voxel_split) {  // the handle's previous launch saw a noisy batch
+    if (p.fast_div) RPL_LAUNCH_VOXEL_SF(true, false, true); else RPL_LAUNCH_VOXEL_SF(false, false, true);
   } else {
-    if (p.cell_range_safe) RPL_LAUNCH_VOXEL(false, true, false); else RPL_LAUNCH_VOXEL(false, false, false);
+    if (p.fast_div) RPL_LAUNCH_VOXEL_SF(true, false, false); else RPL_LAUNCH_VOXEL_SF(false, false, false);
+  }
+#undef RPL_LAUNCH_VOXEL_SF
+  if (with_stats) {  // the statistics follow the launch to pinned memory (no wait)
+    if (hipError_t e = hipMemcpyAsync(T.voxel_stats_host, T.voxel_stats, 16, hipMemcpyDeviceToHost, s);
+        e != hipSuccess)
+      return e;
   }
 #undef RPL_LAUNCH_VOXEL
   return hipGetLastError();
