@@ -177,8 +177,8 @@ __device__ __forceinline__ uint32_t deg_to_q14(float v) {  // setAngle, :107-110
 // sorting; SORT = true runs after it, returns at once for unflagged scans and does the whole
 // job including the sort for the others.  Keeping the sort (32 keys per thread in registers)
 // out of the first kernel keeps its register allocation spill-free.
-// (Round 3: the SORT = false instance is no longer launched — k_ascend_stream below does its job —
-// and the SORT = true instance is a persistent grid over the LIST of flagged scans that
+// (Round 3: the SORT = false instance serves only calls of a few scans — k_ascend_stream below does
+// the batches — and the SORT = true instance is a persistent grid over the LIST of flagged scans that
 // k_ascend_stream appends to: need_sort[0] = how many, need_sort[1 ..] = which.  Launching one
 // 1024-thread, 128 KiB workgroup per scan only to find its flag clear cost more than the
 // streaming kernel itself.)
@@ -237,8 +237,7 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
   first = s_misc[0];
   if (first == 0xFFFFFFFFu) {  // :151 all invalid -> SL_RESULT_OPERATION_FAIL, buffer untouched
     if (threadIdx.x == 0 && status) status[b] = RPLGPU_SCAN_ALL_INVALID;
-    if (threadIdx.x == 0 && !SORT) need_sort[b] = 0u;
-    return;
+    return;  // (not queued for the sorting kernel)
   }
   if (threadIdx.x == 0 && status) status[b] = 0u;
 
@@ -294,7 +293,8 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
   // Equal angles: the reference order is whatever introsort leaves; ours is input order.
   if (!SORT) {
     const bool unsorted = keys_unsorted(s_keys, n, &s_misc[2]);
-    if (threadIdx.x == 0) need_sort[b] = unsorted ? 1u : 0u;
+    // not ascending: queue the scan for the sorting kernel (need_sort[0] = count, then the list)
+    if (threadIdx.x == 0 && unsorted) need_sort[1u + atomicAdd(&need_sort[0], 1u)] = b;
     if (!unsorted) {  // already ascending: only the filled angles move
 #pragma unroll
       for (int j = 0; j < kIters; ++j)
@@ -618,8 +618,16 @@ hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const ui
                          uint32_t B, uint32_t *status, uint32_t *need_sort) {
   if (B == 0) return hipSuccess;
   if (hipError_t e = hipMemsetAsync(need_sort, 0, 4, s); e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_ascend_stream, dim3(B), dim3(kAscT), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
-                     status, need_sort);
+  // A handful of LONG scans (the single-scan seam above the SDK's 8192-node cap): latency counts,
+  // and one 1024-thread workgroup that holds the scan in registers finishes a 32 000-sample scan in
+  // a quarter less time than one 256-thread workgroup streaming it (46 vs 62 us per call; at 360
+  // samples the streaming kernel is the faster one, 18 vs 24 us); batches stream.
+  if (B <= 8u && n_stride > 8192u)
+    hipLaunchKernelGGL(k_ascend<false>, dim3(B), dim3(kBlock), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
+                       status, need_sort);
+  else
+    hipLaunchKernelGGL(k_ascend_stream, dim3(B), dim3(kAscT), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
+                       status, need_sort);
   hipLaunchKernelGGL(k_ascend<true>, dim3(std::min<uint32_t>(B, 256u)), dim3(kBlock), 0, s,
                      (uint2 *)nodes, n_stride, n_per_scan, status, need_sort);
   return hipGetLastError();
