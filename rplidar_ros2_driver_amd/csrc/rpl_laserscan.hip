@@ -61,6 +61,13 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
   float *out_i = intens + (size_t)b * n_stride;
 
   if (threadIdx.x == 0) s_cnt = 0u;
+#ifdef RPL_LS_DBG  // developer build: phase clocks of thread 0 (tools/dev/lsbench.py)
+  unsigned long long dbg_t[7];
+#define RPL_LS_CLK(i) dbg_t[i] = __builtin_amdgcn_s_memtime()
+#else
+#define RPL_LS_CLK(i) (void)0
+#endif
+  RPL_LS_CLK(0);
 
   // Bounds-checked buffer resource over the scan's n*8 bytes: what lies beyond reads as
   // zero = dist 0 = dropped by the keep test (d_lo >= 1).
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
   if (lane_id() == 0 && c) atomicAdd(&s_cnt, c);
   __syncthreads();
   const uint32_t count = s_cnt;
+  RPL_LS_CLK(1);  // loads + count
   if (threadIdx.x == 0) beam_count[b] = count;
   if (count == 0) return;  // :611-613 nothing published
 
@@ -129,6 +137,10 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
                       (ww.z << 16) | (((ww.w >> ishift) & imask) << 8), __float_as_uint(dmB));
     if (j & 1) __builtin_amdgcn_sched_barrier(0);  // keep the conversion in place, 4 table loads in flight
   }
+  RPL_LS_CLK(2);  // conversion
+#ifdef RPL_LS_DBG
+  dbg_t[3] = dbg_t[4] = dbg_t[5] = dbg_t[6] = dbg_t[2];
+#endif
   auto key64 = [](uint32_t low, uint32_t hi) -> unsigned long long {
     return ((unsigned long long)hi << 32) | (unsigned long long)low;
   };
@@ -144,6 +156,9 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
       if (rB < kLsWin) atomicMin(&s_bins[rB], key64(w[j].z, w[j].w));
     }
     __syncthreads();
+#ifdef RPL_LS_DBG
+    if (lo == 0) RPL_LS_CLK(3); else RPL_LS_CLK(5);  // clear + atomics of a window
+#endif
     for (uint32_t t = threadIdx.x; t < nb; t += kBlock) {
       const unsigned long long k = s_bins[t];
       const uint32_t hi = (uint32_t)(k >> 32), low = (uint32_t)k;
@@ -153,7 +168,14 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
       __builtin_nontemporal_store(empty ? 0.0f : (float)((low >> 8) & 0xFFu), &out_i[lo + t]);
     }
     __syncthreads();
+#ifdef RPL_LS_DBG
+    if (lo == 0) RPL_LS_CLK(4); else RPL_LS_CLK(6);  // flush of a window
+#endif
   }
+#ifdef RPL_LS_DBG
+  if (threadIdx.x == 0 && n_stride >= count + 8u)  // (the unused tail of the scan's range row)
+    for (int d = 0; d < 6; ++d) out_r[n_stride - 8 + d] = (float)(dbg_t[d + 1] - dbg_t[d]);
+#endif
 }
 
 // ------------------------------------------------------------------------------
