@@ -408,6 +408,9 @@ def single_scan_table(gpu, params_voxel, seed, cpu_seconds):
     table = {}
     pl1 = Params.defaults(range_max=40.0)
     pin = gpu.host_alloc(1 << 20)
+    params_ror = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0,
+                                 voxel_enable=1, voxel_leaf=0.05, ror_enable=1, ror_radius=0.10,
+                                 ror_min_neighbors=2)
     for n in (360, 3200, 8192, 32000):
         one = synth.make_scan(seed, 9000 + n, n)
         # ascend works in place: every call gets a fresh copy of the scan — as a byte memcpy (a
@@ -428,6 +431,7 @@ def single_scan_table(gpu, params_voxel, seed, cpu_seconds):
                                                                        1, 2, out=pin)),
             ("ascend", lambda: gpu.ascend(fresh())),
             ("voxel_cloud", lambda: gpu.scan_to_cloud(one, params_voxel)),
+            ("ror_voxel_cloud", lambda: gpu.scan_to_cloud(one, params_ror)),
         ):
             for _ in range(20):
                 fn()

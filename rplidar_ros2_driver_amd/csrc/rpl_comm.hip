@@ -77,6 +77,21 @@ hipError_t launch_signal(hipStream_t s, uint32_t *flag, uint32_t seq) {
   return hipGetLastError();
 }
 
+// A staged scan (pinned host memory, read over the bus by the kernel itself) into HBM, for the
+// single-scan paths that read a scan more than once (E5).  One kernel in the stream instead of a
+// copy-engine transfer: no engine hand-over in front of the first kernel of the call.
+__global__ __launch_bounds__(256) void k_stage_in(const uint2 *__restrict__ src, uint2 *__restrict__ dst,
+                                                  uint32_t n_words2) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n_words2) dst[i] = src[i];
+}
+hipError_t launch_stage_in(hipStream_t s, const void *src, void *dst, uint32_t n_words2) {
+  if (n_words2 == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_stage_in, dim3((n_words2 + 255u) / 256u), dim3(256), 0, s,
+                     (const uint2 *)src, (uint2 *)dst, n_words2);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_meta(hipStream_t s, const unsigned long long *cursor,
                             const unsigned long long *scan_start, const uint32_t *n_points,
                             uint32_t B, unsigned long long slot_points, uint32_t max_scans,

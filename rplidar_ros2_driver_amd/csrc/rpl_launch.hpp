@@ -72,6 +72,7 @@ hipError_t launch_laserscan_to_cloud(hipStream_t s, const float *ranges, const f
 
 // multi-GPU exchange, device side (rpl_comm.hip)
 hipError_t launch_signal(hipStream_t s, uint32_t *flag, uint32_t seq);
+hipError_t launch_stage_in(hipStream_t s, const void *src, void *dst, uint32_t n_words2);  // 8-byte words
 hipError_t launch_pack_meta(hipStream_t s, const unsigned long long *cursor,
                             const unsigned long long *scan_start, const uint32_t *n_points,
                             uint32_t B, unsigned long long slot_points, uint32_t max_scans,

@@ -874,14 +874,24 @@ int32_t rplgpu_scan_to_cloud(rplgpu_handle_t h, const rplgpu_node_t *nodes, size
   if (n == 0) return RPLGPU_OK;
   unsigned char *h_out = stage_out(h);
   RPL_HIP(h, hipSetDevice(h->device));
-  if (h->zero_copy && !p->ror_enable) {  // (E5 reads a scan many times: it wants it in HBM)
+  if (h->zero_copy) {
     const ScanStage st = stage_scan(h, nodes, n);
     uint32_t *d_words = reinterpret_cast<uint32_t *>(st.d_out + n * 16);  // n_points, status
+    const rplgpu_node_t *d_in = st.d_nodes;
+    const uint32_t *d_in_n = st.d_n;
+    if (p->ror_enable) {
+      // E5 reads a scan many times: it wants it in HBM.  The staged nodes and their count word
+      // are brought over by a kernel of the same stream (not the copy engine), the results go
+      // straight to the pinned staging as in the plain case.
+      RPL_HIP(h, rpl::launch_stage_in(h->stream, st.d_nodes, h->d_nodes, (uint32_t)n + 1u));
+      d_in = reinterpret_cast<const rplgpu_node_t *>(h->d_nodes);
+      d_in_n = reinterpret_cast<const uint32_t *>(h->d_nodes + n * 8);
+    }
     // (the batch entry point's pointer check asks the runtime about each pointer: skip it for
     // the handle's own staging)
     const bool chk = h->check_ptrs;
     h->check_ptrs = false;
-    const int32_t rc = rplgpu_cloud_batch_dev(h, st.d_nodes, (uint32_t)n, st.d_n, 1, p,
+    const int32_t rc = rplgpu_cloud_batch_dev(h, d_in, (uint32_t)n, d_in_n, 1, p,
                                               reinterpret_cast<float *>(st.d_out), (uint32_t)n,
                                               d_words, d_words + 1);
     h->check_ptrs = chk;
