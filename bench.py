@@ -432,6 +432,8 @@ def single_scan_table(gpu, params_voxel, seed, cpu_seconds):
             ("ascend", lambda: gpu.ascend(fresh())),
             ("voxel_cloud", lambda: gpu.scan_to_cloud(one, params_voxel)),
             ("ror_voxel_cloud", lambda: gpu.scan_to_cloud(one, params_ror)),
+            ("voxel_cloud_msg_pinned", lambda: gpu.scan_to_cloud_msg(one, params_voxel, "laser_frame",
+                                                                     1, 2, out=pin)),
         ):
             for _ in range(20):
                 fn()

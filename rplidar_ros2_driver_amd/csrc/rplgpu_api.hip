@@ -1412,33 +1412,20 @@ int32_t rplgpu_scan_to_cloud_msg(rplgpu_handle_t h, const rplgpu_node_t *nodes, 
     h->err = "message buffer smaller than the worst case (n points)";
     return RPLGPU_ERR_CAPACITY;
   }
-  uint32_t *h_small = reinterpret_cast<uint32_t *>(stage_out(h));  // pinned scratch words
-  h_small[1] = h_small[2] = 0;
+  // The cloud itself comes through rplgpu_scan_to_cloud (zero-copy staging, completion flag): it
+  // lands at its final offset inside the message — the data offset does not depend on the number
+  // of points — and the CDR framing around it is written once that number is known.
+  uint32_t np = 0, st = 0;
+  int32_t crc = RPLGPU_OK;
   if (n) {
-    RPL_HIP(h, hipSetDevice(h->device));
-    const uint32_t *d_n;
-    if (int32_t urc = upload_scan(h, nodes, n, &d_n)) return urc;
-    uint32_t *d_words = reinterpret_cast<uint32_t *>(h->d_out + n * 16);  // n_points, status
-    int32_t rc = rplgpu_cloud_batch_dev(h, reinterpret_cast<const rplgpu_node_t *>(h->d_nodes),
-                                        (uint32_t)n, d_n, 1, p,
-                                        reinterpret_cast<float *>(h->d_out), (uint32_t)n,
-                                        d_words, d_words + 1);
-    if (rc) return rc;
-    RPL_HIP(h, hipMemcpyAsync(h_small + 1, d_words, 8, hipMemcpyDeviceToHost, h->stream));
-    RPL_HIP(h, hipStreamSynchronize(h->stream));
+    crc = rplgpu_scan_to_cloud(h, nodes, n, p, reinterpret_cast<float *>(msg + L.data_off), &np, &st);
+    if (crc != RPLGPU_OK && crc != RPLGPU_ERR_SCAN_OVERFLOW) return crc;
   }
-  const uint32_t np = h_small[1];
   if (int32_t rc = rplgpu_msg_cloud_header(frame_id, stamp, np, msg, cap, &L)) return rc;
-  if (np) {
-    RPL_HIP(h, hipMemcpyAsync(msg + L.data_off, h->d_out, (size_t)np * 16, hipMemcpyDeviceToHost,
-                              h->stream));
-    RPL_HIP(h, hipStreamSynchronize(h->stream));
-  }
   *n_points = np;
   *msg_len = L.total_len;
-  if (status) *status = h_small[2];
-  return (h_small[2] & (RPLGPU_SCAN_CELL_RANGE | RPLGPU_SCAN_TABLE_FULL)) ? RPLGPU_ERR_SCAN_OVERFLOW
-                                                                          : RPLGPU_OK;
+  if (status) *status = st;
+  return crc;
 }
 
 static int32_t make_prefix(rplgpu_handle_t h, const char *frame_id, bool cloud,
