@@ -981,8 +981,10 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     const bool last_chunk = chunk0 + N == carry_nodes;
     const uint32_t seg = (N + kDecBlock - 1u) / kDecBlock;
     const uint32_t i_lo = min(tid * seg, N), i_hi = min(i_lo + seg, N);
-    auto patch = [&](uint32_t i, int st) {  // node i has state st: patch dist_mm_q2 if smoothed
-      if (st != 4 && chunk0 + i < n_out) {  // (bits 16.. of the packed node)
+    // node i has state st: patch dist_mm_q2 if smoothed; `redo`: a guessed state may have been
+    // written before (scale-0 nodes only: the others always have state 4), write what is true
+    auto patch = [&](uint32_t i, int st, bool redo = false) {
+      if ((st != 4 || (redo && is_s0(i))) && chunk0 + i < n_out) {  // (bits 16.. of the packed node)
         const uint32_t d = (uint32_t)(rawd(i) + st - 4);
         uint2 *at = FUSE ? fused_dst(chunk0 + i) : out + chunk0 + i;
         if (at) {
@@ -1004,6 +1006,9 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     // its predecessor; past ~2 m every node does — the segment's states no longer depend on
     // what came before it: they are final and written right away.  (A constant distance keeps
     // two states apart for ever: (x >> 1) has the fixed points 0 and -1.)
+    // While the states still depend on the entry, the nodes are written with the states that
+    // follow from entry state 4 ("the node in front was not smoothed", by far the most frequent):
+    // pass C then only has to walk the segments whose true entry state is another one.
     unsigned long long M = kIdent;
     uint32_t i_open = i_hi;  // [i_lo, i_open): states that depend on the entry state (pass C)
     if (i_lo < i_hi) {
@@ -1024,6 +1029,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
 #pragma unroll
           for (int c = 0; c < 9; ++c) cur[c] = step(i, pd + cur[c] - 4);
         }
+        patch(i, cur[4]);  // (the guess)
         va = cur[0];
         vb = va;
 #pragma unroll
@@ -1037,14 +1043,16 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
         }
       }
       if (two) {
+        const bool guess_b = ((in_b >> 4) & 1u) != 0u;  // entry state 4 leads to vb
         for (; i < i_hi && va != vb; ++i) {
           const int pd = rawd(i - 1u);
           va = step(i, pd + va - 4);
           vb = step(i, pd + vb - 4);
+          patch(i, guess_b ? vb : va);
         }
         if (va == vb) {
           i_open = i - 1u;  // node i-1 merged the last two states: it has state va whatever the entry
-          patch(i - 1u, va);
+          // (already written: every chain, the guessed one included, has state va there)
           for (; i < i_hi; ++i) {
             va = step(i, rawd(i - 1u) + va - 4);
             patch(i, va);
@@ -1082,11 +1090,14 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     // every map in front of a non-empty segment starts with node 0's constant map, so any
     // entry state (take 4) gives the state its predecessor node really has
     int sp = (int)((excl >> (4 * 4)) & 15ull);
-    // pass C: the (usually empty) head of the segment, with the true entry state
-    for (uint32_t i = i_lo; i < min(i_open, i_hi); ++i) {
-      const int last = (i == 0u) ? chunk_last : rawd(i - 1u) + sp - 4;
-      sp = step(i, last);
-      patch(i, sp);
+    // pass C: the (usually empty) head of the segment again, if its true entry state is not the
+    // guessed one
+    if (sp != 4) {
+      for (uint32_t i = i_lo; i < min(i_open, i_hi); ++i) {
+        const int last = (i == 0u) ? chunk_last : rawd(i - 1u) + sp - 4;
+        sp = step(i, last);
+        patch(i, sp, true);
+      }
     }
     __syncthreads();
     chunk_last = (int)L.misc[7];

@@ -102,6 +102,30 @@ def test_ultra_dense_smoothing_chains(gpu, oracle):
         cp._seal_capsules(f)
         for last in (0, 5, 8000, 8190):
             _check_stream(gpu, oracle, 0x86, f.reshape(-1), 125, state=(0, last))
+        # a constant distance entered from 8 below: the smoothed value settles one unit under the
+        # raw one and stays there ((x >> 1) keeps -1), so whole thread segments are entered in a
+        # state other than "not smoothed" and never forget it (the kernel's guess is wrong for
+        # every one of them); a zero now and then restarts the chain from the other fixed point
+        walk = np.full(nfr * 64, 700, np.uint32)
+        walk[0] = 0
+        walk[1] = 699
+        z = np.nonzero(rng.random(nfr * 64) < 0.002)[0]
+        z = z[(z > 2) & (z < nfr * 64 - 2)]
+        walk[z] = 0
+        walk[z[::2] + 1] = 699
+        w = ((walk << 2) & 0xFFC) | (rng.integers(0, 256, nfr * 64).astype(np.uint32) << 12)
+        w = w.reshape(nfr, 64)
+        e, o_ = w[:, 0::2], w[:, 1::2]
+        f[:, 10::5] = e & 0xFF
+        f[:, 11::5] = (e >> 8) & 0xFF
+        f[:, 12::5] = o_ & 0xFF
+        f[:, 13::5] = (o_ >> 8) & 0xFF
+        f[:, 14::5] = ((e >> 16) & 0xF) | (((o_ >> 16) & 0xF) << 4)
+        cp._seal_capsules(f)
+        for last in (0, 5599, 5600):
+            nodes, _, _ = _check_stream(gpu, oracle, 0x86, f.reshape(-1), 125, state=(0, last))
+        d = nodes["dist_mm_q2"]
+        assert (d == 5599).sum() > len(d) // 4  # (the -1 fixed point really is where it sits)
 
 
 def test_decode_state_carries_between_calls(gpu, oracle):
