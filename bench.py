@@ -752,14 +752,15 @@ def main():
                                         "(8 sensors), E5 mask on"}
         del c5b, big_arena, d_c5
 
-    if not args.no_decode and rank == 0:
+    # (the side legs below are single-GPU properties: at N > 1 the ranks leave together)
+    if not args.no_decode and rank == 0 and world == 1:
         extra["decode"] = decode_stage(gpu, dev, stream, args.cpu_seconds)
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         cpu = cpu_baseline(batch_np, lens_np, params, args.cpu_seconds)
 
-    if rank == 0 and not args.no_single:
+    if rank == 0 and world == 1 and not args.no_single:
         extra["single_scan_us"] = single_scan_table(gpu, params, args.seed, args.cpu_seconds)
 
     if rank == 0:
