@@ -69,6 +69,7 @@ struct KParams {
                             // the cell's index in the output buffer (rplgpu_set_cell_key_output)
   int32_t fast_div;   // 1: the mul+2*FMA divides by 4000 and by leaf were validated on this
                       //    device to be bit-identical to the IEEE divide (see k_validate_div)
+  int32_t fast_d4000; // 1: ... the divide by 4000 alone (kernels that do not divide by the leaf)
 };
 
 // ---- packed node decode (uint2 = the 8 raw bytes, little endian) ----------------

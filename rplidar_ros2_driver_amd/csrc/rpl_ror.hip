@@ -61,6 +61,9 @@ __device__ __forceinline__ float2 node_xy(uint2 nd, const float2 *__restrict__ c
   return make_float2(dm * c.x, dm * c.y);  // E2
 }
 
+// FAST: dist / 4000 as mul + 2 FMA (validated bit-identical to the IEEE divide on this device,
+// rplgpu_api.hip validate_divisor) in stage 1, where every sample is converted
+template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ nodes,
                                                      uint32_t n_stride,
                                                      const uint32_t *__restrict__ n_per_scan,
@@ -68,6 +71,9 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
                                                      uint32_t *__restrict__ mask_out,
                                                      uint32_t mask_stride) {
   __shared__ RorLds L;
+#ifdef RPL_ROR_DBG
+  const unsigned long long dbg_entry = __builtin_amdgcn_s_memtime();
+#endif
   const uint32_t b = blockIdx.x;
   const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   const uint2 *scan = nodes + (size_t)b * n_stride;
@@ -85,11 +91,17 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   for (uint32_t t = threadIdx.x; t < kMaxN / 32u; t += kBlock) L.late[t] = 0u;
   __syncthreads();
 
+#ifdef RPL_ROR_DBG  // developer build: phase clocks of thread 0 into the cycle buffer (tools/dev/rorbench.py)
+  unsigned long long dbg_t[6];
+#define RPL_ROR_CLK(i) dbg_t[i] = __builtin_amdgcn_s_memtime()
+#else
+#define RPL_ROR_CLK(i) (void)0
+#endif
+  RPL_ROR_CLK(0);
   const float r2 = p.ror_r2;
   const uint32_t need = p.ror_k;
   // ---- stage 1: E1 keep bits, y extent, and the index-neighbour test ----------------------
   uint32_t kept = 0, keep = 0;
-  float ymin = __uint_as_float(0x7F800000u), ymax = __uint_as_float(0xFF800000u);
   // A trip covers the 2048 consecutive samples [2048 t, 2048 t + 2048): every thread computes
   // the points of its two samples ONCE and publishes them in LDS (a sample that is not kept, or
   // lies outside the scan, as NaN: it then fails every distance test), four halo samples on
@@ -98,11 +110,13 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   // its eight neighbours itself — nine node loads and nine table gathers per sample behind
   // data-dependent branches — made this stage 1.9 ms of C5's 4.3; one 1024-sample window per
   // trip without prefetch 1.35.)
-  const float qnan = __uint_as_float(0x7FC00000u);
+  // A sample that is not kept (or lies outside the scan) is published as a point so far away
+  // that its squared distance from any real point overflows to +inf: then r2 - d2 = -inf, and the
+  // whole test "d2 <= r2" is the SIGN BIT of r2 - d2 (0 = within; equal gives +0; no NaN can
+  // arise: real coordinates are below 1.1e6 m).  The eight sign bits are shifted into one word
+  // (v_alignbit) and counted once — a compare, a select and the bit assembly per neighbour less.
+  const float far = 1.0e30f;
   auto load_node = [&](uint32_t q) -> uint2 { return q < n ? scan[q] : make_uint2(0u, 0u); };  // dist 0: dropped
-  auto point_of = [&](uint2 c) -> float2 {
-    return nd_keep(nd_dist(c), nd_quality(c), p) ? node_xy(c, cs) : make_float2(qnan, qnan);
-  };
   constexpr uint32_t kSpan = 2u * kBlock;
   const int trips = (int)((n + kSpan - 1u) / kSpan);  // block-uniform
   // software pipeline: raw nodes two trips ahead, points (the table gather) one trip ahead; the
@@ -110,26 +124,57 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   // (thread 3's offset base - 1 is 0xFFFFFFFF as a number: "no halo duty" is a flag of its own,
   // not a sentinel value of the offset)
   const bool has_halo = threadIdx.x < 2u * kRorNear;
+  const bool halo_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;  // (scalar: the eight halo lanes live in wave 0)
   const uint32_t halo_q = threadIdx.x < (uint32_t)kRorNear ? threadIdx.x - (uint32_t)kRorNear  // base - 4 + t
                                                            : kSpan + threadIdx.x - (uint32_t)kRorNear;
   auto halo_index = [&](uint32_t base) -> uint32_t {
     // (first trip: base - 4 + t wraps below 0 and fails q < n; no duty: always out of range)
     return has_halo ? base + halo_q : 0xFFFFFFFFu;
   };
-  float2 p0 = point_of(load_node(threadIdx.x)), p1 = point_of(load_node(kBlock + threadIdx.x));
-  float2 ph = point_of(load_node(halo_index(0u)));
+  // gathered (cos, sin) of a node: always a valid table index, whatever the node holds
+  auto cs_of = [&](uint2 c) -> float2 { return cs[nd_q14(c)]; };
+  // the point of a node from its gathered (cos, sin): node_xy's arithmetic (E2), NaN if not kept
+  auto point_from = [&](uint2 c, float2 g) -> float2 {
+    const float df = __uint2float_rn(nd_dist(c));
+    float dm;  // :590
+    if (FAST) {
+      const float q = df * 0.00025f, e = fmaf(-q, 4000.0f, df);
+      dm = fmaf(e, 0.00025f, q);
+    } else {
+      dm = df / 4000.0f;
+    }
+    const bool k = nd_keep(nd_dist(c), nd_quality(c), p);
+    return make_float2(k ? dm * g.x : far, k ? dm * g.y : far);
+  };
+  // nodes of trip 0 and their table entries, nodes of trip 1
+  uint2 c0 = load_node(threadIdx.x), c1 = load_node(kBlock + threadIdx.x), ch = load_node(halo_index(0u));
+  float2 g0 = cs_of(c0), g1 = cs_of(c1), gh = cs_of(ch);
   uint2 n0 = load_node(kSpan + threadIdx.x), n1 = load_node(kSpan + kBlock + threadIdx.x);
   uint2 nh = load_node(halo_index(kSpan));
   for (int t = 0; t < trips; ++t) {
     const uint32_t base = (uint32_t)t * kSpan, i0 = base + threadIdx.x, i1 = i0 + kBlock;
-    const float2 me0 = p0, me1 = p1, meh = ph;
-    const uint2 c0 = n0, c1 = n1, ch = nh;           // nodes of trip t + 1 (loaded a trip ago)
-    n0 = load_node(i0 + 2u * kSpan);                 // nodes of trip t + 2
+    // Vector loads return in order.  The three table gathers of a trip are issued back to back a
+    // trip ahead, IN FRONT of the node loads of the trip after it, and are only consumed here:
+    // the wait for them leaves the younger node loads in flight.  (With the gather inside the
+    // kept-test branch of every point, each was followed by a wait for everything in flight —
+    // three L2 round trips in a row per trip and, behind the node loads, an HBM one: stage 1 was
+    // 103 k cycles per scan.)
+    const float2 me0 = point_from(c0, g0), me1 = point_from(c1, g1);
+    float2 meh = make_float2(far, far);
+    if (halo_wave) meh = point_from(ch, gh);  // (the eight halo lanes live in wave 0)
+    c0 = n0;  // nodes of trip t + 1 (loaded a trip ago)
+    c1 = n1;
+    g0 = cs_of(c0);
+    g1 = cs_of(c1);
+    if (halo_wave) {
+      ch = nh;
+      gh = cs_of(ch);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    n0 = load_node(i0 + 2u * kSpan);  // nodes of trip t + 2
     n1 = load_node(i1 + 2u * kSpan);
-    nh = load_node(halo_index(base + 2u * kSpan));
-    p0 = point_of(c0);                               // points of trip t + 1: gathers issued now
-    p1 = point_of(c1);
-    ph = point_of(ch);
+    if (halo_wave) nh = load_node(halo_index(base + 2u * kSpan));
+    __builtin_amdgcn_sched_barrier(0);
     L.win[kRorNear + threadIdx.x] = me0;
     L.win[kRorNear + kBlock + threadIdx.x] = me1;
     if (threadIdx.x < (uint32_t)kRorNear) L.win[threadIdx.x] = meh;
@@ -140,11 +185,9 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
       const float2 me = h ? me1 : me0;
       const uint32_t i = h ? i1 : i0;
       const int j = 2 * t + h;  // bit j of kept / keep: sample 1024 j + thread
-      if (me.x == me.x) {       // kept (not NaN)
+      if (me.x < 1.0e29f) {     // kept
         kept |= 1u << j;
-        ymin = fminf(ymin, me.y);
-        ymax = fmaxf(ymax, me.y);
-        uint32_t cnt = 0;
+        uint32_t outside = 0;   // one bit per neighbour: d2 > r2
         const int at = (int)(kRorNear + threadIdx.x) + h * kBlock;
 #pragma unroll
         for (int o = 1; o <= kRorNear; ++o) {
@@ -153,9 +196,10 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
             const float2 pc = L.win[at + (sgn ? -o : o)];
             const float dx = me.x - pc.x, dy = me.y - pc.y;
             const float d2 = dx * dx + dy * dy;  // products then sum (-ffp-contract=off)
-            cnt += (d2 <= r2) ? 1u : 0u;         // (false for a NaN neighbour)
+            outside = __builtin_amdgcn_alignbit(outside, __float_as_uint(r2 - d2), 31);
           }
         }
+        const uint32_t cnt = 2u * (uint32_t)kRorNear - (uint32_t)__builtin_popcount(outside);
         if (cnt >= need) {
           keep |= 1u << j;
         } else {  // unsettled: stage 1b / 2
@@ -166,18 +210,8 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
     }
     __syncthreads();
   }
-  ymin = fminf(ymin, __shfl_xor(ymin, 32, 64));  // (six steps of a butterfly)
-  ymax = fmaxf(ymax, __shfl_xor(ymax, 32, 64));
-#pragma unroll
-  for (int d = 16; d > 0; d >>= 1) {
-    ymin = fminf(ymin, __shfl_xor(ymin, d, 64));
-    ymax = fmaxf(ymax, __shfl_xor(ymax, d, 64));
-  }
-  if (lane == 0 && ymin <= ymax) {
-    atomicMin(&L.misc[0], f2ord(ymin));
-    atomicMax(&L.misc[1], f2ord(ymax));
-  }
   __syncthreads();
+  RPL_ROR_CLK(1);
   // ---- stage 1b: a wave per unsettled sample, the 64 samples before and after it -------------
   const uint32_t n_todo1 = L.misc[2];  // block-uniform
   if (n_todo1 != 0u && n_todo1 <= kRorTodo) {
@@ -210,10 +244,73 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
     }
     __syncthreads();
   }
+  RPL_ROR_CLK(2);
   // (a scan with more unsettled samples than the list holds skips 1b: stage 2 re-examines all)
   const uint32_t n_todo_all = n_todo1 <= kRorTodo ? L.misc[3] : n_todo1;  // block-uniform
   const uint16_t *todo = n_todo1 <= kRorTodo ? L.todo2 : L.todo;
-  if (n_todo_all != 0u) {
+  // A handful of leftovers (the usual case when there are any: isolated returns): every thread
+  // runs its own kept samples past them, instead of building the row structure for the whole scan
+  // (two passes and a sort: ~100 k cycles for what is typically one or two samples).
+  constexpr uint32_t kRorFew = 4;
+  if (n_todo_all != 0u && n_todo_all <= kRorFew) {
+    float2 *few = L.win;           // (stage 1 is over: its window is free)
+    uint32_t *few_cnt = L.tmp;     // hits per leftover
+    if (threadIdx.x < n_todo_all) {
+      few[threadIdx.x] = node_xy(scan[todo[threadIdx.x]], cs);
+      few_cnt[threadIdx.x] = 0u;
+    }
+    __syncthreads();
+    uint32_t hits[kRorFew] = {0u, 0u, 0u, 0u};
+    for (int j = 0; j < kIters; ++j) {
+      if ((kept >> j) & 1u) {
+        const uint32_t i = ((uint32_t)(j * kWaves) + wave) * 64u + lane;
+        const float2 pc = node_xy(scan[i], cs);
+#pragma unroll
+        for (uint32_t u = 0; u < kRorFew; ++u) {
+          if (u < n_todo_all) {  // (block-uniform)
+            const float2 me = few[u];
+            const float dx = me.x - pc.x, dy = me.y - pc.y;
+            const float d2 = dx * dx + dy * dy;
+            hits[u] += (i != (uint32_t)todo[u] && d2 <= r2) ? 1u : 0u;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kRorFew; ++u) {
+      if (u < n_todo_all) {
+        const uint32_t tot = wave_incl_scan_fast(hits[u]);  // (the wave's sum in lane 63)
+        if (lane == 63u && tot) atomicAdd(&few_cnt[u], tot);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < n_todo_all && few_cnt[threadIdx.x] >= need) {
+      const uint32_t i = todo[threadIdx.x];
+      atomicOr(&L.late[i >> 5], 1u << (i & 31u));
+    }
+  } else if (n_todo_all != 0u) {
+    // the y extent of the kept samples (only this path needs it: one more pass over the scan)
+    {
+      float ymin = __uint_as_float(0x7F800000u), ymax = __uint_as_float(0xFF800000u);
+      for (int j = 0; j < kIters; ++j) {
+        if ((kept >> j) & 1u) {
+          const uint32_t i = ((uint32_t)(j * kWaves) + wave) * 64u + lane;
+          const float y = node_xy(scan[i], cs).y;
+          ymin = fminf(ymin, y);
+          ymax = fmaxf(ymax, y);
+        }
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        ymin = fminf(ymin, __shfl_xor(ymin, d, 64));
+        ymax = fmaxf(ymax, __shfl_xor(ymax, d, 64));
+      }
+      if (lane == 0 && ymin <= ymax) {
+        atomicMin(&L.misc[0], f2ord(ymin));
+        atomicMax(&L.misc[1], f2ord(ymax));
+      }
+      __syncthreads();
+    }
     const float y0 = ord2f(L.misc[0]), y1 = ord2f(L.misc[1]);
     const float r = sqrtf(p.ror_r2);
     // rows at least 1.001 r high (points within r in y are at most one row apart) and few
@@ -250,6 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
       }
     }
     __syncthreads();
+    RPL_ROR_CLK(3);
     // ---- stage 2: one wave per unsettled sample, 64 candidates at a time ---------------------
     const uint32_t n_todo = min(n_todo_all, kRorTodo);
     for (uint32_t t = wave; t < n_todo; t += kWaves) {
@@ -301,22 +399,50 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
     }
   }
   __syncthreads();
-  // ---- one bit per sample: chunk c = j*16 + wave covers samples [64c, 64c+64) -------------
-  for (int j = 0; j < kIters; ++j) {
-    const uint32_t c = (uint32_t)(j * kWaves) + wave;
-    const uint64_t m = __ballot((keep >> j) & 1u) |
-                       ((uint64_t)L.late[2u * c] | ((uint64_t)L.late[2u * c + 1u] << 32));
-    if (lane == 0 && 2u * c < mask_stride) mask[2u * c] = (uint32_t)m;
-    if (lane == 1 && 2u * c + 1u < mask_stride) mask[2u * c + 1u] = (uint32_t)(m >> 32);
+  RPL_ROR_CLK(4);
+#ifdef RPL_ROR_DBG
+  if (n_todo_all == 0u) dbg_t[3] = dbg_t[2];
+  if (threadIdx.x == 0 && p.dbg) {
+    for (int d = 0; d < 4; ++d) p.dbg[(size_t)b * 16 + d] = dbg_t[d + 1] - dbg_t[d];
+    p.dbg[(size_t)b * 16 + 4] = n_todo1;
+    p.dbg[(size_t)b * 16 + 5] = n_todo_all;
   }
+#endif
+  // ---- one bit per sample: chunk c = j*16 + wave covers samples [64c, 64c+64) -------------
+  // (the stage-1 bits join the late bits in LDS — every lane of a wave ends up with one of the
+  // wave's 64 mask words — and the row of mask words leaves in one coalesced store)
+  static_assert(kIters == 32, "one mask word per lane: lanes 2j and 2j+1 take the ballot of bit j");
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < kIters; ++j) {
+    const uint64_t m = __ballot((keep >> j) & 1u);
+    if ((int)(lane >> 1) == j) mine = (lane & 1u) ? (uint32_t)(m >> 32) : (uint32_t)m;
+  }
+  atomicOr(&L.late[2u * ((lane >> 1) * (uint32_t)kWaves + wave) + (lane & 1u)], mine);
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < kMaxN / 32u && t < mask_stride; t += kBlock) mask[t] = L.late[t];
+#ifdef RPL_ROR_DBG
+  __syncthreads();
+  if (threadIdx.x == 0 && p.dbg) {
+    p.dbg[(size_t)b * 16 + 6] = dbg_t[0] - dbg_entry;                          // prologue
+    p.dbg[(size_t)b * 16 + 7] = __builtin_amdgcn_s_memtime() - dbg_t[4];       // mask write-out
+    p.dbg[(size_t)b * 16 + 8] = dbg_entry;                                     // (absolute: gaps between workgroups)
+    p.dbg[(size_t)b * 16 + 9] = __builtin_amdgcn_s_memtime();
+    p.dbg[(size_t)b * 16 + 10] = __builtin_amdgcn_s_getreg(((6 - 1) << 11) | (0 << 6) | 4) ;  // HW_ID
+  }
+#endif
 }
 
 hipError_t launch_ror_mask(hipStream_t s, const void *nodes, uint32_t n_stride,
                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                            const Tables &T, uint32_t *mask, uint32_t mask_stride) {
   if (B == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_ror_mask, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
-                     n_per_scan, p, T, mask, mask_stride);
+  if (p.fast_d4000)
+    hipLaunchKernelGGL(k_ror_mask<true>, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
+                       n_per_scan, p, T, mask, mask_stride);
+  else
+    hipLaunchKernelGGL(k_ror_mask<false>, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
+                       n_per_scan, p, T, mask, mask_stride);
   return hipGetLastError();
 }
 

@@ -142,6 +142,7 @@ rpl::KParams to_kparams(const rplgpu_params_t &p) {
   k.vox_bias = 0;  // (round 3: offsets are summed as wrapping two's complement, no bias)
   k.inv_leaf = 1.0f;
   k.fast_div = 0;
+  k.fast_d4000 = 0;
   k.dbg = nullptr;
   k.cell_keys = nullptr;
   k.d_lo = 1u;  // :584 alone: dist_mm_q2 != 0
@@ -667,6 +668,7 @@ static int32_t prepare_cloud(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, ui
     }
     kp.fast_div = (h->div4000_ok && h->leaf_ok) ? 1 : 0;
   }
+  kp.fast_d4000 = h->div4000_ok ? 1 : 0;
   kp.dbg = h->dbg;
   kp.cell_keys = h->cell_keys;
   *mask_out = nullptr;
