@@ -43,7 +43,9 @@ struct RorLds {
   uint16_t todo[kRorTodo];      // unsettled samples of stage 1
   uint16_t todo2[kRorTodo];     // ... still unsettled after the +-64 window of stage 1b
   uint32_t late[kMaxN / 32];    // keep bits found by stage 2 (bit i of word i/32)
-  float2 win[2 * kBlock + 2 * kRorNear];  // stage 1: (x, y) of the 2048 samples of a trip + halo
+  // stage 1: (x, y) of the 2048 samples of a trip + halo; two buffers, so that a trip needs ONE
+  // barrier (a wave may publish trip t + 1 while another still reads trip t)
+  float2 win[2][2 * kBlock + 2 * kRorNear];
 };
 
 // order-preserving float <-> uint map (for LDS atomicMin / atomicMax on floats)
@@ -175,31 +177,42 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
     n1 = load_node(i1 + 2u * kSpan);
     if (halo_wave) nh = load_node(halo_index(base + 2u * kSpan));
     __builtin_amdgcn_sched_barrier(0);
-    L.win[kRorNear + threadIdx.x] = me0;
-    L.win[kRorNear + kBlock + threadIdx.x] = me1;
-    if (threadIdx.x < (uint32_t)kRorNear) L.win[threadIdx.x] = meh;
-    else if (threadIdx.x < 2u * kRorNear) L.win[kSpan + threadIdx.x] = meh;
+    float2 *win = L.win[t & 1];
+    win[kRorNear + threadIdx.x] = me0;
+    win[kRorNear + kBlock + threadIdx.x] = me1;
+    if (threadIdx.x < (uint32_t)kRorNear) win[threadIdx.x] = meh;
+    else if (threadIdx.x < 2u * kRorNear) win[kSpan + threadIdx.x] = meh;
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const float2 me = h ? me1 : me0;
       const uint32_t i = h ? i1 : i0;
       const int j = 2 * t + h;  // bit j of kept / keep: sample 1024 j + thread
-      if (me.x < 1.0e29f) {     // kept
-        kept |= 1u << j;
-        uint32_t outside = 0;   // one bit per neighbour: d2 > r2
-        const int at = (int)(kRorNear + threadIdx.x) + h * kBlock;
+      const bool is_kept = me.x < 1.0e29f;
+      // the neighbours at +-1, +-2 first; the outer four only if some lane of the wave is still
+      // short (on ring-like scans with 10 % drop-outs: one wave pass in five)
+      uint32_t outside = 0;  // one bit per tested neighbour: d2 > r2
+      const int at = (int)(kRorNear + threadIdx.x) + h * kBlock;
+      auto test_ring = [&](int o) {
 #pragma unroll
-        for (int o = 1; o <= kRorNear; ++o) {
-#pragma unroll
-          for (int sgn = 0; sgn < 2; ++sgn) {
-            const float2 pc = L.win[at + (sgn ? -o : o)];
-            const float dx = me.x - pc.x, dy = me.y - pc.y;
-            const float d2 = dx * dx + dy * dy;  // products then sum (-ffp-contract=off)
-            outside = __builtin_amdgcn_alignbit(outside, __float_as_uint(r2 - d2), 31);
-          }
+        for (int sgn = 0; sgn < 2; ++sgn) {
+          const float2 pc = win[at + (sgn ? -o : o)];
+          const float dx = me.x - pc.x, dy = me.y - pc.y;
+          const float d2 = dx * dx + dy * dy;  // products then sum (-ffp-contract=off)
+          outside = __builtin_amdgcn_alignbit(outside, __float_as_uint(r2 - d2), 31);
         }
-        const uint32_t cnt = 2u * (uint32_t)kRorNear - (uint32_t)__builtin_popcount(outside);
+      };
+      static_assert(kRorNear == 4, "two rounds of two rings");
+      test_ring(1);
+      test_ring(2);
+      uint32_t cnt = 4u - (uint32_t)__builtin_popcount(outside);
+      if (__builtin_amdgcn_ballot_w64(is_kept && cnt < need) != 0ull) {  // (wave-uniform)
+        test_ring(3);
+        test_ring(4);
+        cnt = 8u - (uint32_t)__builtin_popcount(outside);
+      }
+      if (is_kept) {
+        kept |= 1u << j;
         if (cnt >= need) {
           keep |= 1u << j;
         } else {  // unsettled: stage 1b / 2
@@ -208,7 +221,6 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
         }
       }
     }
-    __syncthreads();
   }
   __syncthreads();
   RPL_ROR_CLK(1);
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   // (two passes and a sort: ~100 k cycles for what is typically one or two samples).
   constexpr uint32_t kRorFew = 4;
   if (n_todo_all != 0u && n_todo_all <= kRorFew) {
-    float2 *few = L.win;           // (stage 1 is over: its window is free)
+    float2 *few = L.win[0];        // (stage 1 is over: its window is free)
     uint32_t *few_cnt = L.tmp;     // hits per leftover
     if (threadIdx.x < n_todo_all) {
       few[threadIdx.x] = node_xy(scan[todo[threadIdx.x]], cs);
