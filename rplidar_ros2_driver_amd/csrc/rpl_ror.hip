@@ -34,8 +34,15 @@ constexpr uint32_t kRorRows = 2048;
 constexpr uint32_t kRorTodo = 8192;  // unsettled samples stage 2 can take (else: next round)
 constexpr int kRorNear = 4;          // stage 1 looks at samples i-4 .. i+4
 
+constexpr int kRorPer = 2;           // stage 1: samples per thread and trip (4: measured slower, 46 k against 42 k cycles)
+constexpr uint32_t kRorSpan = (uint32_t)kRorPer * kBlock;
+constexpr uint32_t kRorWin = kRorSpan + 2u * kRorNear;  // a trip's samples + halo
+
 struct RorLds {
-  uint16_t idx[kMaxN];          // sample indices grouped by row
+  // stage 2: sample indices grouped by row (uint16_t[kMaxN]); stage 1 (over by then): two windows
+  // of (x, y) — the samples of a trip + halo; two of them, so that a trip needs ONE barrier (a
+  // wave may publish trip t + 1 while another still reads trip t)
+  alignas(16) unsigned char idx_or_win[2 * kRorWin * 8 > kMaxN * 2 ? 2 * kRorWin * 8 : kMaxN * 2];
   uint32_t rowstart[kRorRows];  // first slot of a row
   uint32_t rowfill[kRorRows];   // one past its last slot (after the scatter)
   uint32_t misc[8];             // 0/1 ymin/ymax (order-preserving uint encoding), 2 #unsettled
@@ -43,9 +50,6 @@ struct RorLds {
   uint16_t todo[kRorTodo];      // unsettled samples of stage 1
   uint16_t todo2[kRorTodo];     // ... still unsettled after the +-64 window of stage 1b
   uint32_t late[kMaxN / 32];    // keep bits found by stage 2 (bit i of word i/32)
-  // stage 1: (x, y) of the 2048 samples of a trip + halo; two buffers, so that a trip needs ONE
-  // barrier (a wave may publish trip t + 1 while another still reads trip t)
-  float2 win[2][2 * kBlock + 2 * kRorNear];
 };
 
 // order-preserving float <-> uint map (for LDS atomicMin / atomicMax on floats)
@@ -73,6 +77,8 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
                                                      uint32_t *__restrict__ mask_out,
                                                      uint32_t mask_stride) {
   __shared__ RorLds L;
+  uint16_t *const L_idx = reinterpret_cast<uint16_t *>(L.idx_or_win);
+  float2 *const L_win = reinterpret_cast<float2 *>(L.idx_or_win);
 #ifdef RPL_ROR_DBG
   const unsigned long long dbg_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -119,10 +125,10 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   // (v_alignbit) and counted once — a compare, a select and the bit assembly per neighbour less.
   const float far = 1.0e30f;
   auto load_node = [&](uint32_t q) -> uint2 { return q < n ? scan[q] : make_uint2(0u, 0u); };  // dist 0: dropped
-  constexpr uint32_t kSpan = 2u * kBlock;
+  constexpr uint32_t kSpan = kRorSpan;
   const int trips = (int)((n + kSpan - 1u) / kSpan);  // block-uniform
-  // software pipeline: raw nodes two trips ahead, points (the table gather) one trip ahead; the
-  // eight halo samples are a third slot of threads 0..7 and ride the same pipeline
+  // software pipeline: raw nodes two trips ahead, the table gathers one trip ahead; the eight halo
+  // samples are one more slot of threads 0..7 and ride the same pipeline
   // (thread 3's offset base - 1 is 0xFFFFFFFF as a number: "no halo duty" is a flag of its own,
   // not a sentinel value of the offset)
   const bool has_halo = threadIdx.x < 2u * kRorNear;
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   };
   // gathered (cos, sin) of a node: always a valid table index, whatever the node holds
   auto cs_of = [&](uint2 c) -> float2 { return cs[nd_q14(c)]; };
-  // the point of a node from its gathered (cos, sin): node_xy's arithmetic (E2), NaN if not kept
+  // the point of a node from its gathered (cos, sin): node_xy's arithmetic (E2), `far` if not kept
   auto point_from = [&](uint2 c, float2 g) -> float2 {
     const float df = __uint2float_rn(nd_dist(c));
     float dm;  // :590
@@ -149,46 +155,56 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
     return make_float2(k ? dm * g.x : far, k ? dm * g.y : far);
   };
   // nodes of trip 0 and their table entries, nodes of trip 1
-  uint2 c0 = load_node(threadIdx.x), c1 = load_node(kBlock + threadIdx.x), ch = load_node(halo_index(0u));
-  float2 g0 = cs_of(c0), g1 = cs_of(c1), gh = cs_of(ch);
-  uint2 n0 = load_node(kSpan + threadIdx.x), n1 = load_node(kSpan + kBlock + threadIdx.x);
+  uint2 c[kRorPer], nx[kRorPer], ch = load_node(halo_index(0u));
+  float2 g[kRorPer], gh = cs_of(ch);
+#pragma unroll
+  for (int h = 0; h < kRorPer; ++h) {
+    c[h] = load_node((uint32_t)h * kBlock + threadIdx.x);
+    g[h] = cs_of(c[h]);
+  }
+#pragma unroll
+  for (int h = 0; h < kRorPer; ++h) nx[h] = load_node(kSpan + (uint32_t)h * kBlock + threadIdx.x);
   uint2 nh = load_node(halo_index(kSpan));
   for (int t = 0; t < trips; ++t) {
-    const uint32_t base = (uint32_t)t * kSpan, i0 = base + threadIdx.x, i1 = i0 + kBlock;
-    // Vector loads return in order.  The three table gathers of a trip are issued back to back a
-    // trip ahead, IN FRONT of the node loads of the trip after it, and are only consumed here:
-    // the wait for them leaves the younger node loads in flight.  (With the gather inside the
+    const uint32_t base = (uint32_t)t * kSpan;
+    // Vector loads return in order.  The table gathers of a trip are issued back to back a trip
+    // ahead, IN FRONT of the node loads of the trip after it, and are only consumed here: the
+    // wait for them leaves the younger node loads in flight.  (With the gather inside the
     // kept-test branch of every point, each was followed by a wait for everything in flight —
     // three L2 round trips in a row per trip and, behind the node loads, an HBM one: stage 1 was
     // 103 k cycles per scan.)
-    const float2 me0 = point_from(c0, g0), me1 = point_from(c1, g1);
+    float2 me[kRorPer];
+#pragma unroll
+    for (int h = 0; h < kRorPer; ++h) me[h] = point_from(c[h], g[h]);
     float2 meh = make_float2(far, far);
     if (halo_wave) meh = point_from(ch, gh);  // (the eight halo lanes live in wave 0)
-    c0 = n0;  // nodes of trip t + 1 (loaded a trip ago)
-    c1 = n1;
-    g0 = cs_of(c0);
-    g1 = cs_of(c1);
+#pragma unroll
+    for (int h = 0; h < kRorPer; ++h) {
+      c[h] = nx[h];  // nodes of trip t + 1 (loaded a trip ago)
+      g[h] = cs_of(c[h]);
+    }
     if (halo_wave) {
       ch = nh;
       gh = cs_of(ch);
     }
     __builtin_amdgcn_sched_barrier(0);
-    n0 = load_node(i0 + 2u * kSpan);  // nodes of trip t + 2
-    n1 = load_node(i1 + 2u * kSpan);
+#pragma unroll
+    for (int h = 0; h < kRorPer; ++h)  // nodes of trip t + 2
+      nx[h] = load_node(base + 2u * kSpan + (uint32_t)h * kBlock + threadIdx.x);
     if (halo_wave) nh = load_node(halo_index(base + 2u * kSpan));
     __builtin_amdgcn_sched_barrier(0);
-    float2 *win = L.win[t & 1];
-    win[kRorNear + threadIdx.x] = me0;
-    win[kRorNear + kBlock + threadIdx.x] = me1;
+    float2 *win = L_win + (size_t)(t & 1) * kRorWin;
+#pragma unroll
+    for (int h = 0; h < kRorPer; ++h) win[kRorNear + h * kBlock + threadIdx.x] = me[h];
     if (threadIdx.x < (uint32_t)kRorNear) win[threadIdx.x] = meh;
     else if (threadIdx.x < 2u * kRorNear) win[kSpan + threadIdx.x] = meh;
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float2 me = h ? me1 : me0;
-      const uint32_t i = h ? i1 : i0;
-      const int j = 2 * t + h;  // bit j of kept / keep: sample 1024 j + thread
-      const bool is_kept = me.x < 1.0e29f;
+    for (int h = 0; h < kRorPer; ++h) {
+      const float2 m = me[h];
+      const uint32_t i = base + (uint32_t)h * kBlock + threadIdx.x;
+      const int j = kRorPer * t + h;  // bit j of kept / keep: sample 1024 j + thread
+      const bool is_kept = m.x < 1.0e29f;
       // the neighbours at +-1, +-2 first; the outer four only if some lane of the wave is still
       // short (on ring-like scans with 10 % drop-outs: one wave pass in five)
       uint32_t outside = 0;  // one bit per tested neighbour: d2 > r2
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
 #pragma unroll
         for (int sgn = 0; sgn < 2; ++sgn) {
           const float2 pc = win[at + (sgn ? -o : o)];
-          const float dx = me.x - pc.x, dy = me.y - pc.y;
+          const float dx = m.x - pc.x, dy = m.y - pc.y;
           const float d2 = dx * dx + dy * dy;  // products then sum (-ffp-contract=off)
           outside = __builtin_amdgcn_alignbit(outside, __float_as_uint(r2 - d2), 31);
         }
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   // (two passes and a sort: ~100 k cycles for what is typically one or two samples).
   constexpr uint32_t kRorFew = 4;
   if (n_todo_all != 0u && n_todo_all <= kRorFew) {
-    float2 *few = L.win[0];        // (stage 1 is over: its window is free)
+    float2 *few = L_win;           // (stage 1 is over: its window is free)
     uint32_t *few_cnt = L.tmp;     // hits per leftover
     if (threadIdx.x < n_todo_all) {
       few[threadIdx.x] = node_xy(scan[todo[threadIdx.x]], cs);
@@ -355,7 +371,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
       if ((kept >> j) & 1u) {
         const uint32_t i = ((uint32_t)(j * kWaves) + wave) * 64u + lane;
         const uint32_t pos = atomicAdd(&L.rowfill[row_of(node_xy(scan[i], cs).y)], 1u);
-        L.idx[pos] = (uint16_t)i;
+        L_idx[pos] = (uint16_t)i;
       }
     }
     __syncthreads();
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
         const uint32_t q = q0 + lane;
         bool hit = false;
         if (q < e) {
-          const uint32_t jc = L.idx[q];
+          const uint32_t jc = L_idx[q];
           const float2 pc = node_xy(scan[jc], cs);
           const float dx = me.x - pc.x, dy = me.y - pc.y;
           const float d2 = dx * dx + dy * dy;
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
           const uint32_t e = L.rowfill[min(row + 1u, kRorRows - 1u)];
           uint32_t cnt = 0;
           for (uint32_t q = a; q < e && cnt < need; ++q) {
-            const uint32_t jc = L.idx[q];
+            const uint32_t jc = L_idx[q];
             const float2 pc = node_xy(scan[jc], cs);
             const float dx = me.x - pc.x, dy = me.y - pc.y;
             const float d2 = dx * dx + dy * dy;
