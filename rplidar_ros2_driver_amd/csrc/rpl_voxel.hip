@@ -1192,6 +1192,11 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
     if (p.cell_range_safe) RPL_LAUNCH_VOXEL(FD, true, DB, SP); else RPL_LAUNCH_VOXEL(FD, false, DB, SP); \
   } while (0)
   if (p.dbg) {  // developer aid: the instrumented build of the kernel (plain instance only)
+#ifdef RPL_VOXEL_DBG_SPLIT  // (developer build: the instrumented two-class instance as well)
+    if (T.voxel_split) {
+      RPL_LAUNCH_VOXEL_SF(true, true, true);
+    } else
+#endif
     if (p.fast_div) RPL_LAUNCH_VOXEL_SF(true, true, false); else RPL_LAUNCH_VOXEL_SF(false, true, false);
   } else if (T.voxel_split) {  // the handle's previous launch saw a noisy batch
     if (p.fast_div) RPL_LAUNCH_VOXEL_SF(true, false, true); else RPL_LAUNCH_VOXEL_SF(false, false, true);
