@@ -646,6 +646,68 @@ def test_hip_path_matches_genuine_reference_large(gpu, name):
     assert canon.check_large_golden(g, name, CASES[name], asc, ls) == 12
 
 
+@pytest.mark.parametrize("n", [700, 20000, 32000])
+def test_laserscan_far_distances(gpu, oracle, n):
+    """Distances far beyond anything a lidar reports: above 2^24 two dist_mm_q2 values may share a
+    float, and the reference compares the floats (the winner of a bin is the first of equal
+    dist_m in angle order).  Just below 2^22, around it, around 2^24, at the top of the u32 range,
+    and a scan where every kept sample is that far — against the oracle, bit for bit; then the
+    same scans through the batch entry point, more of them than compute units, next to ordinary
+    and empty ones in every order of succession."""
+    rng = np.random.default_rng(900 + n)
+    base = synth.make_scan(31, n, n, invalid_p=0.05, kind="ring", r0_range=(2.0, 20.0))
+    variants = {}
+    near = base.copy()  # just below the seam
+    near["dist_mm_q2"][rng.integers(0, n, 40)] = (1 << 22) - 1 - rng.integers(0, 3, 40)
+    variants["below"] = near
+    far = base.copy()   # a few samples at / beyond the seam, some sharing a float (spacing 1 above 2^24)
+    k = rng.integers(0, n, 64)
+    far["dist_mm_q2"][k[:16]] = (1 << 22) + rng.integers(0, 4, 16)
+    far["dist_mm_q2"][k[16:40]] = (1 << 24) + rng.integers(0, 6, 24)
+    far["dist_mm_q2"][k[40:]] = np.uint32(0xFFFFFFF0) + rng.integers(0, 15, 24).astype(np.uint32)
+    variants["beyond"] = far
+    allfar = base.copy()  # every kept sample far, many equal floats in a bin
+    nz = allfar["dist_mm_q2"] != 0
+    allfar["dist_mm_q2"][nz] = (1 << 25) + (rng.integers(0, 8, int(nz.sum())) & ~np.uint32(1))
+    variants["all_far"] = allfar
+    for name, nodes in variants.items():
+        for inverted in (0, 1):
+            p = Params.defaults(is_new_protocol=1, inverted=inverted, scan_processing=1,
+                                clip_enable=0, range_max=40.0)
+            wr, wi, wm = oracle.publish_scan(nodes, oracle_lib.copy_params(p), 0.1)
+            gr, gi, gm = gpu.scan_to_laserscan(nodes, p, 0.1)
+            assert bytes(gm) == bytes(wm), name
+            assert gr.tobytes() == wr.tobytes(), name
+            if not _has_intensity_tie(nodes, p):
+                assert gi.tobytes() == wi.tobytes(), name
+    if n != 700:
+        return
+    # batch: more scans than compute units — ordinary, far, empty, all far, just below
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    kinds = [base, variants["beyond"], np.zeros(n, NODE_DTYPE), variants["all_far"], variants["below"]]
+    B = 5 * 256 + 7
+    which = [(i // 256 + 3 * (i % 256)) % 5 for i in range(B)]
+    p = Params.defaults(is_new_protocol=1, scan_processing=1, clip_enable=0, range_max=40.0)
+    h = np.zeros((B, n), NODE_DTYPE)
+    for i, kd in enumerate(which):
+        h[i] = kinds[kd]
+    d_nodes = torch.from_numpy(h.view(np.uint8).reshape(B, n * 8)).to(dev)
+    d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
+    d_r = torch.zeros(B, n, dtype=torch.float32, device=dev)
+    d_i = torch.zeros(B, n, dtype=torch.float32, device=dev)
+    d_c = torch.zeros(B, dtype=torch.int32, device=dev)
+    gpu.laserscan_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_r.data_ptr(),
+                            d_i.data_ptr(), d_c.data_ptr())
+    gpu.synchronize()
+    want = [oracle.publish_scan(kd, oracle_lib.copy_params(p), 0.1) for kd in kinds]
+    cnt, rr = d_c.cpu().numpy(), d_r.cpu().numpy()
+    for i, kd in enumerate(which):
+        wr, _, wm = want[kd]
+        assert int(cnt[i]) == wm.count, i
+        assert rr[i, :wm.count].tobytes() == wr[:wm.count].tobytes(), i
+
+
 def test_mode_a_tie_rule(gpu, oracle):
     """The reference keeps the first minimum in std::sort order (:657), i.e. introsort decides
     among samples of one bin with identical dist_m.  The device rule is stated, deterministic
