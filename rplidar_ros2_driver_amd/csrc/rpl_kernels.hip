@@ -199,6 +199,12 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
   __shared__ SortLds s_sort;
   if (SORT) {
     const uint32_t count = need_sort[0];
+    // A grid of ONE workgroup (the single-scan call) leaves the list empty for the next call
+    // itself, so that such a call needs no clearing command in front of it.
+    if (gridDim.x == 1u) {
+      __syncthreads();  // (every thread has read the count)
+      if (threadIdx.x == 0) need_sort[0] = 0u;
+    }
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
       ascend_one<SORT>(need_sort[1u + k], nodes, n_stride, n_per_scan, status, need_sort, s_keys,
                        s_misc, s_sort);
@@ -617,7 +623,10 @@ __global__ __launch_bounds__(256) void k_pack(const float4 *__restrict__ xyzi, u
 hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
                          uint32_t B, uint32_t *status, uint32_t *need_sort) {
   if (B == 0) return hipSuccess;
-  if (hipError_t e = hipMemsetAsync(need_sort, 0, 4, s); e != hipSuccess) return e;
+  // (the list of unsorted scans starts empty: cleared when the handle is created and, after a
+  // single-scan call, by the sorting kernel itself; batches clear it here)
+  if (B != 1u)
+    if (hipError_t e = hipMemsetAsync(need_sort, 0, 4, s); e != hipSuccess) return e;
   // A handful of LONG scans (the single-scan seam above the SDK's 8192-node cap): latency counts,
   // and one 1024-thread workgroup that holds the scan in registers finishes a 32 000-sample scan in
   // a quarter less time than one 256-thread workgroup streaming it (46 vs 62 us per call; at 360
@@ -630,6 +639,8 @@ hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const ui
                        status, need_sort);
   hipLaunchKernelGGL(k_ascend<true>, dim3(std::min<uint32_t>(B, 256u)), dim3(kBlock), 0, s,
                      (uint2 *)nodes, n_stride, n_per_scan, status, need_sort);
+  if (B != 1u)  // (invariant between calls: the list is empty)
+    if (hipError_t e = hipMemsetAsync(need_sort, 0, 4, s); e != hipSuccess) return e;
   return hipGetLastError();
 }
 

@@ -1103,6 +1103,7 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       if (status) status[b] = L.misc[1] | ((total > out_stride) ? RPLGPU_SCAN_OUT_TRUNCATED : 0u);
     }
   }
+  if (B <= gridDim.x) return;  // a workgroup per item (single scans, small batches): no queue
   if (threadIdx.x == 0) L.tmp[31] = gridDim.x + atomicAdd(&T.work_ctr[0], 1u);
   __syncthreads();  // LDS is reused by the next scan
   b = L.tmp[31];
@@ -1176,7 +1177,10 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
     const long g = std::atol(e);
     if (g > 0) grid = std::min<uint32_t>(grid, (uint32_t)g);
   }
-  if (hipError_t e = hipMemsetAsync(T.work_ctr, 0, 4, s); e != hipSuccess) return e;
+  // (a launch with a workgroup per item does not touch the queue: one command less in front of a
+  // single-scan call)
+  if (grid < B)
+    if (hipError_t e = hipMemsetAsync(T.work_ctr, 0, 4, s); e != hipSuccess) return e;
   // queue statistics of the launch (they pick the NEXT launch's instance): batches only
   const bool with_stats = T.voxel_stats && T.voxel_stats_host && B >= 64u;
   Tables Tk = T;

@@ -529,6 +529,10 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
     return fail(RPLGPU_ERR_HIP);
   }
   c->need_sort_cap = c->max_b;
+  if (hipMemset(c->d_need_sort, 0, 4) != hipSuccess) {  // (the list starts, and is kept, empty between calls)
+    c->err = "staging allocation failed";
+    return fail(RPLGPU_ERR_HIP);
+  }
   // the voxel kernel's record stores (overflow of its LDS queue; 512 KiB per resident workgroup,
   // at most two workgroups per CU and never more than scans in a batch)
   c->vstore_wgs = std::min<uint32_t>(c->max_b, rpl::voxel_max_workgroups(c->n_cu));

@@ -1,12 +1,14 @@
 """Developer aid: phase cycle breakdown of k_cloud_voxel on the bench workload."""
 import ctypes as C
+import os
 import sys
 import numpy as np
 import torch
 sys.path.insert(0, ".")
 from rplidar_ros2_driver_amd import Params, RplGpu, synth, abi
 
-B, n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 32000
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n = int(os.environ.get('RPL_VOXDBG_N', '32000')) if True else 32000
 NOISE = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 import os
 R0MAX = float(os.environ.get('RPL_VOXDBG_R0MAX', '30'))
