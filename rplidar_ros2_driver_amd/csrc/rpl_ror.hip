@@ -240,8 +240,51 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   }
   __syncthreads();
   RPL_ROR_CLK(1);
+  uint32_t n_todo1 = L.misc[2];  // block-uniform
+  // ---- a short scan (A1-class: 360 ... 1024 samples) still has ALL its points in the stage-1
+  // window: every unsettled sample is
+  // settled right here, exhaustively and from LDS — a wave per sample, 64 candidates at a time —
+  // instead of going through stages 1b and 2 (a 360-sample scan, where nearly every point is
+  // farther than r from its index neighbours, spent ~100 k cycles building the row structure).
+  // (only for really short scans, <= 1024 samples: a true outlier walks ALL blocks of 64
+  // candidates, ~120 cycles each; at 3200 samples the stages below — two block steps per sample in
+  // 1b, then the handful of leftovers against every thread's samples — are the cheaper way: 52
+  // against 68 us per call)
+  if (n <= 1024u && n_todo1 != 0u && n_todo1 <= kRorTodo) {
+    auto point = [&](uint32_t q) -> float2 {
+      return L_win[(q < kSpan ? 0u : kRorWin) + kRorNear + (q & (kSpan - 1u))];
+    };
+    static_assert((kRorSpan & (kRorSpan - 1u)) == 0u, "the window index is a mask");
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    for (uint32_t t = wave_u; t < n_todo1; t += kWaves) {
+      const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.todo[t]);  // (scalar)
+      const float2 me = point(i);
+      uint32_t cnt = 0;
+      // (blocks of 64 candidates, the sample's own block first and then outwards on both sides:
+      // what can be settled at all is settled within a step or two)
+      const uint32_t nblk = (n + 63u) >> 6, bi = i >> 6;
+      auto hits_in = [&](uint32_t blk) -> uint32_t {
+        const uint32_t q = blk * 64u + lane;
+        bool hit = false;
+        if (q < n && q != i) {
+          const float2 pc = point(q);  // (a sample that is not kept sits 1e30 m away)
+          const float dx = me.x - pc.x, dy = me.y - pc.y;
+          const float d2 = dx * dx + dy * dy;
+          hit = d2 <= r2;
+        }
+        return (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit));
+      };
+      cnt = hits_in(bi);
+      for (uint32_t d = 1; d < nblk && cnt < need; ++d) {
+        if (bi + d < nblk) cnt += hits_in(bi + d);
+        if (d <= bi) cnt += hits_in(bi - d);
+      }
+      if (lane == 0 && cnt >= need) atomicOr(&L.late[i >> 5], 1u << (i & 31u));
+    }
+    __syncthreads();
+    n_todo1 = 0u;  // (settled: nothing goes on to the stages below)
+  }
   // ---- stage 1b: a wave per unsettled sample, the 64 samples before and after it -------------
-  const uint32_t n_todo1 = L.misc[2];  // block-uniform
   if (n_todo1 != 0u && n_todo1 <= kRorTodo) {
     for (uint32_t t = wave; t < n_todo1; t += kWaves) {
       const uint32_t i = L.todo[t];
