@@ -123,7 +123,7 @@ class ScanPath {
   bool ready() const { return h_ != nullptr; }
   // One scan per call pays a fixed ~21 us (launch + completion flag over PCIe) whatever its size;
   // the reference's loop needs ~7 us for the 360 samples of an A1 and overtakes the device path
-  // below ~3000 samples.  Scans shorter than `n` are DECLINED:
+  // below ~1700 samples.  Scans shorter than `n` are DECLINED:
   // fill_laser_scan / fill_point_cloud2 return false with last_error() set, i.e. the caller's own
   // CPU loop runs, exactly as after a device error.  0 (the default) declines nothing.
   void set_min_samples(uint32_t n) { min_samples_ = n; }
