@@ -187,13 +187,15 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
                                            const uint32_t *__restrict__ n_per_scan,
                                            uint32_t *__restrict__ status,
                                            uint32_t *__restrict__ need_sort, uint32_t *s_keys,
-                                           uint32_t *s_misc, SortLds &s_sort);
+                                           uint32_t *s_misc, SortLds &s_sort, uint32_t mark = 0u);
 
+// mark: a status bit the queueing kernels set on a scan they hand to the sorting kernel — a
+// single-scan call launches that kernel only when the bit came back (kAscendUnsorted, internal)
 template <bool SORT>
 __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, uint32_t n_stride,
                                                    const uint32_t *__restrict__ n_per_scan,
                                                    uint32_t *__restrict__ status,
-                                                   uint32_t *__restrict__ need_sort) {
+                                                   uint32_t *__restrict__ need_sort, uint32_t mark) {
   __shared__ uint32_t s_keys[kMaxN];
   __shared__ uint32_t s_misc[8];
   __shared__ SortLds s_sort;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
       __syncthreads();  // LDS is reused by the next scan
     }
   } else {
-    ascend_one<SORT>(blockIdx.x, nodes, n_stride, n_per_scan, status, need_sort, s_keys, s_misc, s_sort);
+    ascend_one<SORT>(blockIdx.x, nodes, n_stride, n_per_scan, status, need_sort, s_keys, s_misc, s_sort, mark);
   }
 }
 
@@ -220,7 +222,7 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
                                            const uint32_t *__restrict__ n_per_scan,
                                            uint32_t *__restrict__ status,
                                            uint32_t *__restrict__ need_sort, uint32_t *s_keys,
-                                           uint32_t *s_misc, SortLds &s_sort) {
+                                           uint32_t *s_misc, SortLds &s_sort, uint32_t mark) {
   const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   uint2 *scan = nodes + (size_t)b * n_stride;
 
@@ -300,7 +302,10 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
   if (!SORT) {
     const bool unsorted = keys_unsorted(s_keys, n, &s_misc[2]);
     // not ascending: queue the scan for the sorting kernel (need_sort[0] = count, then the list)
-    if (threadIdx.x == 0 && unsorted) need_sort[1u + atomicAdd(&need_sort[0], 1u)] = b;
+    if (threadIdx.x == 0 && unsorted) {
+      need_sort[1u + atomicAdd(&need_sort[0], 1u)] = b;
+      if (mark && status) status[b] |= mark;
+    }
     if (!unsorted) {  // already ascending: only the filled angles move
 #pragma unroll
       for (int j = 0; j < kIters; ++j)
@@ -345,7 +350,7 @@ typedef uint32_t asc_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nodes, uint32_t n_stride,
                                                          const uint32_t *__restrict__ n_per_scan,
                                                          uint32_t *__restrict__ status,
-                                                         uint32_t *__restrict__ need_sort) {
+                                                         uint32_t *__restrict__ need_sort, uint32_t mark) {
   __shared__ uint32_t s_misc[4];                  // 0 first valid, 1 front word, 2 not ascending
   __shared__ uint32_t s_edge[2 * (kMaxN / 128)];  // first / last angle word of every 128-sample chunk
   const uint32_t b = blockIdx.x;
@@ -440,7 +445,10 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
   if (__builtin_amdgcn_ballot_w64(bad != 0u) && lane_id() == 0u) atomicOr(&s_misc[2], 1u);
   __syncthreads();
   // not ascending: queue the scan for the sorting kernel (need_sort[0] = count, then the list)
-  if (threadIdx.x == 0 && s_misc[2]) need_sort[1u + atomicAdd(&need_sort[0], 1u)] = b;
+  if (threadIdx.x == 0 && s_misc[2]) {
+    need_sort[1u + atomicAdd(&need_sort[0], 1u)] = b;
+    if (mark && status) status[b] |= mark;
+  }
 }
 
 // ------------------------------------------------------------------------------
@@ -621,24 +629,37 @@ __global__ __launch_bounds__(256) void k_pack(const float4 *__restrict__ xyzi, u
 // host-side launchers (declared in rpl_launch.hpp)
 // ------------------------------------------------------------------------------
 hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
-                         uint32_t B, uint32_t *status, uint32_t *need_sort) {
+                         uint32_t B, uint32_t *status, uint32_t *need_sort, bool defer_sort) {
   if (B == 0) return hipSuccess;
   // (the list of unsorted scans starts empty: cleared when the handle is created and, after a
   // single-scan call, by the sorting kernel itself; batches clear it here)
   if (B != 1u)
     if (hipError_t e = hipMemsetAsync(need_sort, 0, 4, s); e != hipSuccess) return e;
+  // defer_sort (single-scan calls that can read the status word back): the scan is only marked
+  // (kAscendUnsorted) and the caller launches launch_ascend_sort when it sees the mark — the
+  // sorting kernel is a 1024-thread, 128 KiB workgroup that a sorted scan (the usual case)
+  // launched for nothing, 2 us of the call
+  const uint32_t mark = (defer_sort && B == 1u) ? kAscendUnsorted : 0u;
   // A handful of LONG scans (the single-scan seam above the SDK's 8192-node cap): latency counts,
   // and one 1024-thread workgroup that holds the scan in registers finishes a 32 000-sample scan in
   // a quarter less time than one 256-thread workgroup streaming it (46 vs 62 us per call; at 360
   // samples the streaming kernel is the faster one, 18 vs 24 us); batches stream.
   if (B <= 8u && n_stride > 8192u)
     hipLaunchKernelGGL(k_ascend<false>, dim3(B), dim3(kBlock), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
-                       status, need_sort);
+                       status, need_sort, mark);
   else
     hipLaunchKernelGGL(k_ascend_stream, dim3(B), dim3(kAscT), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
-                       status, need_sort);
+                       status, need_sort, mark);
+  if (mark) return hipGetLastError();
+  return launch_ascend_sort(s, nodes, n_stride, n_per_scan, B, status, need_sort);
+}
+
+// the sorting kernel over the list the kernels above left (second half of launch_ascend)
+hipError_t launch_ascend_sort(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
+                              uint32_t B, uint32_t *status, uint32_t *need_sort) {
+  if (B == 0) return hipSuccess;
   hipLaunchKernelGGL(k_ascend<true>, dim3(std::min<uint32_t>(B, 256u)), dim3(kBlock), 0, s,
-                     (uint2 *)nodes, n_stride, n_per_scan, status, need_sort);
+                     (uint2 *)nodes, n_stride, n_per_scan, status, need_sort, 0u);
   if (B != 1u)  // (invariant between calls: the list is empty)
     if (hipError_t e = hipMemsetAsync(need_sort, 0, 4, s); e != hipSuccess) return e;
   return hipGetLastError();

@@ -15,8 +15,13 @@ struct Prefix;
 namespace rpl {
 
 // `need_sort`: B + 1 words of scratch (how many / which scans the second, sorting kernel has to redo)
+// status bit of a scan that launch_ascend(..., defer_sort) left for launch_ascend_sort (internal: the
+// sorting kernel rewrites the status word without it)
+constexpr uint32_t kAscendUnsorted = 0x80000000u;
 hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
-                         uint32_t B, uint32_t *status, uint32_t *need_sort);
+                         uint32_t B, uint32_t *status, uint32_t *need_sort, bool defer_sort = false);
+hipError_t launch_ascend_sort(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
+                              uint32_t B, uint32_t *status, uint32_t *need_sort);
 // publish_scan Mode A (rpl_laserscan.hip); `fast`: the mul+2*FMA divides were validated
 hipError_t launch_laserscan_a(hipStream_t s, const void *nodes, uint32_t n_stride,
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,

@@ -801,10 +801,16 @@ int32_t rplgpu_ascend(rplgpu_handle_t h, rplgpu_node_t *nodes, size_t n, uint32_
     const ScanStage st = stage_scan(h, nodes, n);
     uint32_t *d_status = const_cast<uint32_t *>(st.d_n) + 1;
     RPL_HIP(h, rpl::launch_ascend(h->stream, const_cast<rplgpu_node_t *>(st.d_nodes), (uint32_t)n,
-                                  st.d_n, 1, d_status, h->d_small + 20));
+                                  st.d_n, 1, d_status, h->d_small + 20, /*defer_sort=*/true));
     if (int32_t wrc = wait_scan(h)) return wrc;
     uint32_t stw;
     std::memcpy(&stw, h->h_pin + n * 8 + 4, 4);
+    if (stw & rpl::kAscendUnsorted) {  // (rare: the filled angles do not ascend) the sorting kernel after all
+      RPL_HIP(h, rpl::launch_ascend_sort(h->stream, const_cast<rplgpu_node_t *>(st.d_nodes), (uint32_t)n,
+                                         st.d_n, 1, d_status, h->d_small + 20));
+      if (int32_t wrc = wait_scan(h)) return wrc;
+      std::memcpy(&stw, h->h_pin + n * 8 + 4, 4);
+    }
     const bool all_invalid = (stw & RPLGPU_SCAN_ALL_INVALID) != 0;
     if (!all_invalid) std::memcpy(nodes, h->h_pin, n * 8);
     if (sl_result) *sl_result = all_invalid ? 0x80008001u : 0u;
