@@ -49,12 +49,13 @@ __device__ __forceinline__ float ls_div(float a, float d, float rd) {
 // just covers it — for the scans a lidar really delivers (360 ... 8192 samples, one at a time)
 // 16 waves converting 32 mostly all-zero samples per lane were most of the kernel: 21 -> 16 us per
 // call at 360 samples, 24 -> 20 at 3200.
-template <bool FAST, int PAIRS>
+// MSG: the (single) scan goes straight into its serialised message (LsMsgOut, rpl_launch.hpp).
+template <bool FAST, int PAIRS, bool MSG>
 __global__ __launch_bounds__(kBlock) void k_laserscan_a(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, const float *__restrict__ inc_table, const float *__restrict__ rinc_table,
     float *__restrict__ ranges, float *__restrict__ intens, uint32_t *__restrict__ beam_count,
-    uint32_t n_given) {
+    uint32_t n_given, LsMsgOut mo) {
   __shared__ unsigned long long s_bins[kLsWin];
   __shared__ uint32_t s_cnt;
 
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
   const uint2 *scan = nodes + (size_t)b * n_stride;
   float *out_r = ranges + (size_t)b * n_stride;
   float *out_i = intens + (size_t)b * n_stride;
+  (void)mo;
 
   if (threadIdx.x == 0) s_cnt = 0u;
 #ifdef RPL_LS_DBG  // developer build: phase clocks of thread 0 (tools/dev/lsbench.py)
@@ -107,7 +109,29 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
   const uint32_t count = s_cnt;
   RPL_LS_CLK(1);  // loads + count
   if (threadIdx.x == 0) beam_count[b] = count;
+  if (MSG && threadIdx.x == 0) *mo.msg_len = count ? mo.P.len + 8u * count + 4u : 0u;
   if (count == 0) return;  // :611-613 nothing published
+  if (MSG) {
+    // the message around the arrays (k_msg_laserscan's part): prefix template, then the words
+    // that differ from scan to scan — stamp, the three count-dependent scalars with the
+    // reference's expressions (:635-638: fp64 divides, one rounding to float), both array lengths
+    uint32_t *msg = mo.msg;
+    for (uint32_t i = threadIdx.x; i < mo.P.len / 4u; i += kBlock) msg[i] = mo.P.words[i];
+    __syncthreads();  // the patches overwrite template words
+    if (threadIdx.x == 0) {
+      msg[mo.P.stamp_off / 4] = (uint32_t)mo.sec;
+      msg[mo.P.stamp_off / 4 + 1] = mo.nanosec;
+      const double denom = (double)count;
+      float *f = reinterpret_cast<float *>(msg + mo.P.a_off / 4);
+      f[2] = (float)((2.0 * M_PI) / denom);
+      f[3] = (float)(mo.scan_duration / denom);
+      f[4] = (float)mo.scan_duration;
+      msg[mo.P.b_off / 4] = count;
+      msg[mo.P.len / 4 + count] = count;  // intensities length word, right after ranges
+    }
+    out_r = reinterpret_cast<float *>(msg + mo.P.len / 4);
+    out_i = out_r + count + 1u;
+  }
 
   const float *lut = p.inverted ? T.angle_inv : T.angle;  // :588-599, :646-651
   // (float)(2*pi / (double)count), :635, and its reciprocal: the IEEE operations the host used
@@ -218,16 +242,27 @@ hipError_t launch_laserscan_a(hipStream_t s, const void *nodes, uint32_t n_strid
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                               const Tables &T, const float *inc_table, const float *rinc_table,
                               bool fast, float *ranges, float *intens, uint32_t *beam_count,
-                              uint32_t n_given) {
+                              uint32_t n_given, const LsMsgOut *msg_out) {
   if (B == 0) return hipSuccess;
   if (B != 1) n_given = 0xFFFFFFFFu;
   // the instance that just covers a single scan of known length (see the kernel's head)
   const uint32_t pairs_needed = n_given == 0xFFFFFFFFu ? (uint32_t)kLsPairs
                                                        : (std::min(n_given, kMaxN) + 2u * kBlock - 1u) / (2u * kBlock);
+  // (the message form exists for single scans on the validated fast path; the caller checks)
+  const bool to_msg = msg_out != nullptr;
+  if (to_msg && !(B == 1u && fast)) return hipErrorInvalidValue;
+  const LsMsgOut mo = to_msg ? *msg_out : LsMsgOut{};
 #define RPL_LAUNCH_LS(F, P)                                                                         \
-  hipLaunchKernelGGL((k_laserscan_a<F, P>), dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes,     \
-                     n_stride, n_per_scan, p, T, inc_table, rinc_table, ranges, intens, beam_count, \
-                     n_given)
+  do {                                                                                              \
+    if (F && to_msg)                                                                                \
+      hipLaunchKernelGGL((k_laserscan_a<F, P, F>), dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, \
+                         n_stride, n_per_scan, p, T, inc_table, rinc_table, ranges, intens,        \
+                         beam_count, n_given, mo);                                                  \
+    else                                                                                            \
+      hipLaunchKernelGGL((k_laserscan_a<F, P, false>), dim3(B), dim3(kBlock), 0, s,                \
+                         (const uint2 *)nodes, n_stride, n_per_scan, p, T, inc_table, rinc_table,   \
+                         ranges, intens, beam_count, n_given, mo);                                  \
+  } while (0)
 #define RPL_LAUNCH_LS_P(F)                      \
   do {                                          \
     if (pairs_needed <= 1u) RPL_LAUNCH_LS(F, 1);       \

@@ -7,6 +7,7 @@
 #include "rplgpu_msg.h"
 #include "rplgpu_comm.h"
 #include "rpl_device.hpp"
+#include "rpl_msg.hpp"
 
 namespace rplmsg {
 struct Prefix;
@@ -23,11 +24,24 @@ hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const ui
 hipError_t launch_ascend_sort(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
                               uint32_t B, uint32_t *status, uint32_t *need_sort);
 // publish_scan Mode A (rpl_laserscan.hip); `fast`: the mul+2*FMA divides were validated
+// A single scan straight into its serialised sensor_msgs/LaserScan (Mode A, validated fast
+// divides): the kernel writes the message prefix, patches stamp / scalars / array lengths and
+// flushes its bins to the two arrays' places inside the message — no ranges / intensities in HBM,
+// no second kernel.  msg: device view of a (pinned, 4-byte aligned) buffer that holds the worst
+// case; msg_len: device word receiving the length (0: nothing published).
+struct LsMsgOut {
+  rplmsg::Prefix P;
+  uint32_t *msg;
+  uint32_t *msg_len;
+  int32_t sec;
+  uint32_t nanosec;
+  double scan_duration;
+};
 hipError_t launch_laserscan_a(hipStream_t s, const void *nodes, uint32_t n_stride,
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                               const Tables &T, const float *inc_table, const float *rinc_table,
                               bool fast, float *ranges, float *intens, uint32_t *beam_count,
-                              uint32_t n_given = 0xFFFFFFFFu);
+                              uint32_t n_given = 0xFFFFFFFFu, const LsMsgOut *msg_out = nullptr);
 hipError_t launch_validate_idx(hipStream_t s, const Tables &T, const float *inc_table,
                                const float *rinc_table, uint32_t max_count,
                                uint32_t *d_mismatches);

@@ -333,6 +333,7 @@ int32_t validate_divisor(rplgpu_ctx *c, float d, uint32_t e_lo, uint32_t e_hi, b
 // publish_scan on the handle's stream: Mode A (rpl_laserscan.hip) or Mode B.  The cheap
 // bin-index divide of Mode A is used only after it was compared with the IEEE divide for
 // every (beam count <= 32768, angle word, inverted or not) on this device, once per handle.
+int32_t ensure_idx_checked(rplgpu_ctx *c);
 int32_t run_laserscan(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride,
                       const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t &p,
                       float *d_ranges, float *d_intens, uint32_t *d_beam_count,
@@ -343,6 +344,16 @@ int32_t run_laserscan(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride,
                                          d_intens, d_beam_count));
     return RPLGPU_OK;
   }
+  if (int32_t vrc = ensure_idx_checked(c)) return vrc;
+  RPL_HIP(c, rpl::launch_laserscan_a(c->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(c),
+                                     c->d_inc, c->d_rinc, c->idx_ok && c->div4000_ok, d_ranges,
+                                     d_intens, d_beam_count, n_given));
+  return RPLGPU_OK;
+}
+
+// the bin-index divide of Mode A: validated once per handle (k_validate_idx, every beam count and
+// angle word)
+int32_t ensure_idx_checked(rplgpu_ctx *c) {
   if (!c->idx_checked) {
     uint32_t zero = 0, bad = 1;
     RPL_HIP(c, hipMemcpyAsync(c->d_small + 8, &zero, 4, hipMemcpyHostToDevice, c->stream));
@@ -355,9 +366,6 @@ int32_t run_laserscan(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride,
     c->idx_ok = (bad == 0);
     c->idx_checked = true;
   }
-  RPL_HIP(c, rpl::launch_laserscan_a(c->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(c),
-                                     c->d_inc, c->d_rinc, c->idx_ok && c->div4000_ok, d_ranges,
-                                     d_intens, d_beam_count, n_given));
   return RPLGPU_OK;
 }
 
@@ -1367,6 +1375,30 @@ int32_t rplgpu_scan_to_laserscan_msg(rplgpu_handle_t h, const rplgpu_node_t *nod
     float *d_r = reinterpret_cast<float *>(h->d_out);  // the arrays themselves stay in HBM
     float *d_i = d_r + n;
     uint32_t *d_count = reinterpret_cast<uint32_t *>(st.d_out);  // host-visible
+    if (p->scan_processing) {
+      // Mode A on the validated fast path: ONE kernel bins the scan and writes the message
+      // around and into its arrays (the arrays never exist outside the message)
+      if (int32_t vrc = ensure_idx_checked(h)) return vrc;
+      if (h->idx_ok && h->div4000_ok && (reinterpret_cast<uintptr_t>(d_msg) & 3u) == 0u) {
+        rpl::LsMsgOut mo;
+        mo.P = P;
+        mo.msg = reinterpret_cast<uint32_t *>(d_msg);
+        mo.msg_len = reinterpret_cast<uint32_t *>(tail_d + 16);
+        mo.sec = stamp.sec;
+        mo.nanosec = stamp.nanosec;
+        mo.scan_duration = scan_duration;
+        RPL_HIP(h, rpl::launch_laserscan_a(h->stream, st.d_nodes, (uint32_t)n, st.d_n, 1, to_kparams(*p),
+                                           tables_of(h), h->d_inc, h->d_rinc, true, d_r, d_i, d_count,
+                                           (uint32_t)n, &mo));
+        if (int32_t wrc = wait_scan(h)) return wrc;
+        uint32_t count, len;
+        std::memcpy(&count, st.h_out, 4);
+        std::memcpy(&len, tail_h + 16, 4);
+        rplgpu_fill_meta(p, count, scan_duration, meta);
+        *msg_len = count ? len : 0;
+        return RPLGPU_OK;
+      }
+    }
     if (int32_t lrc = run_laserscan(h, st.d_nodes, (uint32_t)n, st.d_n, 1, *p, d_r, d_i, d_count, (uint32_t)n))
       return lrc;
     const uint32_t stride = (uint32_t)std::min<size_t>(cap, 0xFFFFFFFCu) & ~3u;

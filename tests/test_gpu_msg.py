@@ -83,7 +83,7 @@ def test_cloud_msg_matches_oracle(gpu, oracle, name):
     assert npts == 0 and msg.tobytes() == cdr.cloud_msg("", 0, 0, np.zeros((0, 4), np.float32))
 
 
-def test_pinned_message_buffer(gpu):
+def test_pinned_message_buffer(gpu, oracle):
     nodes = CASES["c2_32000"]
     p = Params.defaults(range_max=40.0)
     want, _ = gpu.scan_to_laserscan_msg(nodes, p, 0.1, FID, 5, 6)
@@ -93,6 +93,28 @@ def test_pinned_message_buffer(gpu):
         got, _ = gpu.scan_to_laserscan_msg(nodes, p, 0.1, FID, 5, 6, out=pin)
         assert got.tobytes() == want.tobytes()
         assert np.all(pin[len(got):][-5:] == 0xEE)
+        # Mode A into a pinned buffer is ONE kernel that bins the scan and writes the message
+        # around its arrays; any other buffer (and Mode B) takes the arrays through HBM and a
+        # second kernel / copies: same bytes, every scan length class, and against the host
+        # framing of the oracle's arrays
+        for name in ("c1_like_360", "ring_8192_rot_jit", "all_invalid", "c2_32000"):
+            sc = CASES[name]
+            for kw in (dict(), dict(is_new_protocol=1, inverted=1), dict(scan_processing=0),
+                       dict(clip_enable=1, q_min=20, range_max=12.0)):
+                pp = Params.defaults(**{"range_max": 40.0, **kw})
+                for cut in (len(sc), max(len(sc) - 1, 0), min(len(sc), 2049), min(len(sc), 700)):
+                    part = sc[:cut]
+                    a, ma = gpu.scan_to_laserscan_msg(part, pp, 0.0731, FID, -3, 999999999)
+                    pin[:] = 0xEE
+                    b, mb = gpu.scan_to_laserscan_msg(part, pp, 0.0731, FID, -3, 999999999, out=pin)
+                    assert bytes(ma) == bytes(mb), (name, kw, cut)
+                    assert a.tobytes() == b.tobytes(), (name, kw, cut)
+                    if pp.scan_processing and len(part):
+                        wr, wi, wm = oracle.publish_scan(part, oracle_lib.copy_params(pp), 0.0731)
+                        assert bytes(mb) == bytes(wm)
+                        if wm.published:
+                            back = cdr.deserialize("LaserScan", b.tobytes())
+                            assert back["ranges"].tobytes() == wr.tobytes(), (name, kw, cut)
         pv = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
         wantc, n1, _ = gpu.scan_to_cloud_msg(nodes, pv, FID, 5, 6)
         gotc, n2, _ = gpu.scan_to_cloud_msg(nodes, pv, FID, 5, 6, out=pin)
