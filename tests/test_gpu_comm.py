@@ -9,6 +9,7 @@ A 1-GPU box can only run world_size 1 (RCCL refuses two ranks on one device), so
     (BASELINE config 5: one GPU per sensor -> fused PointCloud2);
   * the chunked, double-buffered driver bench.py uses for N > 1 (CloudExchange), result equal to
     the unchunked launch."""
+import contextlib
 import sys
 from pathlib import Path
 
@@ -24,6 +25,15 @@ sys.path.insert(0, str(ROOT / "oracle"))
 
 pytestmark = pytest.mark.gpu
 FID = "base_link"
+
+
+@contextlib.contextmanager
+def _restore_stream(torch, prev):
+    try:
+        yield
+    finally:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(prev)
 
 
 def _arena(gpu, torch, dev, batch, p, cap):
@@ -152,7 +162,11 @@ def test_c5_exchange_transform_fused_message_single_rank_rccl(oracle):
     batch = np.stack([synth.make_scan(800 + s, 0, n, noise_m=0.01) for s in range(S)])
     p = Params.defaults(clip_enable=1, range_max=40.0, ror_enable=1, voxel_enable=1)
     poses = np.stack([fo.planar_pose(0.7 * s - 1.0, 0.35 * s, -0.2 * s, 0.05 * s) for s in range(S)])
-    with RplGpu(device=0, max_samples_per_scan=32768, max_batch=S) as gpu:
+    # (torch's current stream is put back afterwards: the session fixture shares ITS stream with
+    # torch, and a test that leaves another one current makes every later test's tensor fills race
+    # the library's kernels)
+    prev_stream = torch.cuda.current_stream(dev)
+    with RplGpu(device=0, max_samples_per_scan=32768, max_batch=S) as gpu, _restore_stream(torch, prev_stream):
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
         gpu.set_stream(stream.cuda_stream)
@@ -225,7 +239,8 @@ def test_chunked_overlapped_exchange_equals_plain_launch():
         B, n, out_stride, chunks = 96, 8000, 4096, 4
         batch = synth.make_batch(5, B, n)
         p = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
-        with RplGpu(device=0, max_samples_per_scan=32768, max_batch=B) as gpu:
+        prev_stream = torch.cuda.current_stream(dev)
+        with RplGpu(device=0, max_samples_per_scan=32768, max_batch=B) as gpu, _restore_stream(torch, prev_stream):
             stream = torch.cuda.Stream(device=dev)
             torch.cuda.set_stream(stream)
             gpu.set_stream(stream.cuda_stream)
