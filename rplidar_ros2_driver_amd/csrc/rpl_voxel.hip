@@ -804,14 +804,13 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // takes the blocks w, w + kVW, ...; lane l of a block owns the sample pair 128 k + 2 l, + 1
         // (one buffer_load_dwordx4).
         // What bounds this loop (profiles/r03/voxel_phaseS_r03.txt): with ~100 vector instructions
-        // per block the vector ALU needs ~25 k cycles per scan, but a compute unit that keeps only
-        // ONE raw load per wave in flight (16 KiB) cannot pull 256 KiB through a ~2 k-cycle memory
-        // latency in less than ~33 k cycles, whatever the instruction count (Little's law; the
-        // loop of rounds 1-2 looked two blocks ahead by name but needed the newest load at the
-        // top of the next trip).  So the raw pairs run THREE blocks ahead in a ring of four
-        // register buffers, unrolled four times so that the ring costs no register moves, and
-        // the compiler's wait at the top of a block leaves the newest raw load in flight
-        // (s_waitcnt vmcnt(1)); the table entries stay one block ahead (they come from L2).
+        // per block the vector ALU needs ~28 k cycles per scan; the phase takes ~37 k.  The raw
+        // pairs run kAhead blocks ahead in a ring of four register buffers, unrolled four times so
+        // that the ring costs no register moves; the table entries stay one block ahead (they come
+        // from L2).  Two blocks ahead (shipped) the gathers of block k + 1 need the raw pair that
+        // was requested one trip earlier, i.e. the wait at the top of a trip covers everything in
+        // flight; three blocks ahead (RPL_VOXEL_AHEAD=3) that wait leaves the newest raw load in
+        // flight (s_waitcnt vmcnt(3..5)) — and was measured slower, 38.1 k against 36.7 k cycles.
         // (Also tried in round 3: four samples per lane.  Read directly — 32 bytes per lane,
         // table gathers at a stride of 8 entries — the texture addresser became the bottleneck,
         // phase S 46 k cycles; transposed through LDS each block waits for two LDS round trips on
