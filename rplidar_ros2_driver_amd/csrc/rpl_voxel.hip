@@ -153,6 +153,12 @@ __device__ __forceinline__ void lds_store128(uint32_t lds_byte_addr, u32x4 v) {
 __device__ __forceinline__ void glb_store128(void *p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
+// (sc1: agent scope — the entry is written through to where the other XCDs' compute units see it;
+// the consumer of a region may run behind another L2, and a release fence per region, i.e. a
+// buffer_wbl2 per wave task, made the producer ten times slower)
+__device__ __forceinline__ void glb_store128_off(const void *base, uint32_t byte_off, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+}
 
 // E8 (include/rplgpu_msg.h): what happens to a point between polar->XY and the grid when a GROUP
 // of scans shares one grid — the scan's motion during its acquisition (E6 de-skew, same
@@ -259,9 +265,23 @@ constexpr uint32_t kSplitAbove = RPL_VOXEL_SPLIT_ABOVE;
 // Only the kernel instance the launcher picks for batches known to be noisy compiles kPassSplit:
 // inlined next to the plain path it costs a clean batch 1.5-2.7 % (profiles/r03/voxel_split_r03.txt).
 enum : int { kPassPlain = 0, kPassSplit = 2 };
-template <bool FILL, int NS, int MODE = kPassPlain>
-__device__ __forceinline__ bool voxel_block_pass(VoxelLds &L, uint4 *__restrict__ G,
-                                                 const bool (&ok)[NS], uint32_t (&key)[NS],
+// Where a block's queue entries go.  QueueSink: the fused kernel's per-scan queue (LDS while it has
+// room, the workgroup's record store after that; the position comes from an LDS atomic).
+// RegionSink: the streaming kernel of the two-kernel path (k_voxel_runs) — a wave owns a chunk of
+// consecutive blocks and appends to its own region of the record store at a cursor it keeps in a
+// scalar register: no atomic, no LDS, no other wave involved.
+struct QueueSink {
+  static constexpr bool kRegion = false;
+  VoxelLds &L;
+  uint4 *G;
+};
+struct RegionSink {
+  static constexpr bool kRegion = true;
+  uint4 *R;      // first entry of this wave's region (wave-uniform)
+  uint32_t cur;  // entries written so far (wave-uniform)
+};
+template <bool FILL, int NS, int MODE = kPassPlain, class Sink>
+__device__ __forceinline__ bool voxel_block_pass(Sink &S, const bool (&ok)[NS], uint32_t (&key)[NS],
                                                  const uint32_t (&qx)[NS], const uint32_t (&qy)[NS],
                                                  const uint32_t (&ci)[NS]) {
   uint64_t okm[NS];
@@ -309,11 +329,13 @@ __device__ __forceinline__ bool voxel_block_pass(VoxelLds &L, uint4 *__restrict_
   // overlaps the scans below (hand-placed so that the compiler's atomic optimiser does not wait
   // for it right away)
   uint32_t base = 0u;
-  if (lane_id() == 0) {
-    asm volatile("ds_add_rtn_u32 %0, %1, %2"
-                 : "=v"(base)
-                 : "v"((uint32_t)(uintptr_t)&L.misc[0]), "v"(total + 1u)
-                 : "memory");
+  if constexpr (!Sink::kRegion) {
+    if (lane_id() == 0) {
+      asm volatile("ds_add_rtn_u32 %0, %1, %2"
+                   : "=v"(base)
+                   : "v"((uint32_t)(uintptr_t)&S.L.misc[0]), "v"(total + 1u)
+                   : "memory");
+    }
   }
   // lane totals -> inclusive block prefix of the lane's LAST sample; the others by subtraction
   uint32_t Px = qx[0], Py = qy[0], Pc = ci[0];
@@ -330,8 +352,13 @@ __device__ __forceinline__ bool voxel_block_pass(VoxelLds &L, uint4 *__restrict_
   for (int j = 0; j < NS; ++j)
     before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[j] >> 32),
                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m[j], before));
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(base)::"memory");
-  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  if constexpr (Sink::kRegion) {
+    base = S.cur;
+    S.cur = base + total + 1u;
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(base)::"memory");
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  }
   uint32_t pos[NS];
   pos[0] = base + 1u + before;  // entries are queued in sample order behind the marker
 #pragma unroll
@@ -350,6 +377,20 @@ __device__ __forceinline__ bool voxel_block_pass(VoxelLds &L, uint4 *__restrict_
   // selected pointer, and a flat instruction anywhere in the loop makes every wait for the
   // prefetched loads a vmcnt(0) (flat accesses return out of order).  The compiler does not see
   // these stores: the stream loop ends with an explicit wait for them before its barrier.
+  if constexpr (Sink::kRegion) {
+    // (saddr form: 32-bit byte offset per lane + the region's base in scalar registers)
+#ifndef RPL_ABL_NOSTORE  // (developer ablation: the streaming kernel without its record stores)
+    if (lane_id() == 0) glb_store128_off(S.R, base * 16u, marker);
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+      if (__builtin_amdgcn_inverse_ballot_w64(m[j])) glb_store128_off(S.R, pos[j] * 16u, rec[j]);
+#else
+    asm volatile("" ::"v"(rec[0]), "v"(rec[NS - 1]), "v"(pos[0]), "v"(pos[NS - 1]));
+#endif
+    return false;
+  } else {
+  VoxelLds &L = S.L;
+  uint4 *const G = S.G;
   const uint32_t lds_rec = (uint32_t)(uintptr_t)&L.rec[0];
   if (base + 1u + total <= kRecCap) {  // wave-uniform: the usual case, everything goes to LDS
     if (lane_id() == 0) lds_store128(lds_rec + base * 16u, marker);
@@ -368,12 +409,13 @@ __device__ __forceinline__ bool voxel_block_pass(VoxelLds &L, uint4 *__restrict_
     }
   }
   return false;
+  }
 }
 
 // A noisy block in two classes (see kPassSplit): class c keeps the samples whose cell has
 // (ix + iy) & 1 == c, the others count as dropped (zero contribution, neighbour's key).
-template <int NS>
-__device__ __forceinline__ void voxel_block_split(VoxelLds &L, uint4 *__restrict__ G,
+template <int NS, class Sink>
+__device__ __forceinline__ void voxel_block_split(Sink &S,
                                                   const bool (&ok)[NS], const uint32_t (&key)[NS],
                                                   const uint32_t (&qx)[NS], const uint32_t (&qy)[NS],
                                                   const uint32_t (&ci)[NS]) {
@@ -389,7 +431,7 @@ __device__ __forceinline__ void voxel_block_split(VoxelLds &L, uint4 *__restrict
       qyc[j] = okc[j] ? qy[j] : 0u;
       cic[j] = okc[j] ? ci[j] : 0u;
     }
-    voxel_block_pass<true, NS, kPassPlain>(L, G, okc, keyc, qxc, qyc, cic);
+    voxel_block_pass<true, NS, kPassPlain>(S, okc, keyc, qxc, qyc, cic);
   }
 }
 
@@ -699,28 +741,171 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
   return 0u;
 }
 
-// SPLIT: the instance for batches known to be noisy (its blocks may be aggregated in two classes,
-// voxel_block_split); the launcher picks it from the queue statistics of the handle's previous
-// launch (T.voxel_stats), so a clean batch runs code without a trace of that path.
-template <bool FAST_DIV, bool SAFE, bool DBG, bool SPLIT>
-__global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cloud_voxel(
-    const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
-    KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
-    float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
-    uint32_t *__restrict__ status, uint32_t B, VoxelArena arena, uint4 *__restrict__ store,
-    uint32_t group, uint32_t n_scans, const float *__restrict__ motion,
-    const float *__restrict__ pose2d) {
-  // B work items; item b = the scans [b * group, min(n_scans, (b + 1) * group)) sharing ONE grid
-  // (group == 1: a scan is an item, the round-1 behaviour; E8 otherwise)
-  __shared__ VoxelLds L;
+// ------------------------------------------------------------------------------
+// Phase S over the blocks blk0, blk0 + STEP, ... < blk_end of ONE scan (`scan_rsrc`: a bounds-checked
+// buffer resource over the bytes this caller may read; beyond it a load returns zeros = dropped
+// samples and costs no memory traffic).  STEP = kVW: the fused kernel, whose waves interleave the
+// blocks of their scan; STEP = 1: k_voxel_runs, where a wave owns a chunk of consecutive blocks.
+// block k = the samples [128 k, 128 k + 128), i.e. one contiguous KiB; lane l owns the sample pair
+// 128 k + 2 l, + 1 (one buffer_load_dwordx4).  The raw pairs run kAhead blocks ahead in a ring of
+// four register buffers, unrolled four times so that the ring costs no register moves; the table
+// entries stay one block ahead (they come from L2 / L1).
+// (Also tried in round 3: four samples per lane.  Read directly — 32 bytes per lane, table gathers
+// at a stride of 8 entries — the texture addresser became the bottleneck; transposed through LDS
+// each block waits for two LDS round trips on top of the loads: profiles/r03/voxel_phaseS_r03.txt.)
+// ------------------------------------------------------------------------------
+template <bool FAST_DIV, bool SAFE, bool SPLIT, bool DBG, bool HASQ, bool HASMASK, bool XF, int STEP,
+          int AHEAD, class Sink>
+__device__ __forceinline__ void voxel_stream(Sink &sink, const KParams &p,
+                                             const float2 *__restrict__ cs,
+                                             const __amdgpu_buffer_rsrc_t scan_rsrc, uint32_t blk0,
+                                             uint32_t blk_end, const uint32_t *__restrict__ ror_bits,
+                                             uint32_t mask_stride, const ScanXf &xf, uint32_t q_min16,
+                                             uint32_t ibfe_off, uint32_t ibfe_w, uint32_t &flags,
+                                             unsigned long long *dbg_slot) {
+  static_assert(AHEAD == 2 || AHEAD == 3, "raw pairs run two or three blocks ahead");
+  if (blk0 >= blk_end) return;  // wave-uniform (no barrier inside the stream)
+  auto load_pair = [&](uint32_t byte_off) -> uint4 {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)byte_off, 0, RPL_RAW_AUX);
+    return make_uint4(t.x, t.y, t.z, t.w);
+  };
+  const uint32_t lane_off = lane_id() * 16u;
+  uint4 w[4];
+  float2 cA[2], cB[2];
+  w[0] = load_pair(blk0 * 1024u + lane_off);
+  w[1] = load_pair((blk0 + (uint32_t)STEP) * 1024u + lane_off);
+  if (AHEAD == 3) w[2] = load_pair((blk0 + 2u * STEP) * 1024u + lane_off);
+  cA[0] = cs[w[0].x & 0xFFFFu];
+  cB[0] = cs[w[0].z & 0xFFFFu];
+  unsigned long long sub[5] = {0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0ull;
+  for (uint32_t blk4 = blk0; blk4 < blk_end; blk4 += 4u * STEP) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t blk = blk4 + (uint32_t)k * STEP;
+      // (the loads are issued whether or not the block exists — beyond the resource they return
+      // zeros — so that every path through the loop has the same loads in flight and the
+      // compiler's waits stay exact)
+      unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+      if (DBG) t0 = clock64();
+#ifndef RPL_ABL_NOGATHER
+      cA[(k + 1) & 1] = cs[w[(k + 1) & 3].x & 0xFFFFu];
+      cB[(k + 1) & 1] = cs[w[(k + 1) & 3].z & 0xFFFFu];
+#else  // (developer ablation: no table gathers)
+      cA[(k + 1) & 1] = make_float2(__uint_as_float(0x3F000000u | (w[(k + 1) & 3].x & 0xFFFFu)), 0.5f);
+      cB[(k + 1) & 1] = make_float2(__uint_as_float(0x3F000000u | (w[(k + 1) & 3].z & 0xFFFFu)), 0.5f);
+#endif
+#ifndef RPL_ABL_NORAW
+      w[(k + AHEAD) & 3] = load_pair((blk + (uint32_t)AHEAD * STEP) * 1024u + lane_off);
+#else  // (developer ablation: no raw loads inside the loop)
+      w[(k + AHEAD) & 3] = w[k];
+      asm volatile("" : "+v"(w[(k + AHEAD) & 3].x), "+v"(w[(k + AHEAD) & 3].y), "+v"(w[(k + AHEAD) & 3].z), "+v"(w[(k + AHEAD) & 3].w));
+#endif
+      if (DBG) {  // [8] issue of the loads (incl. the wait for the raw pair the gathers need)
+        asm volatile("" : "+v"(cA[(k + 1) & 1].x), "+v"(cB[(k + 1) & 1].x)::"memory");
+        t1 = clock64();
+      }
+      if (blk < blk_end) {  // wave-uniform
+        const uint4 w0 = w[k];
+        const float2 c0[2] = {cA[k & 1], cB[k & 1]};
+        uint32_t lo[2] = {w0.x, w0.z}, hi[2] = {w0.y, w0.w};
+        if (HASMASK) {  // E5 mask (one bit per sample): a dropped sample gets dist 0
+          const uint32_t word = blk * 4u + (lane_id() >> 4);  // sample 128 blk + 2 l -> bit 2 (l & 15)
+          const uint32_t bits = (word < mask_stride) ? ror_bits[word] : 0u;
+          const uint32_t two = bits >> ((lane_id() & 15u) * 2u);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (!((two >> j) & 1u)) { lo[j] &= 0x0000FFFFu; hi[j] &= 0xFFFF0000u; }
+        }
+        const uint32_t i0 = blk * 128u + lane_id() * 2u;  // sample index inside the scan
+        bool ok[2];
+        uint32_t key[2], qx[2], qy[2], ci[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          ok[j] = voxel_sample<FAST_DIV, SAFE, HASQ, XF>(lo[j], hi[j], c0[j], p, q_min16, ibfe_off,
+                                                        ibfe_w, key[j], qx[j], qy[j], ci[j], flags,
+                                                        i0 + (uint32_t)j, &xf);
+        if (DBG) {  // [9] wait for this block's table entries + sample arithmetic
+          asm volatile("" : "+v"(qx[1]), "+v"(qy[0]), "+v"(ci[1]), "+v"(key[1])::"memory");
+          t2 = clock64();
+        }
+        uint32_t key0[2] = {key[0], key[1]};  // (the FILL instance rewrites dropped samples' keys)
+        if (voxel_block_pass<HASQ || HASMASK, 2, SPLIT ? kPassSplit : kPassPlain>(sink, ok, key, qx, qy, ci))
+          voxel_block_split<2>(sink, ok, key0, qx, qy, ci);
+        if (DBG) {  // [10] block pass (issue only: its stores are not waited for)
+          t3 = clock64();
+          if (dbg_slot && threadIdx.x == 0) {
+            sub[0] += t1 - t0; sub[1] += t2 - t1; sub[2] += t3 - t2; sub[3] += t0 - tprev; sub[4] += 1;
+          }
+          tprev = t3;
+        }
+      }
+    }
+  }
+  if (DBG && dbg_slot && threadIdx.x == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&dbg_slot[8 + i], sub[i]);
+}
 
+// What of one scan the streaming code needs besides its nodes: the E5 keep bits and the E8 transform.
+struct ScanSide {
+  const uint32_t *ror_bits;
+  ScanXf xf;
+};
+__device__ __forceinline__ ScanSide scan_side(uint32_t sc, const uint32_t *__restrict__ keepmask,
+                                              uint32_t mask_stride, const float *__restrict__ motion,
+                                              const float *__restrict__ pose2d) {
+  ScanSide s;
+  s.ror_bits = keepmask ? keepmask + (size_t)sc * mask_stride : nullptr;
+  s.xf = ScanXf{0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+  if (motion) { s.xf.vx = motion[4 * sc]; s.xf.vy = motion[4 * sc + 1]; s.xf.wz = motion[4 * sc + 2]; s.xf.dt = motion[4 * sc + 3]; }
+  if (pose2d) {
+    s.xf.r00 = pose2d[6 * sc]; s.xf.r01 = pose2d[6 * sc + 1]; s.xf.tx = pose2d[6 * sc + 2];
+    s.xf.r10 = pose2d[6 * sc + 3]; s.xf.r11 = pose2d[6 * sc + 4]; s.xf.ty = pose2d[6 * sc + 5];
+  }
+  return s;
+}
+// (one loop instance per uniform condition, so that none of them is tested per block)
+template <bool FAST_DIV, bool SAFE, bool SPLIT, bool DBG, int STEP, int AHEAD, class Sink>
+__device__ __forceinline__ void voxel_stream_dispatch(Sink &sink, const KParams &p,
+                                                      const float2 *__restrict__ cs,
+                                                      const __amdgpu_buffer_rsrc_t rsrc, uint32_t blk0,
+                                                      uint32_t blk_end, const ScanSide &sd,
+                                                      uint32_t mask_stride, bool use_xf,
+                                                      uint32_t q_min16, uint32_t ibfe_off,
+                                                      uint32_t ibfe_w, uint32_t &flags,
+                                                      unsigned long long *dbg_slot) {
+#define RPL_VS(HQ, HM, XFB)                                                                         \
+  voxel_stream<FAST_DIV, SAFE, SPLIT, DBG, HQ, HM, XFB, STEP, AHEAD>(sink, p, cs, rsrc, blk0, blk_end, \
+                                                                     sd.ror_bits, mask_stride, sd.xf, \
+                                                                     q_min16, ibfe_off, ibfe_w, flags, \
+                                                                     dbg_slot)
+  if (use_xf) {  // (E8 / de-skew: one instance, quality test and mask word always on)
+    if (sd.ror_bits) RPL_VS(true, true, true);
+    else RPL_VS(true, false, true);
+  } else if (sd.ror_bits) RPL_VS(true, true, false);
+  else if (q_min16) RPL_VS(true, false, false);
+  else RPL_VS(false, false, false);
+#undef RPL_VS
+}
+
+// ------------------------------------------------------------------------------
+// The persistent per-item loop shared by the fused kernel and by k_voxel_cells: draw a work item,
+// let `first_band(b, bl, flags)` put the item's queue entries in place — entries [0, kRecCap) in the
+// LDS queue, the rest at their own index in this workgroup's record store G, the total in
+// L.misc[0] — then turn key bands of them into cells (phase R) and publish the item's results.
+// item0: first item of this launch (a launch may be one stage of a batch); B: its items.
+// ------------------------------------------------------------------------------
+template <bool DBG, class FirstBand>
+__device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, const Tables &T,
+                                                uint4 *__restrict__ G, float4 *__restrict__ xyzi,
+                                                uint32_t out_stride, uint32_t *__restrict__ n_points,
+                                                uint32_t *__restrict__ status, uint32_t B,
+                                                uint32_t item0, const VoxelArena &arena,
+                                                FirstBand &&first_band) {
   if (threadIdx.x < 256) L.rcp[threadIdx.x] = T.rcp[threadIdx.x];  // (first barrier below publishes it)
-  // this workgroup's record store (T.voxel_store_recs entries, voxel_store_need(): every sample
-  // of the work item could end a run, plus the block markers)
-  uint4 *G = store + (size_t)blockIdx.x * 2u * T.voxel_store_recs;  // records, then the cell area
-  // persistent workgroups, two per CU; the first scan is blockIdx.x, the next ones come from a
-  // shared counter, so a workgroup that drew cheap scans simply takes more of them
-  for (uint32_t b = blockIdx.x; b < B;) {
+  // persistent workgroups; the first item is blockIdx.x, the next ones come from a shared counter,
+  // so a workgroup that drew cheap scans simply takes more of them
+  for (uint32_t bl = blockIdx.x; bl < B;) {
+  const uint32_t b = item0 + bl;
   float4 *out = arena.base ? arena.base : xyzi + (size_t)b * out_stride;
   int emit_mode = arena.base ? kEmitArenaFirst : kEmitLegacy;
   unsigned long long arena_at = 0ull;  // first point of this scan in the arena
@@ -735,15 +920,11 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
   __syncthreads();
 
-  const float2 *cs = p.inverted ? T.cs_inv : T.cs;
-  const uint32_t ishift = p.is_new_protocol ? 0u : 2u;  // :591-592
-  const uint32_t ibfe_off = 16u + ishift, ibfe_w = 0xFFu >> ishift;  // shift, mask
-  const uint32_t q_min16 = p.clip_enable ? (min(p.q_min, 256u) << 16) : 0u;
   uint32_t flags = 0;
   PhaseClock<DBG> pc;
   pc.start();
 
-  bool first_band = true;
+  bool first = true;
   bool from_store = false;  // block-uniform: the scan's records are (all) in the record store
   uint32_t n_all = 0;       // records of the whole scan (valid once the scan was streamed)
   while (true) {
@@ -766,136 +947,9 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (uint32_t t = threadIdx.x; t < kRowCap; t += kVB) L.rows[t] = 0u;
     __syncthreads();
 
-    if (first_band) {
-      // ---- phase S: raw pairs two rounds ahead, table entries one round ahead -----------
-      // (one loop instance per uniform condition, so that none of them is tested per pass).
-      // Deeper prefetch does not pay (profiles/r02/voxel_phaseS_study.txt: two rounds per
-      // trip, a copy-free four-buffer register ring in plain HIP and with hand-managed vmcnt,
-      // staggered waves — the wait at the end of a round shrinks, the round does not).
-      const bool use_xf = (group > 1u) || motion || pose2d;  // block-uniform
-      const uint32_t s_lo = b * group, s_hi = min(n_scans, s_lo + group);
-      for (uint32_t sc = s_lo; sc < s_hi; ++sc) {
-        // (readfirstlane: the value is wave-uniform, and must live in scalar registers for the
-        // buffer resource below — a min3 in vector registers makes every load a waterfall loop)
-        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)min(n_per_scan[sc], min(n_stride, kMaxN)));  // never past the slot
-        const uint2 *scan = nodes + (size_t)sc * n_stride;
-        // Bounds-checked buffer resource over this scan's n*8 bytes: a node beyond the scan reads
-        // as zero, i.e. dist 0, which the keep test drops.  Every lane always issues the load, so
-        // the compiler's vmcnt bookkeeping is exact.
-        const __amdgpu_buffer_rsrc_t scan_rsrc =
-            __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
-        auto load_pair = [&](uint32_t byte_off) -> uint4 {
-          const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)byte_off, 0, RPL_RAW_AUX);
-          return make_uint4(t.x, t.y, t.z, t.w);
-        };
-        const uint32_t *ror_bits = keepmask ? keepmask + (size_t)sc * mask_stride : nullptr;
-        ScanXf xf = {0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
-        if (motion) { xf.vx = motion[4 * sc]; xf.vy = motion[4 * sc + 1]; xf.wz = motion[4 * sc + 2]; xf.dt = motion[4 * sc + 3]; }
-        if (pose2d) {
-          xf.r00 = pose2d[6 * sc]; xf.r01 = pose2d[6 * sc + 1]; xf.tx = pose2d[6 * sc + 2];
-          xf.r10 = pose2d[6 * sc + 3]; xf.r11 = pose2d[6 * sc + 4]; xf.ty = pose2d[6 * sc + 5];
-        }
-      auto stream = [&](auto hasq_tag, auto mask_tag, auto xf_tag) {
-        constexpr bool HASQ = decltype(hasq_tag)::value;
-        constexpr bool HASMASK = decltype(mask_tag)::value;
-        constexpr bool XF = decltype(xf_tag)::value;
-        // block k of the scan = its samples [128 k, 128 k + 128), i.e. one contiguous KiB; wave w
-        // takes the blocks w, w + kVW, ...; lane l of a block owns the sample pair 128 k + 2 l, + 1
-        // (one buffer_load_dwordx4).
-        // What bounds this loop (profiles/r03/voxel_phaseS_r03.txt): with ~100 vector instructions
-        // per block the vector ALU needs ~28 k cycles per scan; the phase takes ~37 k.  The raw
-        // pairs run kAhead blocks ahead in a ring of four register buffers, unrolled four times so
-        // that the ring costs no register moves; the table entries stay one block ahead (they come
-        // from L2).  Two blocks ahead (shipped) the gathers of block k + 1 need the raw pair that
-        // was requested one trip earlier, i.e. the wait at the top of a trip covers everything in
-        // flight; three blocks ahead (RPL_VOXEL_AHEAD=3) that wait leaves the newest raw load in
-        // flight (s_waitcnt vmcnt(3..5)) — and was measured slower, 38.1 k against 36.7 k cycles.
-        // (Also tried in round 3: four samples per lane.  Read directly — 32 bytes per lane,
-        // table gathers at a stride of 8 entries — the texture addresser became the bottleneck,
-        // phase S 46 k cycles; transposed through LDS each block waits for two LDS round trips on
-        // top of the loads and the slot reservation, which four waves per SIMD do not hide: 41 k.)
-        const uint32_t nblocks = (n + 127u) >> 7;
-        const uint32_t lane_off = lane_id() * 16u;
-        const uint32_t blk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
-        if (blk0 >= nblocks) return;  // wave-uniform (no barrier inside the stream)
-        uint4 w[4];
-        float2 cA[2], cB[2];
-        constexpr int kAhead = RPL_VOXEL_AHEAD;  // blocks the raw pairs run ahead (2 or 3)
-        w[0] = load_pair(blk0 * 1024u + lane_off);
-        w[1] = load_pair((blk0 + kVW) * 1024u + lane_off);
-        if (kAhead == 3) w[2] = load_pair((blk0 + 2u * kVW) * 1024u + lane_off);
-        cA[0] = cs[w[0].x & 0xFFFFu];
-        cB[0] = cs[w[0].z & 0xFFFFu];
-        unsigned long long sub[5] = {0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0ull;
-        for (uint32_t blk4 = blk0; blk4 < nblocks; blk4 += 4u * kVW) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t blk = blk4 + (uint32_t)k * kVW;
-            // (the loads are issued whether or not the block exists — beyond the scan they return
-            // zeros — so that every path through the loop has the same loads in flight and the
-            // compiler's waits stay exact)
-            unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-            if (DBG) t0 = clock64();
-            cA[(k + 1) & 1] = cs[w[(k + 1) & 3].x & 0xFFFFu];
-            cB[(k + 1) & 1] = cs[w[(k + 1) & 3].z & 0xFFFFu];
-            w[(k + kAhead) & 3] = load_pair((blk + (uint32_t)kAhead * kVW) * 1024u + lane_off);
-            if (DBG) {  // [8] issue of the loads (incl. the wait for the raw pair the gathers need)
-              asm volatile("" : "+v"(cA[(k + 1) & 1].x), "+v"(cB[(k + 1) & 1].x)::"memory");
-              t1 = clock64();
-            }
-            if (blk < nblocks) {  // wave-uniform
-              const uint4 w0 = w[k];
-              const float2 c0[2] = {cA[k & 1], cB[k & 1]};
-              uint32_t lo[2] = {w0.x, w0.z}, hi[2] = {w0.y, w0.w};
-              if (HASMASK) {  // E5 mask (one bit per sample): a dropped sample gets dist 0
-                const uint32_t word = blk * 4u + (lane_id() >> 4);  // sample 128 blk + 2 l -> bit 2 (l & 15)
-                const uint32_t bits = (word < mask_stride) ? ror_bits[word] : 0u;
-                const uint32_t two = bits >> ((lane_id() & 15u) * 2u);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                  if (!((two >> j) & 1u)) { lo[j] &= 0x0000FFFFu; hi[j] &= 0xFFFF0000u; }
-              }
-              const uint32_t i0 = blk * 128u + lane_id() * 2u;  // sample index inside the scan
-              bool ok[2];
-              uint32_t key[2], qx[2], qy[2], ci[2];
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-                ok[j] = voxel_sample<FAST_DIV, SAFE, HASQ, XF>(lo[j], hi[j], c0[j], p, q_min16,
-                                                              ibfe_off, ibfe_w, key[j], qx[j], qy[j],
-                                                              ci[j], flags, i0 + (uint32_t)j, &xf);
-              if (DBG) {  // [9] wait for this block's table entries + sample arithmetic
-                asm volatile("" : "+v"(qx[1]), "+v"(qy[0]), "+v"(ci[1]), "+v"(key[1])::"memory");
-                t2 = clock64();
-              }
-              uint32_t key0[2] = {key[0], key[1]};  // (the FILL instance rewrites dropped samples' keys)
-              if (voxel_block_pass<HASQ || HASMASK, 2, SPLIT ? kPassSplit : kPassPlain>(L, G, ok, key, qx, qy, ci))
-                voxel_block_split<2>(L, G, ok, key0, qx, qy, ci);
-              if (DBG) {  // [10] block pass (issue only: its stores are not waited for)
-                t3 = clock64();
-                if (p.dbg && threadIdx.x == 0) {
-                  sub[0] += t1 - t0; sub[1] += t2 - t1; sub[2] += t3 - t2; sub[3] += t0 - tprev; sub[4] += 1;
-                }
-                tprev = t3;
-              }
-            }
-          }
-        }
-        if (DBG && p.dbg && threadIdx.x == 0)
-          for (int i = 0; i < 5; ++i) atomicAdd(&p.dbg[16 * b + 8 + i], sub[i]);
-      };
-      {
-        using T_ = std::true_type;
-        using F_ = std::false_type;
-        if (use_xf) {  // (E8 / de-skew: one instance, quality test and mask word always on)
-          if (keepmask) stream(T_{}, T_{}, T_{});
-          else stream(T_{}, F_{}, T_{});
-        } else if (keepmask) stream(T_{}, T_{}, F_{});
-        else if (q_min16) stream(T_{}, F_{}, F_{});
-        else stream(F_{}, F_{}, F_{});
-      }
-      }  // scans of the group
-      first_band = false;
+    if (first) {
+      first_band(b, bl, flags);
+      first = false;
       // the record stores of phase S are hand-written instructions the compiler does not track
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();  // (workgroup-scope release / acquire: covers the record store too)
@@ -1105,9 +1159,295 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (B <= gridDim.x) return;  // a workgroup per item (single scans, small batches): no queue
   if (threadIdx.x == 0) L.tmp[31] = gridDim.x + atomicAdd(&T.work_ctr[0], 1u);
   __syncthreads();  // LDS is reused by the next scan
-  b = L.tmp[31];
+  bl = L.tmp[31];
   __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------------------
+// The FUSED kernel (single scans, small batches): one persistent workgroup per compute unit
+// streams an item into its LDS queue (phase S) and reduces it (phase R) itself.
+// SPLIT: the instance for batches known to be noisy (its blocks may be aggregated in two classes,
+// voxel_block_split); the launcher picks it from the queue statistics of the handle's previous
+// launch (T.voxel_stats), so a clean batch runs code without a trace of that path.
+// ------------------------------------------------------------------------------
+template <bool FAST_DIV, bool SAFE, bool DBG, bool SPLIT>
+__global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cloud_voxel(
+    const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
+    KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
+    float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
+    uint32_t *__restrict__ status, uint32_t B, VoxelArena arena, uint4 *__restrict__ store,
+    uint32_t group, uint32_t n_scans, const float *__restrict__ motion,
+    const float *__restrict__ pose2d) {
+  // B work items; item b = the scans [b * group, min(n_scans, (b + 1) * group)) sharing ONE grid
+  // (group == 1: a scan is an item, the round-1 behaviour; E8 otherwise)
+  __shared__ VoxelLds L;
+  // this workgroup's record store (T.voxel_store_recs entries, voxel_store_need(): every sample
+  // of the work item could end a run, plus the block markers)
+  uint4 *G = store + (size_t)blockIdx.x * 2u * T.voxel_store_recs;  // records, then the cell area
+  const float2 *cs = p.inverted ? T.cs_inv : T.cs;
+  const uint32_t ishift = p.is_new_protocol ? 0u : 2u;  // :591-592
+  const uint32_t ibfe_off = 16u + ishift, ibfe_w = 0xFFu >> ishift;  // shift, mask
+  const uint32_t q_min16 = p.clip_enable ? (min(p.q_min, 256u) << 16) : 0u;
+  const bool use_xf = (group > 1u) || motion || pose2d;  // block-uniform
+  auto phase_s = [&](uint32_t b, uint32_t, uint32_t &flags) {
+    QueueSink sink{L, G};
+    const uint32_t s_lo = b * group, s_hi = min(n_scans, s_lo + group);
+    for (uint32_t sc = s_lo; sc < s_hi; ++sc) {
+      // (readfirstlane: the value is wave-uniform, and must live in scalar registers for the
+      // buffer resource below — a min3 in vector registers makes every load a waterfall loop)
+      const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(
+          (int)min(n_per_scan[sc], min(n_stride, kMaxN)));  // never past the slot
+      const uint2 *scan = nodes + (size_t)sc * n_stride;
+      // Bounds-checked buffer resource over this scan's n*8 bytes: a node beyond the scan reads
+      // as zero, i.e. dist 0, which the keep test drops.  Every lane always issues the load, so
+      // the compiler's vmcnt bookkeeping is exact.
+      const __amdgpu_buffer_rsrc_t scan_rsrc =
+          __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
+      const ScanSide sd = scan_side(sc, keepmask, mask_stride, motion, pose2d);
+      const uint32_t blk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
+      voxel_stream_dispatch<FAST_DIV, SAFE, SPLIT, DBG, kVW, RPL_VOXEL_AHEAD>(
+          sink, p, cs, scan_rsrc, blk0, (n + 127u) >> 7, sd, mask_stride, use_xf, q_min16, ibfe_off,
+          ibfe_w, flags, (DBG && p.dbg) ? p.dbg + 16 * b : nullptr);
+    }
+  };
+  voxel_work_loop<DBG>(L, p, T, G, xyzi, out_stride, n_points, status, B, 0u, arena, phase_s);
+}
+
+// ------------------------------------------------------------------------------
+// The TWO-KERNEL path (batches, round 4).  The fused kernel needs a compute unit's whole LDS for
+// one scan, so a CU holds 16 waves, every wave has ONE KiB of raw samples in flight, and phase R
+// (LDS latency) runs with nothing streaming: 58 k cycles per scan, a third of the HBM roofline for
+// three rounds.  Here the two phases are two kernels:
+//   k_voxel_runs  — phase S alone.  No LDS, no barrier, no atomic: a WAVE owns a chunk of
+//     kChunkBlocks consecutive blocks (2048 samples) of one scan and appends its queue entries to
+//     its own REGION of the record store at a cursor in a scalar register; the entry count of the
+//     region (and the wave's status flags) go to rcount[].  256-thread workgroups, as many waves
+//     per SIMD as the registers allow: the loads of a wave hide behind the arithmetic of the others.
+//     Tasks are numbered chunk-major (chunk q of items 0 .. B-1, then chunk q + 1, ...): the waves in
+//     flight work on the same angular window of their scans, so the (cos, sin) entries they gather
+//     are shared through the vector L1 instead of being read from L2 once per scan.
+//   k_voxel_cells — phase R alone: a persistent workgroup gathers the regions of an item into its
+//     LDS queue (in region order, i.e. in sample order: every region starts with a block's marker
+//     entry, so "the entry before" stays the right subtrahend) and runs the same per-item loop as
+//     the fused kernel from there (bands, record store, arena modes: all unchanged).
+// Cost: the queue entries travel through L2 once (a clean scan: 52 KB written, 52 KB read, next to
+// 256 KB of samples).
+// ------------------------------------------------------------------------------
+constexpr uint32_t kChunkBlocks = 16u;
+constexpr uint32_t kChunkSamples = kChunkBlocks * 128u;
+// entries a chunk can make: one per sample + one marker per block (two when a block is split)
+constexpr uint32_t kRegionCap = kChunkSamples + 2u * kChunkBlocks;
+#ifndef RPL_RUNS_THREADS
+#define RPL_RUNS_THREADS 256
+#endif
+#ifndef RPL_RUNS_AHEAD
+#define RPL_RUNS_AHEAD 3
+#endif
+#ifndef RPL_RUNS_WAVES_PER_EU
+#define RPL_RUNS_WAVES_PER_EU 8
+#endif
+constexpr int kRunsThreads = RPL_RUNS_THREADS;
+constexpr int kRunsWaves = kRunsThreads / 64;
+
+// Pipelining of the two kernels (`pipe` != null): k_voxel_cells runs NEXT to k_voxel_runs on the
+// same compute units (it is launched on a second stream, takes a CU's LDS and half its wave
+// slots; this kernel takes the other half) and picks an item up as soon as all its regions are
+// written.  Then this kernel is a grid of persistent workgroups (4 per CU) whose waves stride
+// through the tasks — numbered so that the items complete in order, kPipeBurst at a time — and
+// every wave, when its region is complete (agent-scope stores: the consumer may sit behind
+// another L2), bumps pipe->ready[item].  The consumer never blocks this kernel, so
+// the pair cannot deadlock; if the device runs the kernels one after the other (a profiler that
+// serialises dispatches) the consumer simply finds every item ready.
+struct VoxelPipe {
+  uint32_t *task_ctr;   // next task of k_voxel_runs
+  uint32_t *item_ctr;   // next item of k_voxel_cells
+  uint32_t *ready;      // per item of the stage: regions written so far
+};
+constexpr uint32_t kPipeBurst = 256u;  // items whose chunks are streamed together (they complete together)
+
+template <bool FAST_DIV, bool SAFE, bool SPLIT>
+__global__ __launch_bounds__(kRunsThreads)
+__attribute__((amdgpu_waves_per_eu(RPL_RUNS_WAVES_PER_EU, RPL_RUNS_WAVES_PER_EU))) void k_voxel_runs(
+    const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
+    KParams p, const float2 *__restrict__ cs, const uint32_t *__restrict__ keepmask,
+    uint32_t mask_stride, uint4 *__restrict__ regions, uint2 *__restrict__ rcount, uint32_t item0,
+    uint32_t B, uint32_t group, uint32_t n_scans, uint32_t cps, uint32_t scan_major,
+    const float *__restrict__ motion, const float *__restrict__ pose2d, VoxelPipe pipe,
+    uint32_t pipe_want) {
+  const uint32_t qn = group * cps;  // regions per item
+  const uint32_t total = B * qn;
+  const uint32_t ishift = p.is_new_protocol ? 0u : 2u;  // :591-592
+  const uint32_t ibfe_off = 16u + ishift, ibfe_w = 0xFFu >> ishift;
+  const uint32_t q_min16 = p.clip_enable ? (min(p.q_min, 256u) << 16) : 0u;
+  const bool use_xf = (group > 1u) || motion || pose2d;
+  // task t of this launch -> (item bl of the stage, scan g of its group, chunk c of that scan)
+  // (persistent waves take the tasks w, w + W, w + 2 W, ...: the tasks are of one size, and a shared
+  // task counter — 65 536 returning atomics on one address — alone took 0.8 ms)
+  uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kRunsWaves + wave_id()));
+  const uint32_t t_step = gridDim.x * kRunsWaves;
+  if (pipe.task_ctr && pipe_want) {
+    // The consumer's workgroups need a CU's LDS and half its wave slots at once; if this kernel's
+    // small workgroups got there first they would take slot after slot as they come free and the
+    // consumer would only start when this kernel ends.  So it is launched first and this kernel
+    // gives its workgroups a moment (at most 30 us) to settle: pipe.task_ctr counts them.
+    const unsigned long long t_in = wall_clock64();
+    while (__hip_atomic_load(pipe.task_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pipe_want &&
+           wall_clock64() - t_in < 3000ull)
+      __builtin_amdgcn_s_sleep(16);
+  }
+  for (;; t += t_step) {
+    if (t >= total) return;
+    uint32_t q, bl;
+    if (pipe.task_ctr) {  // bursts of kPipeBurst items, chunk-major inside a burst
+      const uint32_t per = kPipeBurst * qn, u = t / per, v = t - u * per;
+      const uint32_t nb = min(kPipeBurst, B - u * kPipeBurst);  // items of this burst
+      q = v / nb;
+      bl = u * kPipeBurst + (v - q * nb);
+    } else if (scan_major) {
+      bl = t / qn;
+      q = t - bl * qn;
+    } else {
+      q = t / B;
+      bl = t - q * B;
+    }
+    const uint32_t g = q / cps, c = q - g * cps;
+    const uint32_t sc = (item0 + bl) * group + g;
+    const uint32_t r = bl * qn + q;  // this wave's region (stage-relative)
+    RegionSink sink{regions + (size_t)r * kRegionCap, 0u};
+    uint32_t flags = 0;
+    if (sc < n_scans) {
+      const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(
+          (int)min(n_per_scan[sc], min(n_stride, kMaxN)));  // never past the slot
+      const uint32_t blk0 = c * kChunkBlocks, blk_end = min((n + 127u) >> 7, blk0 + kChunkBlocks);
+      if (blk0 < blk_end) {
+        // the resource ends with the chunk (or the scan): the ring's loads beyond it return zeros
+        // and move no data
+        const uint32_t lim = min(n, blk_end * 128u) * 8u;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(nodes + (size_t)sc * n_stride), 0, (int)lim, 0x00020000);
+        const ScanSide sd = scan_side(sc, keepmask, mask_stride, motion, pose2d);
+        voxel_stream_dispatch<FAST_DIV, SAFE, SPLIT, false, 1, RPL_RUNS_AHEAD>(
+            sink, p, cs, rsrc, blk0, blk_end, sd, mask_stride, use_xf, q_min16, ibfe_off, ibfe_w,
+            flags, nullptr);
+      }
+    }
+    // status flags of the wave's samples (any lane), then the region's entry count
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) flags |= (uint32_t)__shfl_xor((int)flags, d, 64);
+    if (lane_id() == 0) {
+      const uint64_t cf = (uint64_t)sink.cur | ((uint64_t)flags << 32);
+      __hip_atomic_store(reinterpret_cast<uint64_t *>(rcount + r), cf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (p.dbg && lane_id() == 0) {  // developer aid: when the item's last region was complete
+      atomicMax(&p.dbg[16 * (item0 + bl) + 3], wall_clock64());
+    }
+    if (!pipe.task_ctr) return;
+    // every store of this wave (agent scope, see glb_store128_off; the entries by hand-written
+    // instructions the compiler does not track) has completed before the item's count is bumped
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane_id() == 0) __hip_atomic_fetch_add(&pipe.ready[bl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// (LDS is passed as dynamic shared memory: with the 133 KB visible at compile time the compiler
+// concludes that one workgroup per CU is all there can be and spends 128 registers per lane — which
+// leaves none for the waves of k_voxel_runs that are to run next to this kernel.)
+#ifndef RPL_CELLS_WAVES_PER_EU
+#define RPL_CELLS_WAVES_PER_EU 7  // 72 registers per lane: 4 waves of this + 4 of k_voxel_runs per SIMD
+#endif
+template <bool DBG>
+__global__ __launch_bounds__(kVB)
+__attribute__((amdgpu_waves_per_eu(RPL_CELLS_WAVES_PER_EU, RPL_CELLS_WAVES_PER_EU))) void k_voxel_cells(
+    KParams p, Tables T, const uint4 *__restrict__ regions, const uint2 *__restrict__ rcount,
+    float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
+    uint32_t *__restrict__ status, uint32_t item0, uint32_t B, uint32_t qn, VoxelArena arena,
+    uint4 *__restrict__ store, VoxelPipe pipe) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char voxel_dyn_lds[];
+  VoxelLds &L = *reinterpret_cast<VoxelLds *>(voxel_dyn_lds);
+  if (pipe.item_ctr) T.work_ctr = pipe.item_ctr;
+#ifndef RPL_CELLS_PRIO
+#define RPL_CELLS_PRIO 3
+#endif
+  // This kernel is a chain of dependent LDS round trips and barriers; next to the producer's waves,
+  // which always have a vector instruction ready, its waves would wait their turn at every step
+  // (measured: 3 x slower).  They issue little, so they go first.
+  if (pipe.item_ctr) __builtin_amdgcn_s_setprio(RPL_CELLS_PRIO);
+  if (pipe.task_ctr && threadIdx.x == 0)  // (the producer waits a moment for this, see k_voxel_runs)
+    __hip_atomic_fetch_add(pipe.task_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint4 *G = store + (size_t)blockIdx.x * 2u * T.voxel_store_recs;  // records, then the cell area
+  // the item's regions -> the queue, in region order.  Wave w takes the regions
+  // [w * per, (w + 1) * per): it needs the entries in front of its first region (a block scan over
+  // the waves' totals) and then walks its regions with a running position.
+  auto gather = [&](uint32_t, uint32_t bl, uint32_t &flags) {
+    if (pipe.ready) {  // pipelined: the producer may still be writing this item's regions
+      if (threadIdx.x == 0) {
+        if (p.dbg) p.dbg[16 * (item0 + bl) + 0] = wall_clock64();  // developer aid: began to wait
+        // (bounded: the producer never waits for this kernel, so the item does come — unless the
+        // producer's launch failed; then the item is flagged instead of spinning for ever)
+        const unsigned long long t_in = wall_clock64();
+        bool late = false;
+        while (__hip_atomic_load(&pipe.ready[bl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < qn) {
+          __builtin_amdgcn_s_sleep(32);
+          if (wall_clock64() - t_in > 200000000ull) { late = true; break; }  // 2 s
+        }
+        if (late) atomicOr(&L.misc[1], (uint32_t)RPLGPU_SCAN_TABLE_FULL);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (p.dbg) p.dbg[16 * (item0 + bl) + 1] = wall_clock64();  // ... saw the item ready
+      }
+      __syncthreads();
+    }
+    const uint2 *rc = rcount + (size_t)bl * qn;
+    const uint4 *RG = regions + (size_t)bl * qn * kRegionCap;
+    const uint32_t per = (qn + kVW - 1u) / kVW;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
+    const uint32_t r0 = min(qn, w * per), r1 = min(qn, r0 + per);
+    uint32_t mine = 0u;
+    for (uint32_t r = r0 + lane_id(); r < r1; r += 64u) {
+      const uint2 v = rc[r];
+      mine += min(v.x, kRegionCap);
+      flags |= v.y;
+    }
+    const uint32_t inc = wave_incl_scan_fast(mine);
+    if (lane_id() == 63) L.tmp[wave_id()] = inc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const uint32_t v = (threadIdx.x < kVW) ? L.tmp[threadIdx.x] : 0u;
+      const uint32_t ws = wave_incl_scan_fast(v);
+      if (threadIdx.x < kVW) L.tmp[threadIdx.x] = ws - v;  // entries in front of the wave's regions
+      if (threadIdx.x == kVW - 1) L.misc[0] = ws;          // the item's queue length
+    }
+    __syncthreads();
+    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tmp[w]);
+    for (uint32_t rb = r0; rb < r1; rb += 64u) {
+      const uint32_t cnt_l = (rb + lane_id() < r1) ? rc[rb + lane_id()].x : 0u;
+      const uint32_t nj = min(64u, r1 - rb);
+      for (uint32_t j = 0; j < nj; ++j) {
+        // (never more than a region holds, whatever the count word says: a producer that did not
+        // run leaves the words of an earlier call, or of no call at all)
+        const uint32_t cnt = min((uint32_t)__builtin_amdgcn_readlane((int)cnt_l, (int)j), kRegionCap);
+        const uint4 *src = RG + (size_t)(rb + j) * kRegionCap;
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 256u) {  // four loads in flight per lane
+          uint4 e[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + 64u * k + lane_id();
+            if (i < cnt) e[k] = src[i];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t i = i0 + 64u * k + lane_id();
+            if (i < cnt) {
+              const uint32_t d = pos + i;
+              if (d < kRecCap) L.rec[d] = e[k]; else G[d] = e[k];
+            }
+          }
+        }
+        pos += cnt;
+      }
+    }
+  };
+  voxel_work_loop<DBG>(L, p, T, G, xyzi, out_stride, n_points, status, B, item0, arena, gather);
 }
 
 // ------------------------------------------------------------------------------
@@ -1146,6 +1486,36 @@ hipError_t launch_validate_div(hipStream_t s, float d, float rd, uint32_t e_lo, 
 
 uint32_t voxel_max_workgroups(uint32_t n_cu) { return (kVB == 512 ? 2u : 1u) * (n_cu ? n_cu : 256u); }
 
+uint32_t voxel_regions_per_item(uint32_t group, uint32_t n_stride) {
+  const uint32_t s = n_stride < kMaxN ? n_stride : kMaxN;
+  return (group ? group : 1u) * ((s + kChunkSamples - 1u) / kChunkSamples);
+}
+uint64_t voxel_region_bytes() { return (uint64_t)kRegionCap * 16u; }
+
+// The two-kernel path for the items [0, B) (work items of `group` scans): stages of as many items
+// as the region store holds; k_voxel_runs then k_voxel_cells per stage, on the same stream.
+template <bool FD, bool SF, bool SP>
+static hipError_t launch_runs(hipStream_t s, const void *nodes, uint32_t n_stride,
+                              const uint32_t *n_per_scan, const KParams &p, const Tables &T,
+                              const uint32_t *keepmask, uint32_t mask_stride, uint32_t item0,
+                              uint32_t Bs, uint32_t group, uint32_t n_scans, uint32_t cps,
+                              const float *motion, const float *pose2d, uint32_t pipe_want) {
+  const uint32_t tasks = Bs * group * cps;
+  const uint32_t grid = (tasks + (uint32_t)kRunsWaves - 1u) / (uint32_t)kRunsWaves;
+  VoxelPipe pipe{nullptr, nullptr, nullptr};
+  uint32_t g = grid;
+  if (T.voxel_pipe) {  // persistent waves, voxel_pipe workgroups of 4 waves per CU
+    pipe = VoxelPipe{T.voxel_pipe_ctr, T.voxel_pipe_ctr + 1, T.voxel_pipe_ctr + 2};
+    g = std::min<uint32_t>(grid, (T.n_cu ? T.n_cu : 256u) * (uint32_t)T.voxel_pipe);  // voxel_pipe workgroups per CU
+  }
+  hipLaunchKernelGGL((k_voxel_runs<FD, SF, SP>), dim3(g), dim3(kRunsThreads), 0, s,
+                     (const uint2 *)nodes, n_stride, n_per_scan, p, p.inverted ? T.cs_inv : T.cs,
+                     keepmask, mask_stride, (uint4 *)T.voxel_regions, (uint2 *)T.voxel_rcount, item0,
+                     Bs, group, n_scans, cps, (uint32_t)(T.voxel_scan_major ? 1u : 0u), motion, pose2d,
+                     pipe, pipe_want);
+  return hipGetLastError();
+}
+
 hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_stride,
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                               const Tables &T, const uint32_t *keepmask, uint32_t mask_stride,
@@ -1156,7 +1526,6 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   if (B == 0) return hipSuccess;
   if (group == 0) group = 1;
   group = std::min(group, B);  // (a group larger than the batch is the whole batch)
-  if (kVB == 512 && group > 1) return hipErrorInvalidValue;  // (groups: 16-wave geometry only)
   const uint32_t n_scans = B;
   B = (B + group - 1u) / group;  // work items
   if (!T.voxel_store || T.voxel_store_wgs == 0) return hipErrorInvalidValue;
@@ -1167,25 +1536,97 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   ar.cursor = arena_cursor;
   ar.capacity = arena_capacity;
   ar.scan_start = scan_start;
-  // two persistent workgroups per CU of the handle's device (no more than the handle owns
-  // record stores for); the scan queue is cleared by a memset ahead of every launch (an aborted
-  // launch can therefore not poison the next one)
-  uint32_t grid = std::min<uint32_t>(std::min<uint32_t>(B, voxel_max_workgroups(T.n_cu)),
+  // Which path: the two-kernel path when the handle owns a region store that holds a stage worth
+  // the name (enough waves to fill the device), the fused kernel otherwise (single scans, small
+  // batches, the instrumented build).
+  const uint32_t qn = voxel_regions_per_item(group, n_stride);
+  const uint32_t cps = qn / group;
+  uint32_t stage = 0;
+  if (T.voxel_regions && T.voxel_rcount && T.voxel_two_kernel && (!p.dbg || T.voxel_two_kernel == 2) && qn) {
+    stage = std::min<uint32_t>(B, T.voxel_region_cap / qn);
+    if (T.voxel_stage_items) stage = std::min<uint32_t>(stage, T.voxel_stage_items);
+    if (T.voxel_pipe) stage = std::min<uint32_t>(stage, T.voxel_pipe_items);
+    if (T.voxel_two_kernel < 2 && (uint64_t)stage * qn < 4096u) stage = 0;  // too few waves per stage
+  }
+  if (kVB == 512 && group > 1 && !stage) return hipErrorInvalidValue;  // (fused groups: 16-wave geometry only)
+  // persistent workgroups of the handle's device (no more than the handle owns record stores
+  // for); the item queue is cleared by a memset ahead of every launch (an aborted launch can
+  // therefore not poison the next one)
+  const uint32_t B_launch = stage ? stage : B;
+  uint32_t grid = std::min<uint32_t>(std::min<uint32_t>(B_launch, voxel_max_workgroups(T.n_cu)),
                                      T.voxel_store_wgs);
   if (const char *e = std::getenv("RPLGPU_VOXEL_GRID")) {  // developer aid
     const long g = std::atol(e);
     if (g > 0) grid = std::min<uint32_t>(grid, (uint32_t)g);
   }
-  // (a launch with a workgroup per item does not touch the queue: one command less in front of a
-  // single-scan call)
-  if (grid < B)
-    if (hipError_t e = hipMemsetAsync(T.work_ctr, 0, 4, s); e != hipSuccess) return e;
   // queue statistics of the launch (they pick the NEXT launch's instance): batches only
   const bool with_stats = T.voxel_stats && T.voxel_stats_host && B >= 64u;
   Tables Tk = T;
   if (!with_stats) Tk.voxel_stats = nullptr;
   if (with_stats)
     if (hipError_t e = hipMemsetAsync(T.voxel_stats, 0, 16, s); e != hipSuccess) return e;
+  if (stage) {
+    for (uint32_t i0 = 0; i0 < B; i0 += stage) {
+      const uint32_t Bs = std::min<uint32_t>(stage, B - i0);
+      hipError_t e;
+      if (T.voxel_pipe) {  // task counter, item counter, per-item ready counts; then fork
+        if ((e = hipMemsetAsync(T.voxel_pipe_ctr, 0, (2u + (size_t)Bs) * 4u, s)) != hipSuccess) return e;
+        if ((e = hipEventRecord((hipEvent_t)T.voxel_pipe_ev[0], s)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent((hipStream_t)T.voxel_pipe_stream, (hipEvent_t)T.voxel_pipe_ev[0], 0)) != hipSuccess) return e;
+      }
+#define RPL_RUNS(FD, SF, SP) \
+  e = launch_runs<FD, SF, SP>(s, nodes, n_stride, n_per_scan, p, T, keepmask, mask_stride, i0, Bs, group, n_scans, cps, motion, pose2d, pipe_want)
+      auto launch_cells = [&]() -> hipError_t {
+        const uint32_t g = std::min<uint32_t>(grid, Bs);
+        static bool lds_attr_set = false;  // (> 64 KB of dynamic LDS needs the attribute, once per process)
+        if (!lds_attr_set) {
+          if (hipError_t e2 = hipFuncSetAttribute((const void *)&k_voxel_cells<false>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)sizeof(VoxelLds));
+              e2 != hipSuccess)
+            return e2;
+          lds_attr_set = true;
+        }
+        VoxelPipe pipe{nullptr, nullptr, nullptr};
+        hipStream_t sr = s;
+        if (T.voxel_pipe) {  // the consumer runs next to the producer, on the handle's second stream
+          pipe = VoxelPipe{T.voxel_pipe_ctr, T.voxel_pipe_ctr + 1, T.voxel_pipe_ctr + 2};
+          sr = (hipStream_t)T.voxel_pipe_stream;
+        } else if (g < Bs) {
+          if (hipError_t e2 = hipMemsetAsync(T.work_ctr, 0, 4, s); e2 != hipSuccess) return e2;
+        }
+        hipLaunchKernelGGL((k_voxel_cells<false>), dim3(g), dim3(kVB), sizeof(VoxelLds), sr, p, Tk,
+                           (const uint4 *)T.voxel_regions, (const uint2 *)T.voxel_rcount, (float4 *)xyzi,
+                           out_stride, n_points, status, i0, Bs, qn, ar, (uint4 *)T.voxel_store, pipe);
+        if (hipError_t e2 = hipGetLastError(); e2 != hipSuccess) return e2;
+        if (T.voxel_pipe)  // the caller's stream goes on when the consumer is done
+          if (hipError_t e2 = hipEventRecord((hipEvent_t)T.voxel_pipe_ev[1], sr); e2 != hipSuccess) return e2;
+        return hipSuccess;
+      };
+      if (T.voxel_pipe)  // (first: see k_voxel_runs)
+        if ((e = launch_cells()) != hipSuccess) return e;
+      const uint32_t pipe_want = T.voxel_pipe ? std::min<uint32_t>(std::min<uint32_t>(grid, Bs), T.n_cu ? T.n_cu : 256u) : 0u;
+      const bool sf = p.cell_range_safe != 0, sp = T.voxel_split != 0;
+      if (p.fast_div) {
+        if (sf) { if (sp) RPL_RUNS(true, true, true); else RPL_RUNS(true, true, false); }
+        else { if (sp) RPL_RUNS(true, false, true); else RPL_RUNS(true, false, false); }
+      } else {
+        if (sf) { if (sp) RPL_RUNS(false, true, true); else RPL_RUNS(false, true, false); }
+        else { if (sp) RPL_RUNS(false, false, true); else RPL_RUNS(false, false, false); }
+      }
+#undef RPL_RUNS
+      if (e != hipSuccess) return e;
+      if (!T.voxel_pipe) {
+        if ((e = launch_cells()) != hipSuccess) return e;
+      } else if ((e = hipStreamWaitEvent(s, (hipEvent_t)T.voxel_pipe_ev[1], 0)) != hipSuccess) {
+        return e;
+      }
+    }
+  } else {
+  // (a launch with a workgroup per item does not touch the queue: one command less in front of a
+  // single-scan call)
+  if (grid < B)
+    if (hipError_t e = hipMemsetAsync(T.work_ctr, 0, 4, s); e != hipSuccess) return e;
 #define RPL_LAUNCH_VOXEL(FD, SF, DB, SP)                                                          \
   hipLaunchKernelGGL((k_cloud_voxel<FD, SF, DB, SP>), dim3(grid), dim3(kVB), 0, s, (const uint2 *)nodes, \
                      n_stride, n_per_scan, p, Tk, keepmask, mask_stride, (float4 *)xyzi, out_stride, \
@@ -1207,12 +1648,13 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
     if (p.fast_div) RPL_LAUNCH_VOXEL_SF(true, false, false); else RPL_LAUNCH_VOXEL_SF(false, false, false);
   }
 #undef RPL_LAUNCH_VOXEL_SF
+#undef RPL_LAUNCH_VOXEL
+  }
   if (with_stats) {  // the statistics follow the launch to pinned memory (no wait)
     if (hipError_t e = hipMemcpyAsync(T.voxel_stats_host, T.voxel_stats, 16, hipMemcpyDeviceToHost, s);
         e != hipSuccess)
       return e;
   }
-#undef RPL_LAUNCH_VOXEL
   return hipGetLastError();
 }
 
