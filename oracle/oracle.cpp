@@ -430,3 +430,61 @@ extern "C" uint64_t orc_batch_cloud(const orc_node_t *nodes, size_t n_stride,
   for (auto v : acc) total += v;
   return total;
 }
+
+/* Whole-batch CHECK of a voxelised cloud batch (tests/test_gpu_scale.py): every scan of the batch
+ * through orc_cloud_pipeline on `threads` host threads, compared with the device's output for
+ * that scan — got_xyzi[got_start[b] .. + got_npts[b]), and, when got_keys is given, the device's
+ * (iy + 32768) << 16 | (ix + 32768) word per point.  Per scan res[4 b ..] = {cells the oracle
+ * makes, points whose cell key differs (or all of them when the counts differ), points whose
+ * z != 0 or whose mean intensity differs in any bit, max |dx|,|dy| as float bits}.
+ * Returns the number of scans with a count, key or intensity mismatch. */
+extern "C" uint64_t orc_batch_cloud_check(const orc_node_t *nodes, size_t n_stride,
+                                          const uint32_t *n_per_scan, size_t B,
+                                          const orc_params_t *p, const float *got_xyzi,
+                                          const uint64_t *got_start, const uint32_t *got_npts,
+                                          const uint32_t *got_keys, int threads, uint32_t *res) {
+  int T = std::max(threads, 1);
+  std::vector<uint64_t> bad((size_t)T, 0);
+  struct Buf {
+    std::vector<float> out;
+    std::vector<int32_t> cells;
+  };
+  std::vector<Buf> bufs((size_t)T);
+  for (auto &v : bufs) {
+    v.out.resize(4 * std::max<size_t>(n_stride, 1));
+    v.cells.resize(2 * std::max<size_t>(n_stride, 1));
+  }
+  parallel_over_scans(B, threads, [&](size_t b, int t) {
+    const size_t m = orc_cloud_pipeline(nodes + b * n_stride, n_per_scan[b], p, bufs[t].out.data(),
+                                        bufs[t].cells.data(), nullptr);
+    uint32_t bad_key = 0, bad_int = 0;
+    float worst = 0.0f;
+    if (m != got_npts[b]) {
+      bad_key = (uint32_t)std::max<size_t>(m, got_npts[b]);
+    } else {
+      const float *g = got_xyzi + 4 * got_start[b];
+      const float *w = bufs[t].out.data();
+      for (size_t i = 0; i < m; ++i) {
+        worst = std::max(worst, std::max(std::fabs(g[4 * i] - w[4 * i]), std::fabs(g[4 * i + 1] - w[4 * i + 1])));
+        uint32_t gi, wi;
+        std::memcpy(&gi, g + 4 * i + 3, 4);
+        std::memcpy(&wi, w + 4 * i + 3, 4);
+        bad_int += (gi != wi) || (g[4 * i + 2] != 0.0f);
+        if (got_keys) {
+          const uint32_t want = ((uint32_t)(bufs[t].cells[2 * i + 1] + 32768) << 16) |
+                                (uint32_t)(bufs[t].cells[2 * i] + 32768);
+          bad_key += got_keys[got_start[b] + i] != want;
+        }
+      }
+    }
+    res[4 * b + 0] = (uint32_t)m;
+    res[4 * b + 1] = bad_key;
+    res[4 * b + 2] = bad_int;
+    std::memcpy(&res[4 * b + 3], &worst, 4);
+    bad[t] += (bad_key || bad_int) ? 1 : 0;
+  });
+  uint64_t total = 0;
+  for (auto v : bad) total += v;
+  return total;
+}
+

@@ -124,6 +124,12 @@ uint64_t orc_batch_laserscan(const orc_node_t *nodes, size_t n_stride,
 uint64_t orc_batch_cloud(const orc_node_t *nodes, size_t n_stride,
                          const uint32_t *n_per_scan, size_t B,
                          const orc_params_t *p, int threads);
+/* whole-batch check of a device-made voxel cloud batch against orc_cloud_pipeline (see oracle.cpp) */
+uint64_t orc_batch_cloud_check(const orc_node_t *nodes, size_t n_stride,
+                               const uint32_t *n_per_scan, size_t B, const orc_params_t *p,
+                               const float *got_xyzi, const uint64_t *got_start,
+                               const uint32_t *got_npts, const uint32_t *got_keys, int threads,
+                               uint32_t *res);
 
 
 /* =====================================================================================

@@ -81,6 +81,7 @@ ABI_SYMBOLS = [
     "rplgpu_laserscan_to_cloud",
     "rplgpu_cloud_fused_voxel_dev",
     "rplgpu_set_cell_key_output",
+    "rplgpu_set_voxel_aggregation",
     # include/rplgpu_comm.h
     "rplgpu_comm_unique_id",
     "rplgpu_comm_init",
@@ -202,6 +203,7 @@ def load_library() -> C.CDLL:
     lib.rplgpu_default_params.argtypes = [C.POINTER(Params)]
     lib.rplgpu_default_params.restype = None
     lib.rplgpu_set_stream.argtypes = [vp, vp]
+    lib.rplgpu_set_voxel_aggregation.argtypes = [vp, i32]
     lib.rplgpu_synchronize.argtypes = [vp]
     lib.rplgpu_ascend.argtypes = [vp, vp, sz, C.POINTER(u32)]
     lib.rplgpu_scan_to_laserscan.argtypes = [
@@ -504,6 +506,11 @@ class RplGpu:
         self._check(self._lib.rplgpu_cloud_fused_voxel_dev(
             self._h, d_nodes, n_stride, d_n_per_scan, B, group, C.byref(params), d_motion, d_pose2d,
             d_arena, arena_capacity, d_cursor, d_group_start, d_n_points, d_status))
+
+    def set_voxel_aggregation(self, mode: int = 0):
+        """0 = auto (from the previous batch launch's statistics), 1 = plain, 2 = two-class
+        (include/rplgpu.h RPLGPU_VOXEL_AGG_*).  Results are identical in every mode."""
+        self._check(self._lib.rplgpu_set_voxel_aggregation(self._h, int(mode)))
 
     def set_cell_key_output(self, d_cell_keys: int = 0):
         """Optional voxel output: one u32 per output point, (iy + 32768) << 16 | (ix + 32768)."""

@@ -377,7 +377,12 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
     const uint64_t any = __builtin_amdgcn_ballot_w64(cand != 0xFFFFFFFFu);
     if (any && lane_id() == (uint32_t)__builtin_ctzll(any)) atomicMin(&s_misc[0], cand);
     __syncthreads();
-    if (s_misc[0] != 0xFFFFFFFFu) break;
+    // every wave reads the round's result BEFORE any wave may write the next round's (a wave that
+    // saw "none yet" and ran ahead into the next atomicMin could otherwise make a slower wave
+    // leave the loop one round early: mismatched barriers, front_q read before it is written)
+    const uint32_t found = s_misc[0];
+    __syncthreads();
+    if (found != 0xFFFFFFFFu) break;
   }
   const uint32_t first = s_misc[0];
   if (first == 0xFFFFFFFFu) {  // :151 all invalid -> SL_RESULT_OPERATION_FAIL, buffer untouched

@@ -59,6 +59,7 @@ struct rplgpu_ctx {
   // launch (no synchronisation): they choose the kernel instance of the NEXT launch (voxel_split)
   unsigned long long *h_vstats = nullptr;
   bool voxel_split = false;
+  uint32_t stats_group = 1;           // scans per work item of the launch the statistics come from
   uint32_t n_cu = 0;                  // compute units of `device`
   void *d_vstore = nullptr;           // k_cloud_voxel record stores (one per resident workgroup)
   // the two-kernel voxel path's region store (k_voxel_runs -> k_voxel_cells), allocated by the
@@ -194,7 +195,7 @@ void refresh_voxel_mode(rplgpu_ctx *c) {
   const unsigned long long entries = __atomic_load_n(&c->h_vstats[0], __ATOMIC_RELAXED);
   const unsigned long long items = __atomic_load_n(&c->h_vstats[1], __ATOMIC_RELAXED);
   if (items == 0 || entries > items * 70000ull) return;
-  const unsigned long long avg = entries / items;
+  const unsigned long long avg = entries / (items * std::max(1u, c->stats_group));  // per scan, not per work item
   if (!c->voxel_split && avg > 6500ull) c->voxel_split = true;       // (a clean C3 scan: ~3300)
   else if (c->voxel_split && avg < 4000ull) c->voxel_split = false;  // (1 cm noise, split: ~6200)
 }
@@ -653,9 +654,15 @@ int32_t rplgpu_set_cell_key_output(rplgpu_handle_t h, uint32_t *d_cell_keys) {
   return RPLGPU_OK;
 }
 
-// Developer aid (not part of rplgpu.h): device buffer of 2*B u64 receiving, per scan, the
-// shader cycles k_cloud_voxel spent in its streaming and ranking phases.  0 = fast divides
-// rejected, 1 = accepted, via rplgpu_debug_fast_div.
+int32_t rplgpu_set_voxel_aggregation(rplgpu_handle_t h, int32_t mode) {
+  if (!h || mode < RPLGPU_VOXEL_AGG_AUTO || mode > RPLGPU_VOXEL_AGG_TWO_CLASS) return RPLGPU_ERR_INVALID_ARG;
+  h->force_split = mode == RPLGPU_VOXEL_AGG_AUTO ? -1 : (mode == RPLGPU_VOXEL_AGG_TWO_CLASS ? 1 : 0);
+  return RPLGPU_OK;
+}
+
+// Developer aid (not part of rplgpu.h): device buffer of 16*B u64 receiving, per work item, the
+// shader cycles k_cloud_voxel spent in its phases (slots 0-7: stream, ..., emit; 8-12: the
+// streaming loop's sub-phases).  0 = fast divides rejected, 1 = accepted, via rplgpu_debug_fast_div.
 int32_t rplgpu_debug_set_cycle_buffer(rplgpu_handle_t h, void *d_buf) {
   if (!h) return RPLGPU_ERR_INVALID_ARG;
   h->dbg = (unsigned long long *)d_buf;
@@ -803,8 +810,10 @@ int32_t rplgpu_cloud_arena_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
   if ((rc = ensure_regions(h, B, 1u, n_stride))) return rc;
   RPL_HIP(h, hipMemsetAsync(d_cursor, 0, 8, h->stream));
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "64-bit cursor");
+  const rpl::Tables T_arena = tables_of(h);
+  if (B >= 64u) h->stats_group = 1u;
   RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
-                                     tables_of(h), mask, kMaskStride, nullptr, 0, d_n_points,
+                                     T_arena, mask, kMaskStride, nullptr, 0, d_n_points,
                                      d_status, d_arena, arena_capacity,
                                      reinterpret_cast<unsigned long long *>(d_cursor),
                                      reinterpret_cast<unsigned long long *>(d_scan_start)));
@@ -855,8 +864,10 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
   if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
   if ((rc = ensure_regions(h, B, group, n_stride))) return rc;
   RPL_HIP(h, hipMemsetAsync(d_cursor, 0, 8, h->stream));
+  const rpl::Tables T_fused = tables_of(h);  // (reads the previous launch's statistics: before stats_group changes)
+  if ((B + group - 1u) / group >= 64u) h->stats_group = group;
   RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
-                                     tables_of(h), mask, kMaskStride, nullptr, 0, d_n_points,
+                                     T_fused, mask, kMaskStride, nullptr, 0, d_n_points,
                                      d_status, d_arena, arena_capacity,
                                      reinterpret_cast<unsigned long long *>(d_cursor),
                                      reinterpret_cast<unsigned long long *>(d_group_start), group,

@@ -185,6 +185,7 @@ class ScanPath {
     if (nodes.empty()) return false;  // :561-563
     if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
     if (nodes.size() < min_samples_) return fail("scan below the configured minimum (CPU loop is faster)");
+    last_error_.clear();
     rplgpu_laserscan_layout_t L;
     if (rplgpu_msg_laserscan_layout(frame_id.size(), static_cast<uint32_t>(nodes.size()), &L))
       return fail("frame_id too long");
@@ -209,6 +210,7 @@ class ScanPath {
     if (nodes.empty()) return false;
     if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
     if (nodes.size() < min_samples_) return fail("scan below the configured minimum (CPU loop is faster)");
+    last_error_.clear();
     rplgpu_cloud_layout_t L;
     if (rplgpu_msg_cloud_layout(frame_id.size(), static_cast<uint32_t>(nodes.size()), &L))
       return fail("frame_id too long");
@@ -272,6 +274,7 @@ class ScanPath {
     if (nodes.empty()) return false;
     if (!h_ || nodes.size() > max_n_) return fail("scan larger than the configured capacity");
     if (nodes.size() < min_samples_) return fail("scan below the configured minimum (CPU loop is faster)");
+    last_error_.clear();
     const rplgpu_params_t p = cfg.to_params();
     uint32_t n_points = 0, status = 0;
     const int32_t rc = rplgpu_scan_to_cloud(h_, as_nodes(nodes.data()), nodes.size(), &p,

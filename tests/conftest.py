@@ -44,17 +44,65 @@ def reflibs():
     return oracle_lib.load_ref()
 
 
+_STREAM = None
+
+
+def _shared_stream():
+    """One real stream shared by torch and EVERY handle of the session: tensor fills / copies
+    issued by a test and the library's kernels are then ordered (a handle's own stream would
+    race torch's, and so would a second handle on a stream of its own)."""
+    global _STREAM
+    import torch
+    if _STREAM is None:
+        _STREAM = torch.cuda.Stream(device=0)
+        torch.cuda.set_stream(_STREAM)
+    return _STREAM
+
+
 @pytest.fixture(scope="session")
 def gpu():
     import torch
 
     from rplidar_ros2_driver_amd import RplGpu
     h = RplGpu(device=0, max_samples_per_scan=32768, max_batch=4096)
-    # one real stream shared by torch and the library: tensor fills / copies issued by a test
-    # and the library's kernels are then ordered (the handle's own stream would race torch's)
-    stream = torch.cuda.Stream(device=0)
-    torch.cuda.set_stream(stream)
-    h.set_stream(stream.cuda_stream)
+    h.set_stream(_shared_stream().cuda_stream)
+    yield h
+    torch.cuda.synchronize()
+    h.close()
+
+
+# The voxel path has alternative forms that must give the same clouds: the two-class block
+# aggregation (RPLGPU_VOXEL_AGG_TWO_CLASS, normally picked from the previous launch's statistics)
+# and the two-kernel path (k_voxel_runs + k_voxel_cells, sequential or pipelined; a developer
+# option since round 4, selected by environment variables the library reads in rplgpu_create).
+# `gpu_mode` runs a test once per form, each on its own handle.
+_MODES = {
+    "default": ({}, 0),
+    "two_class": ({}, 2),
+    "two_kernel": ({"RPLGPU_VOXEL_PATH": "two"}, 0),
+    "two_kernel_pipe": ({"RPLGPU_VOXEL_PATH": "two", "RPLGPU_VOXEL_PIPE": "3"}, 0),
+}
+
+
+@pytest.fixture(scope="session", params=list(_MODES))
+def gpu_mode(request):
+    import torch
+
+    from rplidar_ros2_driver_amd import RplGpu
+    env, agg = _MODES[request.param]
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        h = RplGpu(device=0, max_samples_per_scan=32768, max_batch=4096)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    h.set_voxel_aggregation(agg)
+    h.set_stream(_shared_stream().cuda_stream)
+    h.mode_name = request.param
     yield h
     torch.cuda.synchronize()
     h.close()

@@ -75,6 +75,28 @@ class Oracle:
         for name in ("orc_batch_laserscan", "orc_batch_cloud"):
             getattr(lib, name).argtypes = [vp, sz, vp, sz, C.POINTER(OParams), C.c_int]
             getattr(lib, name).restype = C.c_uint64
+        lib.orc_batch_cloud_check.argtypes = [vp, sz, vp, sz, C.POINTER(OParams), vp, vp, vp, vp,
+                                              C.c_int, vp]
+        lib.orc_batch_cloud_check.restype = C.c_uint64
+
+    def batch_cloud_check(self, batch: np.ndarray, p: "OParams", arena: np.ndarray, start: np.ndarray,
+                          npts: np.ndarray, keys, threads: int):
+        """Every scan of `batch` through the cloud oracle (all host threads), compared with the
+        device's output.  Returns (scans with a count / key / intensity mismatch, per-scan table:
+        oracle cells, bad keys, bad intensities, max |dx|,|dy|)."""
+        B, n = batch.shape
+        nodes = np.ascontiguousarray(batch)
+        lens = np.full(B, n, np.uint32)
+        arena = np.ascontiguousarray(arena, np.float32)
+        start = np.ascontiguousarray(start, np.uint64)
+        npts = np.ascontiguousarray(npts, np.uint32)
+        keys = None if keys is None else np.ascontiguousarray(keys, np.uint32)
+        res = np.zeros((B, 4), np.uint32)
+        bad = int(self.lib.orc_batch_cloud_check(
+            nodes.ctypes.data, n, lens.ctypes.data, B, C.byref(p), arena.ctypes.data,
+            start.ctypes.data, npts.ctypes.data, None if keys is None else keys.ctypes.data,
+            int(threads), res.ctypes.data))
+        return bad, res
 
     def ascend(self, nodes: np.ndarray):
         out = np.ascontiguousarray(nodes).copy()

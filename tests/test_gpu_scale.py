@@ -3,9 +3,10 @@
 ``bench.py`` measures BASELINE config 3 — seed 2026, 4096 scans x 32 000 samples through
 ``rplgpu_cloud_arena_dev`` — and reports noisy / uniform variants of the same shape.  These
 tests run exactly those batches through the same entry point and compare with the CPU oracle:
-  * every k-th scan in full (number of cells, (iy, ix) order, centroids <= 1e-6 m, mean
-    intensity bit-exact),
-  * the whole batch through its cell count (the oracle on all host cores),
+  * EVERY scan in full (number of cells, the (iy, ix) key of every point bit-exact and in the
+    oracle's order, centroids <= 1e-6 m, mean intensity bit-exact; the oracle runs the whole
+    batch on all host cores, oracle/oracle.cpp orc_batch_cloud_check),
+  * the same call without the optional cell-key output (the production form) byte for byte,
   * ``status_bits == 0`` and a gap-free arena.
 E1-E5 are not in the reference: the oracle is the spec of SURVEY.md §8(a-ext) ("parity
 unpinned", DESIGN.md §2)."""
@@ -23,7 +24,7 @@ pytestmark = pytest.mark.gpu
 XYZ_TOL = 1e-6
 
 
-def _run_arena(gpu, batch, p, cap_per_scan):
+def _run_arena(gpu, batch, p, cap_per_scan, with_keys=True):
     import torch
     dev = torch.device("cuda:0")
     B, n = batch.shape
@@ -35,9 +36,12 @@ def _run_arena(gpu, batch, p, cap_per_scan):
     d_start = torch.zeros(B, dtype=torch.int64, device=dev)
     d_np = torch.zeros(B, dtype=torch.int32, device=dev)
     d_st = torch.zeros(B, dtype=torch.int32, device=dev)
-    # the optional cell-key output (include/rplgpu.h): one word per output point, same index
-    d_keys = torch.zeros(cap, dtype=torch.int32, device=dev)
-    gpu.set_cell_key_output(d_keys.data_ptr())
+    # the optional cell-key output (include/rplgpu.h): one word per output point, same index.
+    # (It changes how a multi-band scan reaches the arena — count, reserve, write instead of the
+    # temporary cell area + one copy — so every batch is run both ways and the bytes compared.)
+    d_keys = torch.zeros(cap if with_keys else 1, dtype=torch.int32, device=dev)
+    if with_keys:
+        gpu.set_cell_key_output(d_keys.data_ptr())
     try:
         gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_arena.data_ptr(), cap,
                             d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
@@ -47,10 +51,13 @@ def _run_arena(gpu, batch, p, cap_per_scan):
     total = int(d_cur.item())
     return (d_arena[:total].cpu().numpy(), d_start.cpu().numpy(),
             d_np.cpu().numpy().astype(np.int64), d_st.cpu().numpy(), total,
-            d_keys[:total].cpu().numpy().view(np.uint32))
+            d_keys[:total].cpu().numpy().view(np.uint32) if with_keys else None)
 
 
-def _check_batch(gpu, oracle, batch, p, every, cap_per_scan):
+def _check_batch(gpu, oracle, batch, p, cap_per_scan):
+    """EVERY scan of the batch against the oracle (all host cores): number of cells, the (iy, ix)
+    key of every output point bit-exact and in the oracle's order, mean intensity bit-exact, z = 0,
+    centroids within 1e-6 m."""
     B, n = batch.shape
     arena, start, npts, st, total, keys = _run_arena(gpu, batch, p, cap_per_scan)
     assert int(st.max()) == 0, "status_bits"
@@ -59,51 +66,50 @@ def _check_batch(gpu, oracle, batch, p, every, cap_per_scan):
     nz = np.nonzero(npts)[0]
     order = nz[np.argsort(start[nz], kind="stable")]
     assert np.array_equal(np.cumsum(npts[order]) - npts[order], start[order])
-    # whole batch: the oracle's cell count (all host cores)
     op = oracle_lib.copy_params(p)
-    lens = np.full(B, n, np.uint32)
-    nodes = np.ascontiguousarray(batch)
-    want_total = int(oracle.lib.orc_batch_cloud(nodes.ctypes.data, n, lens.ctypes.data, B,
-                                                C.byref(op), os.cpu_count() or 1))
-    assert total == want_total
-    worst = 0.0
-    for b in range(0, B, every):
-        want, wcells, wcounts = oracle.cloud_pipeline(batch[b], op)
-        got = arena[start[b]: start[b] + npts[b]]
-        assert len(got) == len(want), b
-        if not len(want):
-            continue
-        err = np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2]))
-        worst = max(worst, float(err))
-        assert err <= XYZ_TOL, (b, err)
-        assert np.all(got[:, 2] == 0.0)
-        assert got[:, 3].tobytes() == want[:, 3].tobytes(), b  # mean intensity: bit-exact
-        # cell indices: bit-exact.  The kernel's optional cell-key output carries the (iy, ix) every
-        # output point was reduced under; it must be the oracle's cell list, in the oracle's order
-        k = keys[start[b]: start[b] + npts[b]]
-        wkey = ((wcells[:, 1].astype(np.int64) + 32768) << 16 | (wcells[:, 0].astype(np.int64) + 32768))
-        assert np.array_equal(k.astype(np.int64), wkey), b
-        assert np.all(np.diff(k.astype(np.int64)) > 0), b  # strictly ascending (iy, ix)
+    bad, res = oracle.batch_cloud_check(batch, op, arena, start, npts, keys, os.cpu_count() or 1)
+    first = np.nonzero((res[:, 1] != 0) | (res[:, 2] != 0))[0]
+    assert bad == 0, (bad, first[:8], res[first[:8]])
+    assert np.array_equal(res[:, 0].astype(np.int64), npts)
+    worst = float(res[:, 3].copy().view(np.float32).max())
+    assert worst <= XYZ_TOL, worst
+    # keys strictly ascending inside every scan: (iy, ix) order, no cell twice
+    d = np.diff(keys.astype(np.int64))
+    inner = np.ones(total - 1, bool) if total > 1 else np.zeros(0, bool)
+    ends = (start + npts)[npts > 0]
+    inner[ends[ends < total] - 1] = False  # (the step from one scan's last cell to the next scan's first)
+    assert np.all(d[inner] > 0)
+    # the production form of the same call (no cell-key output): the same cloud, byte for byte,
+    # scan by scan (the scans sit in the arena in completion order, which differs between runs)
+    arena2, start2, npts2, st2, total2, _ = _run_arena(gpu, batch, p, cap_per_scan, with_keys=False)
+    assert total2 == total and int(st2.max()) == 0 and np.array_equal(npts2, npts)
+    a1 = np.ascontiguousarray(arena).view(np.uint8).reshape(-1, 16)
+    a2 = np.ascontiguousarray(arena2).view(np.uint8).reshape(-1, 16)
+    idx1 = np.concatenate([np.arange(start[b], start[b] + npts[b]) for b in range(B)]) if total else np.zeros(0, np.int64)
+    idx2 = np.concatenate([np.arange(start2[b], start2[b] + npts2[b]) for b in range(B)]) if total else np.zeros(0, np.int64)
+    assert a1[idx1].tobytes() == a2[idx2].tobytes()
     return total, worst
 
 
-def test_bench_batch_config3_voxel_matches_oracle(gpu, oracle):
+def test_bench_batch_config3_voxel_matches_oracle(gpu_mode, oracle):
+    gpu = gpu_mode
     """The bench batch itself: seed 2026, 4096 x 32 000, the bench parameters."""
     B, n = 4096, 32000
     batch = synth.make_batch(2026, B, n)
     p = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1,
                         voxel_leaf=0.05)
-    total, worst = _check_batch(gpu, oracle, batch, p, every=64, cap_per_scan=8192)
+    total, worst = _check_batch(gpu, oracle, batch, p, cap_per_scan=8192)
     assert total > 9_000_000  # ~2.7 k cells per scan
     # the same batch with the quality filter of BASELINE config 3 switched on
     pq = Params.defaults(clip_enable=1, q_min=48, range_min=0.15, range_max=40.0, voxel_enable=1,
                          voxel_leaf=0.05)
-    total_q, _ = _check_batch(gpu, oracle, batch[:512], pq, every=32, cap_per_scan=8192)
+    total_q, _ = _check_batch(gpu, oracle, batch[:512], pq, cap_per_scan=8192)
     assert 0 < total_q
 
 
 @pytest.mark.parametrize("regime", ["ring_noise_1cm", "uniform"])
-def test_other_regimes_at_full_scan_size(gpu, oracle, regime):
+def test_other_regimes_at_full_scan_size(gpu_mode, oracle, regime):
+    gpu = gpu_mode
     """256 scans x 32 000 samples of the two other generators of SURVEY.md §8(d): a ring with
     1 cm range noise (what a real lidar delivers: neighbouring samples alternate between cells)
     and uniformly random ranges (nearly every sample its own cell)."""
@@ -114,13 +120,55 @@ def test_other_regimes_at_full_scan_size(gpu, oracle, regime):
         batch = synth.make_batch(2026, B, n, noise_m=0.01)
     p = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1,
                         voxel_leaf=0.05)
-    _check_batch(gpu, oracle, batch, p, every=8, cap_per_scan=n)
+    _check_batch(gpu, oracle, batch, p, cap_per_scan=n)
 
 
-def test_c5_shape_ror_voxel_batch_matches_oracle(gpu, oracle):
+def test_c5_shape_ror_voxel_batch_matches_oracle(gpu_mode, oracle):
+    gpu = gpu_mode
     """Config 5 at batch scale: 8 sensors x 8 frames of 32 000 noisy samples, E5 + E4."""
     B, n = 64, 32000
     batch = synth.make_batch(2031, B, n, noise_m=0.01)
     p = Params.defaults(clip_enable=1, range_min=0.15, range_max=40.0, voxel_enable=1,
                         voxel_leaf=0.05, ror_enable=1, ror_radius=0.10, ror_min_neighbors=2)
-    _check_batch(gpu, oracle, batch, p, every=16, cap_per_scan=n)
+    _check_batch(gpu, oracle, batch, p, cap_per_scan=n)
+
+
+def test_every_sample_its_own_run_at_the_largest_scan(gpu_mode, oracle):
+    """The worst case of the record budget: scans of the maximum length whose samples are
+    all valid and all in different cells, so that every sample ends a run and every block adds its
+    marker entries (two per block when the block is aggregated in two classes) — a single scan per
+    work item and a fused group of four sharing one grid."""
+    import torch
+    gpu = gpu_mode
+    dev = torch.device("cuda:0")
+    B, n = 8, 32768
+    batch = synth.make_batch(77, B, n, kind="uniform", invalid_p=0.0)
+    p = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1,
+                        voxel_leaf=0.05)
+    _check_batch(gpu, oracle, batch, p, cap_per_scan=n)
+    # the same scans as two groups of four, identity poses, no motion: one grid per group
+    group = 4
+    ng = B // group
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+    d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
+    cap = B * n
+    d_arena = torch.zeros(cap, 4, dtype=torch.float32, device=dev)
+    d_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_start = torch.zeros(ng, dtype=torch.int64, device=dev)
+    d_np = torch.zeros(ng, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(ng, dtype=torch.int32, device=dev)
+    gpu.cloud_fused_voxel_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, group, p, 0, 0,
+                              d_arena.data_ptr(), cap, d_cur.data_ptr(), d_start.data_ptr(),
+                              d_np.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    assert int(d_st.max()) == 0
+    arena, start, npts = d_arena.cpu().numpy(), d_start.cpu().numpy(), d_np.cpu().numpy()
+    op = oracle_lib.copy_params(p)
+    op.voxel_enable = 0
+    for g in range(ng):
+        pts = np.concatenate([oracle.scan_to_cloud(batch[b], op) for b in range(g * group, (g + 1) * group)])
+        want, _, _ = oracle.voxel_grid(pts, 0.05)
+        got = arena[start[g]: start[g] + npts[g]]
+        assert len(got) == len(want), g
+        assert np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2])) <= XYZ_TOL
+        assert got[:, 2:].tobytes() == want[:, 2:].tobytes()
