@@ -52,7 +52,32 @@ def static_traffic(kernel: str, B: int, n: int):
     ent = rec.get(kernel)
     if not ent or ent.get("scans") != B or ent.get("samples_per_scan") != n:
         return None, None
+    # the record names the kernel source it was measured on: a kernel edited since then gets no
+    # traffic figure (re-run tools/prof.sh) instead of the old one
+    want = ent.get("source_sha256")
+    have = source_sha256(ent.get("source_file", "rplidar_ros2_driver_amd/csrc/rpl_voxel.hip"))
+    if not want or want != have:
+        return None, "stale: profiles/traffic.json was measured on another state of the kernel source " \
+                     f"(recorded {str(want)[:12]}, now {str(have)[:12]}); re-run tools/prof.sh"
     return int(ent["hbm_bytes_per_launch"]), "static: " + str(ent.get("source"))
+
+
+def source_sha256(rel: str):
+    import hashlib
+    try:
+        return hashlib.sha256((ROOT / rel).read_bytes()).hexdigest()
+    except Exception:
+        return None
+
+
+def host_cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
 
 
 def parse_args():
@@ -197,6 +222,7 @@ def cpu_baseline(batch_np, lens_np, params, target_s):
         "value": round(nscans * n / t_all / 1e6, 3),
         "unit": "Mpoints/s",
         "cores": cores,
+        "cpu_model": host_cpu_model(),
         "kind": "port",
         "sample": f"first {nscans} scans x {n} samples of the same batch, best of {passes} "
                   f"passes ({t_all:.2f} s wall each, {cores * t_all:.0f} core-seconds), "
@@ -549,6 +575,9 @@ def main():
         # two chunks, so that the first half's clouds travel while the second half is voxelised)
         n_chunks = args.chunks if args.chunks > 0 else (1 if world == 1 else 2)
         exch = CloudExchange(gpu, dist, dev, world, rank, B, n, out_stride, n_chunks)
+        if exch.native and exch.comm_ranks != world:
+            raise SystemExit(f"--gpus {args.gpus}: the RCCL communicator spans {exch.comm_ranks} rank(s), "
+                             f"not {world}")
 
     def step():
         if exch is None:
@@ -564,11 +593,17 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # the K timed steps: wall clock between two fences (the contract), and HIP events on the launch
+    # stream around the SAME K steps (the device time of the launches alone, <= the wall time)
+    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_a.record(stream)
     for _ in range(args.steps):
         step()
+    ev_b.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
+    loop_dev_ms = ev_a.elapsed_time(ev_b) / args.steps
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -593,6 +628,7 @@ def main():
                         "overlapped_ms": round(elapsed / args.steps * 1e3, 4),
                         "gathered_bytes_per_rank": exch.last_bytes(),
                         "exchange_backend": exch.backend, "chunks": exch.chunks,
+                        "comm_ranks": exch.comm_ranks,
                         "note": "compute = the rank's whole block in one launch, no exchange; "
                                 "exchange_only = RCCL all-gather of the last step's clouds; "
                                 "overlapped = the timed step (chunked, two streams)"}
@@ -624,7 +660,10 @@ def main():
     # back to back (the figure the roofline uses: one event pair around `reps` launches, so the
     # gaps between an event and a launch are not counted reps times) and per launch (min)
     reps = max(args.steps, 5)
-    k_ms_b2b = timed(compute_only_step, stream, reps, lambda: torch.cuda.synchronize(dev))
+    # N = 1: the step IS the launch, so the kernel's average duration is the device time of the
+    # timed loop itself; N > 1: the step also holds the exchange, the launch is timed on its own
+    k_ms_b2b = loop_dev_ms if exch is None else \
+        timed(compute_only_step, stream, reps, lambda: torch.cuda.synchronize(dev))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(reps)]
     for a, b in ev:
@@ -665,11 +704,54 @@ def main():
                 ts.append(a.elapsed_time(b))
             res[name] = min(ts[1:])
         valid = int(d_cnt.to(torch.int64).sum().item())
+
+        def ascend_row(d_src, Bv, ms):
+            """what the call did to the batch: nodes rewritten (filled angle word or moved by the
+            sort), scans whose nodes were reordered; algorithmic bytes = 8 read per node + 8 written
+            per node that changed"""
+            d_w = d_src.clone()
+            gpu.ascend_batch_dev(d_w.data_ptr(), n, d_len.data_ptr(), Bv, d_st.data_ptr())
+            torch.cuda.synchronize(dev)
+            a, b = d_src.view(Bv, n, 8), d_w.view(Bv, n, 8)
+            changed = int((a != b).any(dim=2).sum().item())
+            reordered = int((a[:, :, 2:6] != b[:, :, 2:6]).any(dim=2).any(dim=1).sum().item())
+            del d_w
+            return {"ms": round(ms, 4), "gpts_s": round(Bv * n / ms / 1e6, 1), "scans": Bv,
+                    "nodes_rewritten_frac": round(changed / (Bv * n), 4),
+                    "scans_reordered_frac": round(reordered / Bv, 4),
+                    "frac": round((8 * Bv * n + 8 * changed) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+        asc = {"uniform_angles": ascend_row(d_nodes, B, res["ascend"])}
+        asc["uniform_angles"]["note"] = "the headline batch: exactly uniform angle words, the fill pass " \
+            "recomputes the word already there and nothing needs the sort — the best case"
+        Bv = min(B, 1024)
+        for name, jit, note in (
+                ("jitter1", 1, "valid samples' angle words jittered by +-1 (step 2.05): every filled word "
+                               "differs from the stored one (8-byte stores), the order survives"),
+                ("jitter3", 3, "jitter +-3: neighbouring samples swap, nearly every scan takes the "
+                               "sorting kernel (k_ascend<true>) on top of the streaming one")):
+            vb = synth.make_batch(args.seed + 11, Bv, n, jitter=jit)
+            d_v = torch.from_numpy(vb.view(np.uint8).reshape(Bv, n * 8)).to(dev)
+            d_w = d_v.clone()
+            ts = []
+            for it in range(4):
+                d_w.copy_(d_v)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                gpu.ascend_batch_dev(d_w.data_ptr(), n, d_len.data_ptr(), Bv, d_st.data_ptr())
+                b.record(stream)
+                torch.cuda.synchronize(dev)
+                ts.append(a.elapsed_time(b))
+            asc[name] = ascend_row(d_v, Bv, min(ts[1:]))
+            asc[name]["note"] = note
+            del vb, d_v, d_w
         extra["reference_path_gpu"] = {
             "ascend_ms": round(res["ascend"], 4),
             "laserscan_ms": round(res["laserscan"], 4),
             "ascend_mpts": round(B * n / res["ascend"] / 1e3, 1),
             "laserscan_mpts": round(B * n / res["laserscan"] / 1e3, 1),
+            "ascend_frac": asc["uniform_angles"]["frac"],
+            "ascend_regimes": asc,
             "laserscan_frac": round((8 * B * n + 8 * valid) / (res["laserscan"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         }
         # secondary: the LaserScans of the batch as serialised (CDR) messages in HBM, and the
@@ -803,20 +885,27 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel_ms_avg": round(k_ms_b2b, 4),
                 "kernel_ms_min": round(k_ms[0], 4),
-                "kernel_ms_note": "avg = back-to-back launches between one event pair (this rank's "
-                                  "block); min = best single launch bracketed by its own events",
+                "kernel_ms_note": "avg = HIP events on the launch stream around the K timed steps "
+                                  "themselves (N = 1: a step is the launch + two 8-byte memsets; N > 1: "
+                                  "the launch alone, back to back); min = best single launch bracketed "
+                                  "by its own events",
                 "algorithmic_bytes": algo_bytes,
-                "note": "priced against HBM as SURVEY 8(d) asks; the kernel is not HBM bound: its "
-                        "streaming phase is paced by the compute unit's memory pipeline (raw HBM misses "
-                        "and the L2-resident (cos, sin) table share it, ~36 k cycles per scan whether "
-                        "the loop issues 125 or 92 vector instructions per block), its reduce phase by "
-                        "LDS latency (profiles/r03/voxel_phaseS_r03.txt)",
+                "note": "priced against HBM as SURVEY 8(d) asks; the kernel is not HBM bound: per "
+                        "scan and SIMD the vector ALU is busy 24 k cycles in the streaming phase and "
+                        "13.5 k in the reduce phase (PMC, profiles/r04/voxel_two_kernel_r04.txt: 0.29 ms "
+                        "per launch at 100 % utilisation), the streaming phase is further paced by the "
+                        "CU's vector-memory instruction rate (raw loads, two table gathers per 128 "
+                        "samples) and the reduce phase by LDS latency",
             },
             "cpu_baseline": cpu,
             "variants": variants,
             "c5": c5,
             "compute_only": compute_only,
+            "compute_only_ms": None if compute_only is None else compute_only["ms_per_step"],
+            "exchange_only_ms": None if compute_only is None else compute_only["exchange_only_ms"],
+            "gathered_bytes_per_rank": None if compute_only is None else compute_only["gathered_bytes_per_rank"],
             "exchange_backend": None if compute_only is None else compute_only["exchange_backend"],
+            "exchange_ranks": None if compute_only is None else compute_only.get("comm_ranks"),
             "exchange_bytes_per_point": None if compute_only is None else 12,
             "status_bits": status,
             "cells_out_rank0": cells_local,

@@ -52,6 +52,9 @@ int32_t rplgpu_comm_unique_id(uint8_t id[RPLGPU_COMM_ID_BYTES]);
 int32_t rplgpu_comm_init(rplgpu_handle_t h, int32_t rank, int32_t world,
                          const uint8_t id[RPLGPU_COMM_ID_BYTES]);
 int32_t rplgpu_comm_destroy(rplgpu_handle_t h); /* also done by rplgpu_destroy */
+/* The communicator as RCCL sees it (ncclCommCount / ncclCommUserRank): *world = 0 when the handle
+ * has none.  A launcher checks it against the number of ranks it meant to start. */
+int32_t rplgpu_comm_size(rplgpu_handle_t h, int32_t *world, int32_t *rank);
 
 uint32_t rplgpu_cloud_meta_words(uint32_t max_scans); /* 4 + 3 * max_scans */
 /* Device-side META block of this rank's arena (see above), asynchronous on the main stream.

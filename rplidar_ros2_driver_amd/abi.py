@@ -86,6 +86,7 @@ ABI_SYMBOLS = [
     "rplgpu_comm_unique_id",
     "rplgpu_comm_init",
     "rplgpu_comm_destroy",
+    "rplgpu_comm_size",
     "rplgpu_cloud_meta_words",
     "rplgpu_pack_cloud_meta_dev",
     "rplgpu_allgather_clouds_dev",
@@ -266,6 +267,7 @@ def load_library() -> C.CDLL:
     lib.rplgpu_comm_unique_id.argtypes = [vp]
     lib.rplgpu_comm_init.argtypes = [vp, i32, i32, vp]
     lib.rplgpu_comm_destroy.argtypes = [vp]
+    lib.rplgpu_comm_size.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.rplgpu_cloud_meta_words.argtypes = [u32]
     lib.rplgpu_cloud_meta_words.restype = u32
     lib.rplgpu_pack_cloud_meta_dev.argtypes = [vp, vp, vp, vp, u32, u64, u32, vp]
@@ -530,6 +532,12 @@ class RplGpu:
         uid = np.ascontiguousarray(uid, np.uint8)
         assert uid.nbytes == 128
         self._check(self._lib.rplgpu_comm_init(self._h, rank, world, uid.ctypes.data))
+
+    def comm_size(self):
+        """(ranks, this rank) of the handle's communicator as RCCL reports them; (0, -1) without one."""
+        w, r = C.c_int32(0), C.c_int32(-1)
+        self._check(self._lib.rplgpu_comm_size(self._h, C.byref(w), C.byref(r)))
+        return int(w.value), int(r.value)
 
     def comm_destroy(self):
         self._check(self._lib.rplgpu_comm_destroy(self._h))

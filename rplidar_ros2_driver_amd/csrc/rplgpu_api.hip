@@ -1774,6 +1774,8 @@ struct RcclApi {
   int (*GetUniqueId)(void *) = nullptr;
   int (*CommInitRank)(void **, int, rplgpu_nccl_id_t, int) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
+  int (*CommCount)(void *, int *) = nullptr;
+  int (*CommUserRank)(void *, int *) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
@@ -1793,6 +1795,8 @@ RcclApi &rccl() {
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.lib, "ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(a.lib, "ncclCommCount"));
+    a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(a.lib, "ncclCommUserRank"));
     a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
     a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.lib, "ncclGroupStart"));
     a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
@@ -1843,6 +1847,20 @@ int32_t rplgpu_comm_unique_id(uint8_t id[RPLGPU_COMM_ID_BYTES]) {
   if (!rccl().ok) return RPLGPU_ERR_NO_DEVICE;
   static_assert(sizeof(rplgpu_nccl_id_t) == RPLGPU_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
   return rccl().GetUniqueId(id) == 0 ? RPLGPU_OK : RPLGPU_ERR_HIP;
+}
+
+int32_t rplgpu_comm_size(rplgpu_handle_t h, int32_t *world, int32_t *rank) {
+  if (!h || !world) return RPLGPU_ERR_INVALID_ARG;
+  *world = 0;
+  if (rank) *rank = -1;
+  if (!h->comm) return RPLGPU_OK;  // no communicator: 0 ranks
+  if (!rccl().ok || !rccl().CommCount) return RPLGPU_ERR_NO_DEVICE;
+  int n = 0, r = -1;
+  RPL_NCCL(h, rccl().CommCount(h->comm, &n));  // what RCCL itself says, not what was asked for
+  if (rank && rccl().CommUserRank) RPL_NCCL(h, rccl().CommUserRank(h->comm, &r));
+  *world = n;
+  if (rank) *rank = r;
+  return RPLGPU_OK;
 }
 
 int32_t rplgpu_comm_init(rplgpu_handle_t h, int32_t rank, int32_t world,

@@ -136,6 +136,11 @@ class ScanPath {
   template <class NodeT>
   uint32_t ascendScanData(NodeT *nodebuffer, size_t count) {
     uint32_t sl_result = 0x80008001u;
+    last_error_.clear();
+    if (count < min_samples_) {  // declined: the SDK's own loop is faster for a scan this small
+      last_error_ = "scan below the configured minimum (CPU loop is faster)";
+      return 0x80008002u;
+    }
     if (!h_ || rplgpu_ascend(h_, as_nodes(nodebuffer), count, &sl_result) != RPLGPU_OK) {
       note_error();
       return 0x80008002u;  // SL_RESULT_OPERATION_TIMEOUT class: "did not happen"

@@ -225,6 +225,9 @@ class CloudExchange:
                     gpu.comm_destroy()
                 ok = int(flag.item())
         self.native = bool(ok)
+        # what RCCL itself says about the communicator (bench.py refuses a run whose communicator
+        # does not span the ranks it was asked for)
+        self.comm_ranks = gpu.comm_size()[0] if self.native else None
         self.cursor = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.chunks)]
         self.start = [torch.zeros(self.Bc, dtype=torch.int64, device=dev) for _ in range(self.chunks)]
         self.npts = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(self.chunks)]

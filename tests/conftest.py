@@ -12,6 +12,7 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu2: needs TWO MI355X in one node (real RCCL ranks; skipped below two devices)")
 
 
 def _gpu_present() -> bool:
@@ -24,10 +25,16 @@ def _gpu_present() -> bool:
 
 def pytest_collection_modifyitems(config, items):
     if _gpu_present():
+        import torch
+        if torch.cuda.device_count() < 2:
+            skip2 = pytest.mark.skip(reason="needs two GPUs in one node")
+            for item in items:
+                if "gpu2" in item.keywords:
+                    item.add_marker(skip2)
         return
     skip = pytest.mark.skip(reason="no GPU in this container (GPU tests run via gpurun)")
     for item in items:
-        if "gpu" in item.keywords:
+        if "gpu" in item.keywords or "gpu2" in item.keywords:
             item.add_marker(skip)
 
 
