@@ -100,6 +100,16 @@ int32_t rplgpu_unpack_gathered_dev(rplgpu_handle_t h, const float *d_points_all,
  *                                    points (z = 0 put back) + the per-scan tables */
 int32_t rplgpu_pack_cloud_xyi_dev(rplgpu_handle_t h, const float *d_arena, const uint64_t *d_cursor,
                                   uint64_t slot_points, float *d_slot);
+/* rplgpu_cloud_arena_dev (include/rplgpu.h) writing the 12-byte points ITSELF: d_slot is this rank's
+ * slot of the receive buffer (slot_points x 3 floats), filled by the voxel kernel directly — no
+ * 16-byte arena, no compaction pass in front of the all-gather.  d_cursor / d_scan_start /
+ * d_n_points / d_status as rplgpu_cloud_arena_dev, in points; a cloud that outgrows the slot is cut
+ * and flagged (RPLGPU_SCAN_OUT_TRUNCATED).  The optional cell-key output still has one word per point. */
+int32_t rplgpu_cloud_arena_xyi_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
+                                   uint32_t n_stride, const uint32_t *d_n_per_scan, uint32_t B,
+                                   const rplgpu_params_t *p, float *d_slot, uint64_t slot_points,
+                                   uint64_t *d_cursor, uint64_t *d_scan_start, uint32_t *d_n_points,
+                                   uint32_t *d_status);
 int32_t rplgpu_allgather_clouds_xyi_dev(rplgpu_handle_t h, const float *d_slot_local,
                                         uint64_t slot_points, const uint32_t *d_meta_local,
                                         uint32_t meta_words, float *d_slots_all,

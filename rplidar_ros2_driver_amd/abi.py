@@ -94,6 +94,7 @@ ABI_SYMBOLS = [
     "rplgpu_comm_fence_lag",
     "rplgpu_unpack_gathered_dev",
     "rplgpu_pack_cloud_xyi_dev",
+    "rplgpu_cloud_arena_xyi_dev",
     "rplgpu_allgather_clouds_xyi_dev",
     "rplgpu_unpack_gathered_xyi_dev",
     "rplgpu_pack_cloud_meta_host",
@@ -217,6 +218,8 @@ def load_library() -> C.CDLL:
         vp, vp, u32, vp, u32, C.POINTER(Params), vp, u32, vp, vp]
     lib.rplgpu_pack_clouds_dev.argtypes = [vp, vp, u32, vp, u32, vp, vp]
     lib.rplgpu_cloud_arena_dev.argtypes = [
+        vp, vp, u32, vp, u32, C.POINTER(Params), vp, C.c_uint64, vp, vp, vp, vp]
+    lib.rplgpu_cloud_arena_xyi_dev.argtypes = [
         vp, vp, u32, vp, u32, C.POINTER(Params), vp, C.c_uint64, vp, vp, vp, vp]
     lib.rplgpu_fill_meta.argtypes = [C.POINTER(Params), u32, C.c_double, C.POINTER(ScanMeta)]
     lib.rplgpu_fill_meta.restype = None
@@ -551,6 +554,14 @@ class RplGpu:
                              meta_words: int, d_points_all: int, d_meta_all: int):
         self._check(self._lib.rplgpu_allgather_clouds_dev(
             self._h, d_points_local, slot_points, d_meta_local, meta_words, d_points_all, d_meta_all))
+
+    def cloud_arena_xyi_dev(self, d_nodes: int, n_stride: int, d_n_per_scan: int, B: int, p: Params,
+                            d_slot: int, slot_points: int, d_cursor: int, d_scan_start: int,
+                            d_n_points: int, d_status: int = 0):
+        """cloud_arena_dev writing 12-byte points (x, y, intensity) straight into an exchange slot."""
+        self._check(self._lib.rplgpu_cloud_arena_xyi_dev(
+            self._h, d_nodes, n_stride, d_n_per_scan, B, C.byref(p), d_slot, slot_points, d_cursor,
+            d_scan_start, d_n_points, d_status))
 
     def pack_cloud_xyi_dev(self, d_arena: int, d_cursor: int, slot_points: int, d_slot: int):
         self._check(self._lib.rplgpu_pack_cloud_xyi_dev(self._h, d_arena, d_cursor, slot_points, d_slot))

@@ -66,7 +66,9 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               // E8: `group` consecutive scans share one grid; per-scan motion
                               // (vx, vy, wz, dt) and planar pose (r00 r01 tx r10 r11 ty), optional
                               uint32_t group = 1, const float *motion = nullptr,
-                              const float *pose2d = nullptr);
+                              const float *pose2d = nullptr,
+                              // the arena holds 12-byte points (x, y, intensity): the exchange payload
+                              bool arena_xyi = false);
 // record stores k_cloud_voxel needs: one per resident workgroup (two per CU) ...
 uint32_t voxel_max_workgroups(uint32_t n_cu);
 // ... of this many 16-byte entries for work items of `group` scans of `n_stride` samples: every

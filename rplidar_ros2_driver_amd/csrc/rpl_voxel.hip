@@ -453,6 +453,10 @@ struct VoxelArena {
   unsigned long long *cursor;    // next free point
   unsigned long long capacity;   // points the arena holds
   unsigned long long *scan_start;
+  // 1: the arena holds 12-byte points (x, y, intensity) — the exchange payload of
+  // include/rplgpu_comm.h written by the kernel itself (z is 0 for every point of this path).
+  // `base` then only serves as the origin of point indices: point j is the floats 3 j .. 3 j + 2.
+  int xyi;
 };
 // kEmitArenaTemp (round 3): a scan of several bands writes its cells to the workgroup's temporary
 // cell area (behind its record store) band after band and copies them into the arena once their
@@ -729,8 +733,15 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
       qx = fma(fma(-qx, dc, Sx), rc, qx);
       qy = fma(fma(-qy, dc, Sy), rc, qy);
       qi = fma(fma(-qi, dc, si), rc, qi);
-      out[out_base + c] = make_float4((float)(qx * inv_scale), (float)(qy * inv_scale), 0.0f,
-                                      (float)qi);
+      if (arena.xyi && (mode == kEmitArenaFirst || mode == kEmitArenaKnown)) {
+        float *f = reinterpret_cast<float *>(arena.base) + 3u * (size_t)((out - arena.base) + out_base + c);
+        f[0] = (float)(qx * inv_scale);
+        f[1] = (float)(qy * inv_scale);
+        f[2] = (float)qi;
+      } else {
+        out[out_base + c] = make_float4((float)(qx * inv_scale), (float)(qy * inv_scale), 0.0f,
+                                        (float)qi);
+      }
       if (cell_keys) cell_keys[out_base + c] = key;  // (block-uniform pointer, usually null)
     }
   }
@@ -1132,8 +1143,18 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
       const unsigned long long room = arena_at >= arena.capacity ? 0ull : arena.capacity - arena_at;
       const uint32_t ncopy = (uint32_t)min((unsigned long long)total, room);
       const float4 *src = reinterpret_cast<const float4 *>(G + T.voxel_store_recs);
-      float4 *dst = arena.base + arena_at;
-      for (uint32_t i = threadIdx.x; i < ncopy; i += kVB) dst[i] = src[i];
+      if (arena.xyi) {
+        float *dst = reinterpret_cast<float *>(arena.base) + 3u * (size_t)arena_at;
+        for (uint32_t i = threadIdx.x; i < ncopy; i += kVB) {
+          const float4 v = src[i];
+          dst[3u * i] = v.x;
+          dst[3u * i + 1u] = v.y;
+          dst[3u * i + 2u] = v.w;
+        }
+      } else {
+        float4 *dst = arena.base + arena_at;
+        for (uint32_t i = threadIdx.x; i < ncopy; i += kVB) dst[i] = src[i];
+      }
     }
   }
   if (DBG && p.dbg && threadIdx.x == 0) {
@@ -1522,7 +1543,8 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               float *xyzi, uint32_t out_stride, uint32_t *n_points,
                               uint32_t *status, float *arena, unsigned long long arena_capacity,
                               unsigned long long *arena_cursor, unsigned long long *scan_start,
-                              uint32_t group, const float *motion, const float *pose2d) {
+                              uint32_t group, const float *motion, const float *pose2d,
+                              bool arena_xyi) {
   if (B == 0) return hipSuccess;
   if (group == 0) group = 1;
   group = std::min(group, B);  // (a group larger than the batch is the whole batch)
@@ -1536,6 +1558,7 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   ar.cursor = arena_cursor;
   ar.capacity = arena_capacity;
   ar.scan_start = scan_start;
+  ar.xyi = (arena && arena_xyi) ? 1 : 0;
   // Which path: the two-kernel path when the handle owns a region store that holds a stage worth
   // the name (enough waves to fill the device), the fused kernel otherwise (single scans, small
   // batches, the instrumented build).

@@ -793,10 +793,11 @@ static int32_t prepare_cloud(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, ui
   return RPLGPU_OK;
 }
 
-int32_t rplgpu_cloud_arena_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
+static int32_t cloud_arena_impl(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
                                const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
                                float *d_arena, uint64_t arena_capacity, uint64_t *d_cursor,
-                               uint64_t *d_scan_start, uint32_t *d_n_points, uint32_t *d_status) {
+                               uint64_t *d_scan_start, uint32_t *d_n_points, uint32_t *d_status,
+                               bool xyi) {
   int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
   if (rc) return rc;
   if (!p || !d_arena || !d_cursor || !d_scan_start || !d_n_points) return RPLGPU_ERR_INVALID_ARG;
@@ -816,8 +817,26 @@ int32_t rplgpu_cloud_arena_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
                                      T_arena, mask, kMaskStride, nullptr, 0, d_n_points,
                                      d_status, d_arena, arena_capacity,
                                      reinterpret_cast<unsigned long long *>(d_cursor),
-                                     reinterpret_cast<unsigned long long *>(d_scan_start)));
+                                     reinterpret_cast<unsigned long long *>(d_scan_start), 1u, nullptr,
+                                     nullptr, xyi));
   return RPLGPU_OK;
+}
+
+int32_t rplgpu_cloud_arena_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
+                               const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
+                               float *d_arena, uint64_t arena_capacity, uint64_t *d_cursor,
+                               uint64_t *d_scan_start, uint32_t *d_n_points, uint32_t *d_status) {
+  return cloud_arena_impl(h, d_nodes, n_stride, d_n_per_scan, B, p, d_arena, arena_capacity, d_cursor,
+                          d_scan_start, d_n_points, d_status, false);
+}
+
+int32_t rplgpu_cloud_arena_xyi_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
+                                   uint32_t n_stride, const uint32_t *d_n_per_scan, uint32_t B,
+                                   const rplgpu_params_t *p, float *d_slot, uint64_t slot_points,
+                                   uint64_t *d_cursor, uint64_t *d_scan_start, uint32_t *d_n_points,
+                                   uint32_t *d_status) {
+  return cloud_arena_impl(h, d_nodes, n_stride, d_n_per_scan, B, p, d_slot, slot_points, d_cursor,
+                          d_scan_start, d_n_points, d_status, true);
 }
 
 int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,

@@ -173,8 +173,8 @@ def unpack_gathered(points_all: torch.Tensor, meta_all: torch.Tensor, slot_point
 
 class CloudExchange:
     """bench.py's N > 1 step through the library's own exchange: the rank's block of scans is cut
-    into `chunks`; chunk c is voxelised into the rank's arena, compacted to 12-byte points
-    (x, y, intensity: z is 0 for every point of this path and does not travel) STRAIGHT INTO this
+    into `chunks`; chunk c is voxelised as 12-byte points (x, y, intensity: z is 0 for every point
+    of this path and does not travel) by the voxel kernel itself STRAIGHT INTO this
     rank's slot of chunk c's receive buffer (RCCL's in-place all-gather then moves no local
     bytes) on the handle's main stream, and all-gathered on the exchange stream while chunk c + 1
     is being voxelised.  Every chunk has its own receive buffer, so nothing is reused inside a step and the
@@ -233,7 +233,6 @@ class CloudExchange:
         self.npts = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(self.chunks)]
         self.stat = [torch.zeros(self.Bc, dtype=torch.int32, device=dev) for _ in range(self.chunks)]
         self.slot = None
-        self.arena = None     # per chunk: this rank's voxelised cloud (16-byte points)
         self.recv_pts = None  # per chunk: every rank's compact slot (12-byte points: x, y, intensity)
         self.recv_meta = torch.zeros(self.chunks, world, self.mw, dtype=torch.int32, device=dev)
 
@@ -260,7 +259,6 @@ class CloudExchange:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         # head room 5 % + 256 points: the slot travels whole (an all-gather moves equal pieces)
         self.slot = min(cap, int(int(t.item()) * 1.05) + 256)
-        self.arena = torch.empty(self.chunks, self.slot, 4, dtype=torch.float32, device=self.dev)
         self.recv_pts = torch.empty(self.chunks, self.world, self.slot, 3, dtype=torch.float32,
                                     device=self.dev)
 
@@ -274,11 +272,12 @@ class CloudExchange:
                 continue
             mine = self.recv_pts[c, r]      # this rank's slot of chunk c (in place in the receive buffer)
             meta = self.recv_meta[c, r]
-            g.cloud_arena_dev(d_nodes.data_ptr() + lo * self.n * 8, self.n, d_len.data_ptr() + lo * 4, nb,
-                              params, self.arena[c].data_ptr(), self.slot, self.cursor[c].data_ptr(),
-                              self.start[c].data_ptr(), self.npts[c].data_ptr(), self.stat[c].data_ptr())
-            g.pack_cloud_xyi_dev(self.arena[c].data_ptr(), self.cursor[c].data_ptr(), self.slot,
-                                 mine.data_ptr())
+            # (round 4: the voxel kernel writes the 12-byte points straight into the slot — the
+            # 16-byte arena and the compaction pass in front of the all-gather are gone)
+            g.cloud_arena_xyi_dev(d_nodes.data_ptr() + lo * self.n * 8, self.n, d_len.data_ptr() + lo * 4,
+                                  nb, params, mine.data_ptr(), self.slot, self.cursor[c].data_ptr(),
+                                  self.start[c].data_ptr(), self.npts[c].data_ptr(),
+                                  self.stat[c].data_ptr())
             g.pack_cloud_meta_dev(self.cursor[c].data_ptr(), self.start[c].data_ptr(),
                                   self.npts[c].data_ptr(), nb, self.slot, self.Bc, meta.data_ptr())
             self._gather(c, mine, meta)

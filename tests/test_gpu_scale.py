@@ -172,3 +172,42 @@ def test_every_sample_its_own_run_at_the_largest_scan(gpu_mode, oracle):
         assert len(got) == len(want), g
         assert np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2])) <= XYZ_TOL
         assert got[:, 2:].tobytes() == want[:, 2:].tobytes()
+
+
+@pytest.mark.parametrize("regime", ["ring", "ring_noise_1cm"])
+def test_exchange_slot_written_by_the_kernel_equals_the_packed_arena(gpu_mode, regime):
+    """rplgpu_cloud_arena_xyi_dev (the voxel kernel writes the 12-byte exchange points itself, incl.
+    the multi-band scans that go through the temporary cell area) against rplgpu_cloud_arena_dev:
+    per scan the same (x, y, intensity), bit for bit; a slot too small cuts and flags, never overruns."""
+    import torch
+    gpu = gpu_mode
+    dev = torch.device("cuda:0")
+    B, n = 192, 32000
+    batch = synth.make_batch(2027, B, n, **({"noise_m": 0.01} if regime != "ring" else {}))
+    p = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1,
+                        voxel_leaf=0.05)
+    arena, start, npts, st, total, _ = _run_arena(gpu, batch, p, n, with_keys=False)
+    assert int(st.max()) == 0
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+    d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
+    for slot in (B * n, total, total - 1000):
+        d_slot = torch.full((slot + 64, 3), -7.0, dtype=torch.float32, device=dev)  # (+ guard rows)
+        d_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_start = torch.zeros(B, dtype=torch.int64, device=dev)
+        d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+        gpu.cloud_arena_xyi_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_slot.data_ptr(), slot,
+                                d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+        gpu.synchronize()
+        pts, s2, n2, st2 = d_slot.cpu().numpy(), d_start.cpu().numpy(), d_np.cpu().numpy().astype(np.int64), d_st.cpu().numpy()
+        assert np.all(pts[slot:] == -7.0)  # nothing behind the slot
+        assert int(d_cur.item()) == total  # (the cursor counts every cell, kept or cut)
+        if slot >= total:
+            assert int(st2.max()) == 0 and np.array_equal(n2, npts)
+        else:
+            assert int(n2.sum()) <= slot and np.any(st2 & 8)  # RPLGPU_SCAN_OUT_TRUNCATED
+            assert np.all((n2 == npts) | ((st2 & 8) != 0))
+        for b in range(B):
+            if n2[b] == npts[b] and npts[b]:
+                want = arena[start[b]: start[b] + npts[b]][:, [0, 1, 3]]
+                assert pts[s2[b]: s2[b] + n2[b]].tobytes() == np.ascontiguousarray(want).tobytes(), (slot, b)
