@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of two builds: phase cycles (tools/voxdbg.py) and launch time (tools/dev/vbench.py), alternating
-R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; O=$R/gpurun_out/r4l; mkdir -p $O; export RPL_SYNTH_CACHE=/tmp/rplc
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; O=$R/gpurun_out/r4n; mkdir -p $O; export RPL_SYNTH_CACHE=/tmp/rplc
 LIB=$R/rplidar_ros2_driver_amd/lib
 {
 for i in 1 2; do for v in base new; do
@@ -10,4 +10,4 @@ for i in 1 2; do for v in base new; do
   RPLGPU_LIBRARY=$L timeout 120 python tools/dev/vbench.py 4096 10 0.01 2>&1 | tail -1
 done; done
 } 2>&1 | tee $O/ab.txt
-timeout 600 python -m pytest tests/test_gpu_scale.py tests/test_gpu_fuzz.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
