@@ -248,6 +248,32 @@ int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
                                 uint32_t max_count, rplgpu_node_t *d_batch, uint32_t n_stride,
                                 uint32_t scan_cap, uint32_t *d_n_per_scan, uint32_t *d_n_scans,
                                 uint32_t *d_n_errors, uint32_t *d_status);
+/* A recording longer than one call (rplgpu_decode_max_frames frames per stream and call): the same,
+ * plus the scan a stream is still building when the call ends.  ScanDataHolder keeps that scan in
+ * its operational buffer (src/sdk/src/sl_lidar_driver.cpp:272-310); here it leaves the call in
+ * d_carry_out (d_carry_len_out[b] nodes at d_carry_out + b*carry_stride, at most
+ * min(max_count, carry_stride), the buffer's own "keep overwriting the last slot" rule applied) and
+ * enters the next call as d_carry_in / d_carry_len_in (NULL, NULL for the first call of a recording):
+ * it is completed by that call's first sync node — and delivered as its first scan — unless a
+ * scan-reset request comes first.  Fed call after call with d_state_out -> d_state_in (for the
+ * capsule types each piece after the first starts one frame early with state flags bit 0 set, as for
+ * rplgpu_decode_batch_dev) and
+ * carry_out -> carry_in (two buffers, swapped by the caller; in and out must differ), a recording of
+ * any length becomes exactly the scans one pass of the SDK's unpacker + ScanDataHolder makes of it,
+ * without the host seeing a node.  Every stream takes the decode-then-assemble path here (the
+ * capsule types' fused decoder skips the nodes outside a call's completed scans). */
+int32_t rplgpu_decode_scans_carry_dev(rplgpu_handle_t h, uint8_t ans_type,
+                                      uint32_t sample_duration_us, const uint8_t *d_bytes,
+                                      uint64_t stream_stride, const uint32_t *d_frame_off,
+                                      const uint8_t *d_gap, const uint32_t *d_n_frames,
+                                      uint32_t max_frames, uint32_t B, const int32_t *d_state_in,
+                                      int32_t *d_state_out, uint32_t max_count,
+                                      rplgpu_node_t *d_batch, uint32_t n_stride, uint32_t scan_cap,
+                                      uint32_t *d_n_per_scan, uint32_t *d_n_scans,
+                                      uint32_t *d_n_errors, uint32_t *d_status,
+                                      const rplgpu_node_t *d_carry_in, const uint32_t *d_carry_len_in,
+                                      rplgpu_node_t *d_carry_out, uint32_t *d_carry_len_out,
+                                      uint32_t carry_stride);
 /* One stream of any length, HOST buffers: framing on the host, decode on the GPU in pieces of
  * rplgpu_decode_max_frames frames (overlapping by one frame, see flags bit 0).  No state is kept
  * in the handle: pass state in/out explicitly ({0,0,0,0} for a fresh unpacker).  nodes: cap

@@ -60,6 +60,7 @@ ABI_SYMBOLS = [
     "rplgpu_frame_stream",
     "rplgpu_decode_batch_dev",
     "rplgpu_decode_scans_dev",
+    "rplgpu_decode_scans_carry_dev",
     "rplgpu_segment_batch_dev",
     "rplgpu_scans_to_batch_dev",
     "rplgpu_decode_stream",
@@ -236,6 +237,8 @@ def load_library() -> C.CDLL:
                                             vp, u32, vp, vp, u32, vp, vp, vp]
     lib.rplgpu_decode_scans_dev.argtypes = [vp, u8, u32, vp, u64, vp, vp, vp, u32, u32, vp, vp,
                                             u32, vp, u32, u32, vp, vp, vp, vp]
+    lib.rplgpu_decode_scans_carry_dev.argtypes = [vp, u8, u32, vp, u64, vp, vp, vp, u32, u32, vp, vp,
+                                                  u32, vp, u32, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32]
     lib.rplgpu_segment_batch_dev.argtypes = [vp, vp, u32, vp, vp, u32, vp, u32, u32, vp, u32, vp,
                                              u32, vp, vp]
     lib.rplgpu_scans_to_batch_dev.argtypes = [vp, vp, u32, vp, u32, vp, u32, vp, vp, u32, u32, vp]
@@ -639,6 +642,22 @@ class RplGpu:
             self._h, ans_type, sample_duration_us, d_bytes, stream_stride, d_frame_off, d_gap,
             d_n_frames, max_frames, B, d_state_in, d_state_out, max_count, d_batch, n_stride,
             scan_cap, d_n_per_scan, d_n_scans, d_n_errors, d_status))
+
+    def decode_scans_carry_dev(self, ans_type: int, sample_duration_us: int, d_bytes: int,
+                               stream_stride: int, d_frame_off: int, d_gap: int, d_n_frames: int,
+                               max_frames: int, B: int, d_state_in: int, d_state_out: int,
+                               max_count: int, d_batch: int, n_stride: int, scan_cap: int,
+                               d_n_per_scan: int, d_n_scans: int, d_n_errors: int, d_status: int,
+                               d_carry_in: int, d_carry_len_in: int, d_carry_out: int,
+                               d_carry_len_out: int, carry_stride: int):
+        """decode_scans_dev for one piece of a longer recording: the scan open at the end of the
+        call leaves in d_carry_out and enters the next call as d_carry_in."""
+        self._check(self._lib.rplgpu_decode_scans_carry_dev(
+            self._h, ans_type, sample_duration_us, d_bytes, stream_stride, d_frame_off or None,
+            d_gap or None, d_n_frames, max_frames, B, d_state_in or None, d_state_out or None,
+            max_count, d_batch, n_stride, scan_cap, d_n_per_scan, d_n_scans, d_n_errors or None,
+            d_status, d_carry_in or None, d_carry_len_in or None, d_carry_out, d_carry_len_out,
+            carry_stride))
 
     def segment_batch_dev(self, d_nodes: int, node_stride: int, d_n_nodes: int, d_reset_at: int,
                           reset_stride: int, d_n_reset: int, B: int, max_count: int,

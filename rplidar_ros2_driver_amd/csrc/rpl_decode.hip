@@ -1283,6 +1283,19 @@ __global__ __launch_bounds__(kDecBlock) void k_segment(
   }
 }
 
+// The scan a stream was still building when a call ended (ScanDataHolder's operational buffer,
+// src/sdk/src/sl_lidar_driver.cpp:272-310), carried to the next call (rplgpu_decode_scans_carry_dev):
+// `in` holds it on entry — len_in[b] nodes at in + b * stride —, `out` receives the one open at
+// the end of this call (two buffers: other workgroups of the stream still read `in`).  All null:
+// no carry, a scan across the end of a call belongs to neither.
+struct AssembleCarry {
+  const uint2 *in;
+  uint2 *out;
+  const uint32_t *len_in;
+  uint32_t *len_out;
+  uint32_t stride;
+};
+
 // Scan assembly straight into the batch layout: the same rules as k_segment, but the sync nodes
 // come from the decoder's list and completed scan s of stream b is written to batch slot
 // g = b * scan_cap + s (n_per_scan[g] = its length, 0 for the slots a stream does not fill) —
@@ -1295,7 +1308,7 @@ __global__ __launch_bounds__(kDecBlock) void k_assemble(
     const uint32_t *__restrict__ reset_at, uint32_t reset_stride, const uint32_t *__restrict__ n_reset,
     uint32_t max_count, uint2 *__restrict__ batch, uint32_t n_stride, uint32_t scan_cap,
     uint32_t *__restrict__ n_per_scan, uint32_t *__restrict__ n_scans, uint32_t *__restrict__ status,
-    const uint32_t *__restrict__ only) {
+    const uint32_t *__restrict__ only, AssembleCarry cy) {
   __shared__ uint32_t sync_pos[kSegMaxSync + 1];
   __shared__ uint32_t unsorted[kSegMaxSync + 1];
   __shared__ uint32_t tmp[8];
@@ -1333,9 +1346,20 @@ __global__ __launch_bounds__(kDecBlock) void k_assemble(
   }
   __syncthreads();
   const uint32_t ncand = nsync ? nsync - 1u : 0u;
+  // the carried scan: it completes at this call's first sync node unless a reset request came
+  // first (a request at position p clears the buffer before node p is pushed: any p <= s0)
+  constexpr uint32_t kHead = 0xFFFFFFFEu;
+  const uint32_t ccap = min(max_count, cy.stride);
+  const uint32_t C = cy.in ? min(cy.len_in[b], ccap) : 0u;
+  const uint2 *cin = cy.in ? cy.in + (size_t)b * cy.stride : nullptr;
+  const bool head = C > 0u && nsync >= 1u && !(nr > 0u && rs[0] <= sync_pos[0]);
   // the slot-th completed scan: candidates in order (a stream holds a handful; one lane walks)
   if (tid == 0) {
     uint32_t completed = 0, mine = 0xFFFFFFFFu;
+    if (head) {
+      if (slot == 0u) mine = kHead;
+      completed = 1u;
+    }
     uint32_t ri = 0;  // reset positions <= s0 so far (both lists ascend)
     for (uint32_t j = 0; j < ncand; ++j) {
       const uint32_t s0 = sync_pos[j], s1 = sync_pos[j + 1];
@@ -1357,7 +1381,22 @@ __global__ __launch_bounds__(kDecBlock) void k_assemble(
     if (completed > scan_cap) st |= RPLGPU_STREAM_RESETS_TRUNCATED;
   }
   uint32_t len = 0;
-  if (mine != 0xFFFFFFFFu) {
+  if (mine == kHead) {
+    // carried nodes, then this call's nodes in front of its first sync node; the buffer keeps
+    // max_count nodes and goes on overwriting its last slot (:301-304)
+    const uint32_t s0 = sync_pos[0], total = C + s0;
+    const uint32_t full = min(total, max_count);
+    len = min(full, n_stride);
+    if (full > n_stride) st |= RPLGPU_SCAN_OUT_TRUNCATED;
+    uint2 *dst = batch + (size_t)g * n_stride;
+    const uint32_t body = len ? len - 1u : 0u;
+    for (uint32_t e = tid; e < body; e += kDecBlock) dst[e] = e < C ? cin[e] : in[e - C];
+    if (tid == 0 && len) {
+      const uint32_t e = len - 1u;
+      if (len == full && total > full) dst[e] = s0 ? in[s0 - 1u] : cin[C - 1u];
+      else dst[e] = e < C ? cin[e] : in[e - C];
+    }
+  } else if (mine != 0xFFFFFFFFu) {
     const uint32_t s0 = sync_pos[mine], s1 = sync_pos[mine + 1];
     const uint32_t full = min(s1 - s0, max_count);  // ScanDataHolder keeps max_count nodes
     len = min(full, n_stride);
@@ -1390,6 +1429,35 @@ __global__ __launch_bounds__(kDecBlock) void k_assemble(
       // scan's last node (src/sdk/src/sl_lidar_driver.cpp:286-292)
       const uint32_t last_src = (len == full && (s1 - s0) > full) ? s1 - 1u : s0 + len - 1u;
       dst[len - 1u] = in[last_src];
+    }
+  }
+  if (cy.out && slot == 0u) {
+    // the scan still open at the end of this call: from the last sync node on, unless a reset
+    // request followed it (then nothing is open until the next sync node); without any sync node
+    // the carried scan goes on growing — or was cleared by a reset request
+    uint32_t from_c = 0u, from = n;  // nodes taken from the carried scan / first node taken from `in`
+    bool open = false;
+    if (nsync >= 1u) {
+      const uint32_t s_last = sync_pos[nsync - 1u];
+      open = !(nr > 0u && rs[nr - 1u] > s_last);
+      from = s_last;
+    } else if (C > 0u && nr == 0u) {
+      open = true;
+      from_c = C;
+      from = 0u;
+    }
+    uint2 *cout = cy.out + (size_t)b * cy.stride;
+    const uint32_t total = open ? from_c + (n - from) : 0u;
+    const uint32_t full = min(total, ccap);
+    const uint32_t body = full ? full - 1u : 0u;
+    for (uint32_t e = tid; e < body; e += kDecBlock) cout[e] = e < from_c ? cin[e] : in[from + (e - from_c)];
+    if (tid == 0) {
+      if (full) {
+        const uint32_t e = full - 1u;
+        if (total > full) cout[e] = n > from ? in[n - 1u] : cin[C - 1u];
+        else cout[e] = e < from_c ? cin[e] : in[from + (e - from_c)];
+      }
+      cy.len_out[b] = full;
     }
   }
   if (tid == 0) {
@@ -1533,12 +1601,16 @@ hipError_t launch_assemble(hipStream_t s, const void *nodes, uint32_t node_strid
                            const uint32_t *n_sync, const uint32_t *reset_at, uint32_t reset_stride,
                            const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *batch,
                            uint32_t n_stride, uint32_t scan_cap, uint32_t *n_per_scan,
-                           uint32_t *n_scans, uint32_t *status, const uint32_t *only) {
+                           uint32_t *n_scans, uint32_t *status, const uint32_t *only,
+                           const void *carry_in, void *carry_out, const uint32_t *carry_len_in,
+                           uint32_t *carry_len_out, uint32_t carry_stride) {
   if (B == 0 || scan_cap == 0) return hipSuccess;
+  const AssembleCarry cy{(const uint2 *)carry_in, (uint2 *)carry_out, carry_len_in, carry_len_out,
+                         carry_stride};
   hipLaunchKernelGGL(k_assemble, dim3(B, scan_cap), dim3(kDecBlock), 0, s, (const uint2 *)nodes,
                      node_stride, n_nodes, sync_at, sync_stride, n_sync, reset_at, reset_stride,
                      n_reset, max_count, (uint2 *)batch, n_stride, scan_cap, n_per_scan, n_scans,
-                     status, only);
+                     status, only, cy);
   return hipGetLastError();
 }
 uint32_t decode_sync_stride() { return kSegMaxSync + 1u; }

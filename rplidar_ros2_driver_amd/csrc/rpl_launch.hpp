@@ -141,7 +141,11 @@ hipError_t launch_assemble(hipStream_t s, const void *nodes, uint32_t node_strid
                            const uint32_t *n_sync, const uint32_t *reset_at, uint32_t reset_stride,
                            const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *batch,
                            uint32_t n_stride, uint32_t scan_cap, uint32_t *n_per_scan,
-                           uint32_t *n_scans, uint32_t *status, const uint32_t *only = nullptr);
+                           uint32_t *n_scans, uint32_t *status, const uint32_t *only = nullptr,
+                           // the scan open at a call boundary (rplgpu_decode_scans_carry_dev), or nulls
+                           const void *carry_in = nullptr, void *carry_out = nullptr,
+                           const uint32_t *carry_len_in = nullptr, uint32_t *carry_len_out = nullptr,
+                           uint32_t carry_stride = 0);
 uint32_t decode_sync_stride();
 hipError_t launch_scans_to_batch(hipStream_t s, const void *seg_nodes, uint32_t seg_stride,
                                  const uint32_t *scan_off, uint32_t scan_cap,

@@ -1171,15 +1171,24 @@ int32_t rplgpu_decode_batch_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
   return RPLGPU_OK;
 }
 
-int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
+static int32_t decode_scans_impl(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
                                 const uint8_t *d_bytes, uint64_t stream_stride,
                                 const uint32_t *d_frame_off, const uint8_t *d_gap,
                                 const uint32_t *d_n_frames, uint32_t max_frames, uint32_t B,
                                 const int32_t *d_state_in, int32_t *d_state_out,
                                 uint32_t max_count, rplgpu_node_t *d_batch, uint32_t n_stride,
                                 uint32_t scan_cap, uint32_t *d_n_per_scan, uint32_t *d_n_scans,
-                                uint32_t *d_n_errors, uint32_t *d_status) {
+                                uint32_t *d_n_errors, uint32_t *d_status,
+                                const rplgpu_node_t *d_carry_in, const uint32_t *d_carry_len_in,
+                                rplgpu_node_t *d_carry_out, uint32_t *d_carry_len_out,
+                                uint32_t carry_stride) {
   if (!h) return RPLGPU_ERR_INVALID_ARG;
+  const bool carry = d_carry_out != nullptr;
+  if (carry) {
+    if (!d_carry_len_out || carry_stride == 0 || (d_carry_in == nullptr) != (d_carry_len_in == nullptr) ||
+        d_carry_in == d_carry_out)
+      return RPLGPU_ERR_INVALID_ARG;
+  }
   const size_t npf = rplgpu_nodes_per_frame(ans_type);
   if (!npf || max_count == 0 || scan_cap == 0 || n_stride == 0) return RPLGPU_ERR_INVALID_ARG;
   if (sample_duration_us == 0 || sample_duration_us > 1000000u) return RPLGPU_ERR_INVALID_ARG;
@@ -1228,7 +1237,9 @@ int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
   // sync nodes / reset requests than its tables hold raises t_todo[b] and takes the general path
   // below (decode to the node stream, then assemble), which skips every stream already done.
   const uint32_t *only = nullptr;
-  if (rpl::decode_fusable(ans_type)) {
+  // (with a carried scan every stream takes the general path: the fused decoder neither decodes
+  // the nodes in front of a call's first sync node nor those behind its last)
+  if (!carry && rpl::decode_fusable(ans_type)) {
     RPL_HIP(h, rpl::launch_decode_fused(h->stream, ans_type, d_bytes, stream_stride, d_frame_off,
                                         d_gap, d_n_frames, max_frames, B, sample_duration_us,
                                         d_state_in, d_state_out, d_n_errors, d_status, max_count,
@@ -1241,8 +1252,49 @@ int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
                                 d_n_errors, d_status, t_sync, sync_stride, t_ns, only));
   RPL_HIP(h, rpl::launch_assemble(h->stream, t_nodes, node_stride, t_nn, t_sync, sync_stride, t_ns,
                                   t_rst, reset_stride, t_nr, B, max_count, d_batch, n_stride,
-                                  scan_cap, d_n_per_scan, d_n_scans, d_status, only));
+                                  scan_cap, d_n_per_scan, d_n_scans, d_status, only, d_carry_in,
+                                  d_carry_out, d_carry_len_in, d_carry_len_out, carry_stride));
   return RPLGPU_OK;
+}
+
+int32_t rplgpu_decode_scans_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sample_duration_us,
+                                const uint8_t *d_bytes, uint64_t stream_stride,
+                                const uint32_t *d_frame_off, const uint8_t *d_gap,
+                                const uint32_t *d_n_frames, uint32_t max_frames, uint32_t B,
+                                const int32_t *d_state_in, int32_t *d_state_out,
+                                uint32_t max_count, rplgpu_node_t *d_batch, uint32_t n_stride,
+                                uint32_t scan_cap, uint32_t *d_n_per_scan, uint32_t *d_n_scans,
+                                uint32_t *d_n_errors, uint32_t *d_status) {
+  return decode_scans_impl(h, ans_type, sample_duration_us, d_bytes, stream_stride, d_frame_off, d_gap,
+                           d_n_frames, max_frames, B, d_state_in, d_state_out, max_count, d_batch,
+                           n_stride, scan_cap, d_n_per_scan, d_n_scans, d_n_errors, d_status, nullptr,
+                           nullptr, nullptr, nullptr, 0u);
+}
+
+int32_t rplgpu_decode_scans_carry_dev(rplgpu_handle_t h, uint8_t ans_type,
+                                      uint32_t sample_duration_us, const uint8_t *d_bytes,
+                                      uint64_t stream_stride, const uint32_t *d_frame_off,
+                                      const uint8_t *d_gap, const uint32_t *d_n_frames,
+                                      uint32_t max_frames, uint32_t B, const int32_t *d_state_in,
+                                      int32_t *d_state_out, uint32_t max_count,
+                                      rplgpu_node_t *d_batch, uint32_t n_stride, uint32_t scan_cap,
+                                      uint32_t *d_n_per_scan, uint32_t *d_n_scans,
+                                      uint32_t *d_n_errors, uint32_t *d_status,
+                                      const rplgpu_node_t *d_carry_in, const uint32_t *d_carry_len_in,
+                                      rplgpu_node_t *d_carry_out, uint32_t *d_carry_len_out,
+                                      uint32_t carry_stride) {
+  if (!d_carry_out) return RPLGPU_ERR_INVALID_ARG;
+  if (h && B) {
+    if (!device_readable(h, d_carry_out, "d_carry_out") ||
+        !device_readable(h, d_carry_len_out, "d_carry_len_out") ||
+        (d_carry_in && (!device_readable(h, d_carry_in, "d_carry_in") ||
+                        !device_readable(h, d_carry_len_in, "d_carry_len_in"))))
+      return RPLGPU_ERR_INVALID_ARG;
+  }
+  return decode_scans_impl(h, ans_type, sample_duration_us, d_bytes, stream_stride, d_frame_off, d_gap,
+                           d_n_frames, max_frames, B, d_state_in, d_state_out, max_count, d_batch,
+                           n_stride, scan_cap, d_n_per_scan, d_n_scans, d_n_errors, d_status,
+                           d_carry_in, d_carry_len_in, d_carry_out, d_carry_len_out, carry_stride);
 }
 
 int32_t rplgpu_segment_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,

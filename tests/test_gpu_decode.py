@@ -526,6 +526,95 @@ def test_decode_scans_carried_state_through_the_fused_path(gpu, oracle, ans):
                 assert batch[b * scan_cap + s_, :keep].tobytes() == want[:keep].tobytes(), (hex(ans), b, s_)
 
 
+@pytest.mark.parametrize("ans", ALL_ANS)
+def test_long_recording_becomes_scans_across_calls(gpu, oracle, ans):
+    """rplgpu_decode_scans_carry_dev: recordings cut into pieces of a few dozen frames (cuts anywhere:
+    inside scans, right at sync nodes, pieces without any sync node, pieces with corrupted frames that
+    raise scan-reset requests), decoder state and the open scan carried from call to call.  All
+    pieces together must deliver exactly the scans ONE pass of the unpacker + ScanDataHolder makes of
+    the whole recording (oracle.unpack + oracle.segment, pinned against the genuine SDK), in order."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    S = cp.FRAME_SIZE[ans]
+    # (HQ frames carry their 96 sync flags in a random payload: dozens of tiny scans per frame, so
+    # fewer frames, more and shorter batch slots)
+    B, nf = 6, (420 if ans != 0x83 else 40)
+    rng = np.random.default_rng(ans)
+    streams = []
+    for b in range(B):
+        d = cp.make_stream(ans, nf, 5200 + 17 * b + ans, payload="ring" if b % 2 else "random",
+                           frames_per_rev=(3.3, 9.7, 25.0, 61.0, 130.0, 500.0)[b]).copy()
+        if b in (1, 4):  # a few broken frames: checksum failures -> scan-reset requests mid-recording
+            for f in rng.choice(nf - 2, 3, replace=False):
+                d[(f + 1) * S + S // 2] ^= 0x5A
+        streams.append(d)
+    max_count, n_stride, scan_cap = (8192, 2048, 64) if ans != 0x83 else (8192, 64, 1024)
+    # the whole recording in one pass: the expectation
+    want = []
+    for d in streams:
+        nodes, rst, err, _ = oracle.unpack(ans, d, 125)
+        scans, off = oracle.segment(nodes, rst, max_count)
+        want.append([scans[off[i]: off[i + 1]] for i in range(len(off) - 1)])
+    assert sum(len(w) for w in want) >= 12
+    # ... and in pieces; (frames per piece differ per call, one piece shorter than a revolution)
+    pieces = [37, 5, 64, 1, 90, 23, 200] if ans != 0x83 else [7, 1, 12, 3, 9, 2, 6]
+    assert sum(pieces) == nf
+    carry_stride = max_count
+    d_carry = [torch.zeros(B, carry_stride * 8, dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_clen = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2)]
+    d_state = [torch.zeros(B, 4, dtype=torch.int32, device=dev) for _ in range(2)]
+    got = [[] for _ in range(B)]
+    at = 0
+    caps = ans in (0x82, 0x84, 0x85, 0x86)
+    for k, pf in enumerate(pieces):
+        # a capsule piece after the first starts one frame early, state flags bit 0 set: that frame
+        # only serves as the predecessor of the next one (include/rplgpu.h, rplgpu_decode_batch_dev)
+        lo = at - 1 if (caps and k) else at
+        buf = np.stack([d[lo * S: (at + pf) * S] for d in streams])
+        at += pf
+        pf = buf.shape[1] // S
+        if k:
+            d_state[k & 1][:, 2] = 1 if caps else 0
+        d_bytes = torch.from_numpy(np.ascontiguousarray(buf)).to(dev)
+        d_nf = torch.full((B,), pf, dtype=torch.int32, device=dev)
+        d_batch = torch.zeros(B * scan_cap, n_stride * 8, dtype=torch.uint8, device=dev)
+        d_len = torch.full((B * scan_cap,), -1, dtype=torch.int32, device=dev)
+        d_ns = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_ne = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+        i, o = k & 1, (k + 1) & 1
+        gpu.decode_scans_carry_dev(ans, 125, d_bytes.data_ptr(), pf * S, 0, 0, d_nf.data_ptr(), pf, B,
+                                   d_state[i].data_ptr(), d_state[o].data_ptr(), max_count,
+                                   d_batch.data_ptr(), n_stride, scan_cap, d_len.data_ptr(),
+                                   d_ns.data_ptr(), d_ne.data_ptr(), d_st.data_ptr(),
+                                   d_carry[i].data_ptr() if k else 0, d_clen[i].data_ptr() if k else 0,
+                                   d_carry[o].data_ptr(), d_clen[o].data_ptr(), carry_stride)
+        gpu.synchronize()
+        # (RPLGPU_SCAN_OUT_TRUNCATED = 8 is expected for the streams whose revolutions hold more
+        # nodes than a batch slot: the slot then has the scan's first n_stride nodes)
+        assert int(d_st.max()) & ~8 == 0
+        batch = d_batch.cpu().numpy().view(NODE_DTYPE).reshape(B * scan_cap, n_stride)
+        lens, ns = d_len.cpu().numpy(), d_ns.cpu().numpy()
+        for b in range(B):
+            for s_ in range(ns[b]):
+                got[b].append(batch[b * scan_cap + s_, : lens[b * scan_cap + s_]].copy())
+            assert np.all(lens[b * scan_cap + ns[b]: (b + 1) * scan_cap] == 0)
+    for b in range(B):
+        assert len(got[b]) == len(want[b]), (hex(ans), b, len(got[b]), len(want[b]))
+        for j, (g, w) in enumerate(zip(got[b], want[b])):
+            keep = min(len(w), n_stride)
+            assert len(g) == keep and g.tobytes() == w[:keep].tobytes(), (hex(ans), b, j)
+    # what is still open at the end of the recording is the oracle's unfinished scan
+    clen = d_clen[len(pieces) & 1].cpu().numpy()
+    for b, d in enumerate(streams):
+        nodes, rst, _, _ = oracle.unpack(ans, d, 125)
+        sync = np.flatnonzero(nodes["flag"] & 1)
+        open_len = 0
+        if len(sync) and not np.any(np.asarray(rst) > sync[-1]):
+            open_len = min(len(nodes) - sync[-1], max_count)
+        assert clen[b] == open_len, (hex(ans), b)
+
+
 def test_decode_full_size_properties(gpu):
     """BASELINE config-3 shape for the decode stage (4096 DenseBoost streams x 801 capsules =
     131 M nodes), checked through size-independent properties computed on the device:

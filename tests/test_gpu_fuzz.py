@@ -61,7 +61,7 @@ def _unique_valid_angles(nodes):
 
 
 # RPL_FUZZ_SEEDS=400 for a long run (25 scans x parameter draws per seed)
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RPL_FUZZ_SEEDS", "12"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RPL_FUZZ_SEEDS", "48"))))
 def test_fuzz_against_oracle(gpu, oracle, seed):
     rng = np.random.default_rng(9000 + seed)
     for it in range(25):
@@ -122,7 +122,7 @@ def test_fuzz_against_oracle(gpu, oracle, seed):
             assert got[:, 3].tobytes() == wantc[:, 3].tobytes(), ctx
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("RPL_FUZZ_SEEDS", "12"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RPL_FUZZ_SEEDS", "48"))))
 def test_fuzz_decode_against_oracle(gpu, oracle, seed):
     """Recorded answer streams of all six types: random lengths, heavy fault rates, pure byte
     soup, and recordings cut at arbitrary frame boundaries with the state carried over —
