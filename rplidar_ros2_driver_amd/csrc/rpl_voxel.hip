@@ -1601,15 +1601,12 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   e = launch_runs<FD, SF, SP>(s, nodes, n_stride, n_per_scan, p, T, keepmask, mask_stride, i0, Bs, group, n_scans, cps, motion, pose2d, pipe_want)
       auto launch_cells = [&]() -> hipError_t {
         const uint32_t g = std::min<uint32_t>(grid, Bs);
-        static bool lds_attr_set = false;  // (> 64 KB of dynamic LDS needs the attribute, once per process)
-        if (!lds_attr_set) {
-          if (hipError_t e2 = hipFuncSetAttribute((const void *)&k_voxel_cells<false>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)sizeof(VoxelLds));
-              e2 != hipSuccess)
-            return e2;
-          lds_attr_set = true;
-        }
+        // (> 64 KB of dynamic LDS needs the attribute; it is per device, the call is cheap)
+        if (hipError_t e2 = hipFuncSetAttribute((const void *)&k_voxel_cells<false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)sizeof(VoxelLds));
+            e2 != hipSuccess)
+          return e2;
         VoxelPipe pipe{nullptr, nullptr, nullptr};
         hipStream_t sr = s;
         if (T.voxel_pipe) {  // the consumer runs next to the producer, on the handle's second stream
