@@ -158,6 +158,7 @@ def test_fuzz_decode_against_oracle(gpu, oracle, seed):
             assert nodes.tobytes() == w_nodes.tobytes(), ctx
             assert list(rst) == list(w_rst) and err == w_err and st == w_st, ctx
             _fuzz_decode_scans(gpu, oracle, ans, data, dur, state, w_nodes, w_rst, w_err, w_st, rng, ctx)
+            _fuzz_decode_scans_carry(gpu, oracle, ans, data, dur, state, w_nodes, w_rst, w_err, w_st, rng, ctx)
             # the same recording in two pieces, state handed over (cut on a frame boundary of
             # the clean stream; for faulty streams the cut lands anywhere, which is the point)
             S = cp.FRAME_SIZE[ans]
@@ -214,3 +215,72 @@ def _fuzz_decode_scans(gpu, oracle, ans, data, dur, state, w_nodes, w_rst, w_err
         scan = scans[w_off[s_]: w_off[s_ + 1]]
         keep = min(len(scan), n_stride)
         assert lens[s_] == keep and batch[s_, :keep].tobytes() == scan[:keep].tobytes(), (ctx, s_)
+
+
+def _fuzz_decode_scans_carry(gpu, oracle, ans, data, dur, state, w_nodes, w_rst, w_err, w_st, rng, ctx):
+    """The same stream through rplgpu_decode_scans_carry_dev in random pieces (host framing, pieces cut
+    at arbitrary frames, a capsule piece after the first one frame early with flags bit 0, decoder
+    state and the open scan handed from call to call, random ScanDataHolder capacity): the scans of
+    all pieces together == oracle.segment of the oracle's nodes for the WHOLE stream."""
+    import torch
+    from rplidar_ros2_driver_amd import NODE_DTYPE, abi
+    dev = torch.device("cuda:0")
+    off, gap = abi.frame_stream(ans, data)
+    max_frames = abi.load_library().rplgpu_decode_max_frames(ans)
+    nf = len(off)
+    if nf < 2 or nf > max_frames:
+        return
+    max_count = int(rng.choice([8192, 37, 5]))
+    scans, w_off = oracle.segment(w_nodes, w_rst, max_count)
+    n_want = len(w_off) - 1
+    scan_cap = 512
+    if n_want > scan_cap or len(w_nodes) > 200000:
+        return
+    n_stride = int(min(max(np.diff(w_off).max() if n_want else 1, 1), 8192))
+    caps = ans in (0x82, 0x84, 0x85, 0x86)
+    cuts = sorted(set(int(c) for c in rng.integers(1, nf, int(rng.integers(1, 5)))))
+    bounds = [0] + cuts + [nf]
+    d_bytes = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+    off = np.asarray(off, np.uint32)
+    gap = np.asarray(gap, np.uint8)
+    d_carry = [torch.zeros(max(max_count, 1) * 8, dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_clen = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
+    d_state = [torch.tensor([state[0], state[1], 0, 0], dtype=torch.int32, device=dev),
+               torch.zeros(4, dtype=torch.int32, device=dev)]
+    got, errs = [], 0
+    for k in range(len(bounds) - 1):
+        first, end = bounds[k], bounds[k + 1]
+        lo = first - 1 if (caps and k) else first
+        cnt = end - lo
+        d_off = torch.from_numpy(np.ascontiguousarray(off[lo:end]).view(np.int32)).to(dev)
+        d_gap = torch.from_numpy(np.ascontiguousarray(gap[lo:end])).to(dev)
+        d_nf = torch.tensor([cnt], dtype=torch.int32, device=dev)
+        i, o = k & 1, (k + 1) & 1
+        d_state[i][2] = 1 if (caps and k) else 0
+        d_batch = torch.zeros(scan_cap, n_stride * 8, dtype=torch.uint8, device=dev)
+        d_len = torch.full((scan_cap,), -1, dtype=torch.int32, device=dev)
+        d_ns = torch.zeros(1, dtype=torch.int32, device=dev)
+        d_ne = torch.zeros(1, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(1, dtype=torch.int32, device=dev)
+        gpu.decode_scans_carry_dev(ans, dur, d_bytes.data_ptr(), len(data), d_off.data_ptr(), d_gap.data_ptr(),
+                                   d_nf.data_ptr(), cnt, 1, d_state[i].data_ptr(), d_state[o].data_ptr(),
+                                   max_count, d_batch.data_ptr(), n_stride, scan_cap, d_len.data_ptr(),
+                                   d_ns.data_ptr(), d_ne.data_ptr(), d_st.data_ptr(),
+                                   d_carry[i].data_ptr() if k else 0, d_clen[i].data_ptr() if k else 0,
+                                   d_carry[o].data_ptr(), d_clen[o].data_ptr(), max(max_count, 1))
+        gpu.synchronize()
+        assert int(d_st.item()) & ~8 == 0, (ctx, k, int(d_st.item()))
+        errs += int(d_ne.item())
+        lens = d_len.cpu().numpy()
+        batch = d_batch.cpu().numpy().view(NODE_DTYPE).reshape(scan_cap, n_stride)
+        for s_ in range(int(d_ns.item())):
+            got.append(batch[s_, : lens[s_]].copy())
+    last = len(bounds) - 1
+    assert errs == w_err, (ctx, "errors")
+    assert tuple(int(v) for v in d_state[last & 1].cpu().numpy()[:2]) == tuple(w_st), (ctx, "state")
+    assert len(got) == n_want, (ctx, len(got), n_want, bounds)
+    for j, g in enumerate(got):
+        want = scans[w_off[j]: w_off[j + 1]]
+        keep = min(len(want), n_stride)
+        assert len(g) == keep and g.tobytes() == want[:keep].tobytes(), (ctx, j, bounds)
+
