@@ -57,6 +57,7 @@ ABI_SYMBOLS = [
     "rplgpu_frame_size",
     "rplgpu_nodes_per_frame",
     "rplgpu_decode_max_frames",
+    "rplgpu_decode_staged_frames",
     "rplgpu_frame_stream",
     "rplgpu_decode_batch_dev",
     "rplgpu_decode_scans_dev",
@@ -231,6 +232,8 @@ def load_library() -> C.CDLL:
     lib.rplgpu_nodes_per_frame.restype = sz
     lib.rplgpu_decode_max_frames.argtypes = [u8]
     lib.rplgpu_decode_max_frames.restype = u32
+    lib.rplgpu_decode_staged_frames.argtypes = [u8]
+    lib.rplgpu_decode_staged_frames.restype = u32
     lib.rplgpu_frame_stream.argtypes = [u8, vp, sz, vp, vp, sz]
     lib.rplgpu_frame_stream.restype = sz
     lib.rplgpu_decode_batch_dev.argtypes = [vp, u8, u32, vp, u64, vp, vp, vp, u32, u32, vp, vp,

@@ -32,7 +32,10 @@
 namespace rpl {
 
 constexpr int kDecBlock = 256;
-constexpr uint32_t kDecMaxFrames = 2048;     // frames of one stream per call (LDS frame table)
+#ifndef RPL_DEC_MAXFRAMES
+#define RPL_DEC_MAXFRAMES 2048
+#endif
+constexpr uint32_t kDecMaxFrames = RPL_DEC_MAXFRAMES;     // frames of one stream per call (LDS frame table)
 constexpr uint32_t kUdMaxFrames = 512;       // ultra-dense: 64 nodes each -> 32768 LDS slots
 // LDS is sized per answer type so that several streams share a CU (a 32 000-sample DenseBoost
 // scan is 800 frames): dense 25 KiB, express / ultra 16 KiB, HQ 34 KiB, ultra-dense 24 KiB
@@ -97,6 +100,34 @@ __device__ __forceinline__ uint4 ld128(const uint8_t *p) {
   return v;
 }
 
+// Where a workgroup reads its stream from: global memory, or (STG) a copy of the stream's bytes
+// the workgroup made in LDS before anything else — byte offset `off` of the stream in both cases.
+// LDS reads are aligned dwords re-aligned with v_alignbyte (a frame starts at any byte).
+template <bool STG>
+struct DecSrc {
+  const uint8_t *g;
+  const uint32_t *l;
+  __device__ __forceinline__ uint32_t u32(uint32_t off) const {
+    if (!STG) return ld32(g + off);
+    const uint32_t a = off >> 2;
+    return __builtin_amdgcn_alignbyte(l[a + 1u], l[a], off & 3u);
+  }
+  __device__ __forceinline__ uint32_t u16(uint32_t off) const {
+    if (!STG) return ld16(g + off);
+    return u32(off) & 0xFFFFu;
+  }
+  __device__ __forceinline__ uint32_t u8(uint32_t off) const {
+    if (!STG) return ld8(g + off);
+    return (l[off >> 2] >> (8u * (off & 3u))) & 0xFFu;
+  }
+  __device__ __forceinline__ uint64_t u64(uint32_t off) const {
+    if (!STG) return ld64(g + off);
+    const uint32_t a = off >> 2, w0 = l[a], w1 = l[a + 1u], w2 = l[a + 2u];
+    return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, off & 3u) |
+           ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, off & 3u) << 32);
+  }
+};
+
 __host__ __device__ constexpr uint32_t dec_frame_size(int ans) {
   return ans == RPLGPU_ANS_MEASUREMENT            ? 5u
          : ans == RPLGPU_ANS_CAPSULED             ? 84u
@@ -114,6 +145,22 @@ __host__ __device__ constexpr uint32_t dec_nodes_per_frame(int ans) {
          : ans == RPLGPU_ANS_DENSE_CAPSULED       ? 40u
          : ans == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? 64u
                                                   : 0u;
+}
+
+// k_decode<..., STG>: byte offsets inside the dynamic LDS of a workgroup whose call allows `mf` frames
+struct DecStageLayout {
+  uint32_t raw_at, raw_words, frame_at, emit_at, total;
+};
+__host__ __device__ inline DecStageLayout dec_stage_layout(int ans, uint32_t mf) {
+  DecStageLayout l;
+  // (+16: the re-aligning reads of the last bytes look a dword or two further)
+  l.raw_at = ((mf * dec_frame_size(ans) + 15u) & ~15u) + 16u;
+  const bool filtered = ans == RPLGPU_ANS_DENSE_CAPSULED || ans == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
+  l.raw_words = filtered ? (mf * dec_nodes_per_frame(ans) + 63u) / 64u : 0u;
+  l.frame_at = l.raw_at + 8u * l.raw_words;
+  l.emit_at = l.frame_at + 4u * mf;
+  l.total = (l.emit_at + 2u * mf + 15u) & ~15u;
+  return l;
 }
 
 // the common tail of every capsule decoder (e.g. :246-257): wrap the Q6 angle once, build the
@@ -216,12 +263,12 @@ __device__ __forceinline__ uint32_t hq_crc_64frames(const uint8_t *base, uint32_
   return (((crc ^ 0xFFFFFFFFu) == stored) ? 1u : 0u) | (first << 8);
 }
 
-template <int ANS>
+template <int ANS, bool STG>  // STG: the three per-frame tables live in the dynamic part, sized by the call
 struct DecodeLds {
   // per frame: bit31 valid, bits 0..15 start_angle_sync_q6
-  uint32_t frame[DecCfg<ANS>::kTableSlots];
-  uint16_t emit_frame[DecCfg<ANS>::kTableSlots];  // compacted list of the frames that publish nodes
-  unsigned long long rawbits[DecCfg<ANS>::kRawBitWords];  // dense types: raw sync bit per node
+  uint32_t frame[STG ? 1u : DecCfg<ANS>::kTableSlots];
+  uint16_t emit_frame[STG ? 1u : DecCfg<ANS>::kTableSlots];  // compacted list of the frames that publish nodes
+  unsigned long long rawbits[STG ? 1u : DecCfg<ANS>::kRawBitWords];  // dense types: raw sync bit per node
   uint16_t smooth[DecCfg<ANS>::kSmoothSlots];  // ultra-dense: bit15 scale 0, bits 0..13 raw dist_q2
   uint32_t crc_table[DecCfg<ANS>::kCrcWords];  // HQ: slicing-by-4 tables
   uint32_t stage[DecCfg<ANS>::kStageWords];    // HQ: per wave, 64 frames x 16 words (+1 pad)
@@ -234,14 +281,15 @@ struct DecodeLds {
   uint32_t misc[8];  // 0 status, 3 last sync out, 4 last dist out, 5 error count, 6 sync nodes
 };
 
+template <int NT = kDecBlock>
 __device__ __forceinline__ uint32_t dec_block_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
-  // exclusive scan over kDecBlock = 256 threads (4 waves)
+  // exclusive scan over the workgroup's NT threads (NT / 64 waves)
   uint32_t inc = wave_incl_scan(v);
   if (lane_id() == 63) tmp[wave_id()] = inc;
   __syncthreads();
   uint32_t base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < kDecBlock / 64; ++w) {
+  for (int w = 0; w < NT / 64; ++w) {
     const uint32_t t = tmp[w];
     if (w < (int)wave_id()) base += t;
     tot += t;
@@ -262,8 +310,10 @@ struct DecFuse {
   uint32_t n_stride, scan_cap, max_count;
 };
 
-template <int ANS, bool FRAMED, bool FUSE>  // FRAMED: frame offsets (and gaps) given; else back to back
-__global__ __launch_bounds__(kDecBlock) void k_decode(
+// FRAMED: frame offsets (and gaps) given; else back to back.  STG: the workgroup (NT threads) copies
+// its stream into LDS first and decodes from there (see the head of the kernel).
+template <int ANS, bool FRAMED, bool FUSE, bool STG = false, int NT = kDecBlock>
+__global__ __launch_bounds__(NT) void k_decode(
     const uint8_t *__restrict__ bytes, uint64_t stream_stride, const uint32_t *__restrict__ frame_off,
     const uint8_t *__restrict__ gap, const uint32_t *__restrict__ n_frames, uint32_t max_frames,
     uint32_t sample_duration_us, const int32_t *__restrict__ state_in,
@@ -278,8 +328,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
                         ANS == RPLGPU_ANS_DENSE_CAPSULED || ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
   constexpr bool FILTERED = ANS == RPLGPU_ANS_DENSE_CAPSULED || ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
   constexpr uint32_t SA_OFF = ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? 8u : 2u;
-  __shared__ DecodeLds<ANS> L;
-  constexpr uint32_t kRawBitWords = DecCfg<ANS>::kRawBitWords;
+  __shared__ DecodeLds<ANS, STG> L;
 
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
   if (!FUSE && fz.only && fz.only[b] == 0u) return;  // (the fused kernel dealt with this stream)
@@ -291,13 +340,47 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   auto frame_ptr = [&](uint32_t k) -> const uint8_t * {
     return base + (FRAMED ? (size_t)foff[k] : (size_t)k * S);
   };
+  auto frame_at = [&](uint32_t k) -> uint32_t { return FRAMED ? foff[k] : k * S; };
+#ifdef RPL_DEC_DBG
+  const unsigned long long dbg_start = __builtin_amdgcn_s_memtime();
+#endif
+  // STG: the dynamic part of the workgroup's LDS = [the stream's bytes | raw sync bits | frame table |
+  // emit list], the three tables sized by the call's max_frames (dec_stage_layout, shared with the
+  // launcher).  While other workgroups of the CU have node stores in flight every global load of
+  // the CU queues behind them (profiles/r02/decode_study.txt section 3): P1 and P3 of the plain kernel
+  // wait that queue out once per trip.  Here the stream crosses it ONCE, as one burst of 16-byte
+  // loads issued before this workgroup has stored anything, and both passes read LDS.
+  extern __shared__ uint4 dec_stage[];
+  static_assert(!STG || (CAPS && !FRAMED), "STG: back-to-back capsule streams");
+  static_assert(ANS != RPLGPU_ANS_HQ || NT == 256, "HQ: one CRC table entry per thread");
+  const DecStageLayout lay = dec_stage_layout(ANS, STG ? min(max_frames, DecCfg<ANS>::kMaxFrames) : 0u);
+  uint8_t *dyn = reinterpret_cast<uint8_t *>(dec_stage);
+  const uint32_t raw_words = STG ? lay.raw_words : DecCfg<ANS>::kRawBitWords;
+  unsigned long long *Lraw = STG ? reinterpret_cast<unsigned long long *>(dyn + lay.raw_at) : L.rawbits;
+  uint32_t *Lframe = STG ? reinterpret_cast<uint32_t *>(dyn + lay.frame_at) : L.frame;
+  uint16_t *Lemit = STG ? reinterpret_cast<uint16_t *>(dyn + lay.emit_at) : L.emit_frame;
+  const DecSrc<STG> src{base, reinterpret_cast<const uint32_t *>(dec_stage)};
+  if (STG) {
+    const uint32_t nbytes = nf * S, n16 = nbytes >> 4;
+    constexpr uint32_t UN = 4;
+    uint32_t i = tid;
+    for (; i + (UN - 1u) * NT < n16; i += UN * NT) {
+      uint4 v[UN];
+#pragma unroll
+      for (uint32_t u = 0; u < UN; ++u) v[u] = ld128(base + 16u * (size_t)(i + u * NT));
+#pragma unroll
+      for (uint32_t u = 0; u < UN; ++u) dec_stage[i + u * NT] = v[u];
+    }
+    for (; i < n16; i += NT) dec_stage[i] = ld128(base + 16u * (size_t)i);
+    for (uint32_t q = (n16 << 4) + tid; q < nbytes; q += NT) dyn[q] = base[q];
+  }
 
   // state word 2, bit 0: frame 0 is the previous call's last frame, handed over again only as
   // the predecessor of frame 1 (its errors / reset request / nodes were accounted for then)
   const bool carry0 = CAPS && state_in && (state_in[4 * b + 2] & 1);
   if (tid < 8) L.misc[tid] = 0u;
   if (ANS == RPLGPU_ANS_HQ) {
-    uint32_t c = tid;  // kDecBlock == 256 table entries
+    uint32_t c = tid;  // NT == 256 table entries
 #pragma unroll
     for (int j = 0; j < 8; ++j) c = (c & 1u) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
     L.crc_table[tid] = c;
@@ -309,14 +392,14 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     }
   }
   if (FILTERED) {  // raw sync bits are rare: P3 sets them with an LDS atomic, so start from zero
-    const uint32_t nw = min(kRawBitWords, (uint32_t)(((uint64_t)nf * NPF + 63u) >> 6));
-    for (uint32_t w = tid; w < nw; w += kDecBlock) L.rawbits[w] = 0ull;
+    const uint32_t nw = min(raw_words, (uint32_t)(((uint64_t)nf * NPF + 63u) >> 6));
+    for (uint32_t w = tid; w < nw; w += NT) Lraw[w] = 0ull;
   }
   if (ANS == RPLGPU_ANS_CAPSULED_ULTRA) {
     // handler_capsules.cpp:545-556: offsetAngleMean_q16 depends on the distance only through
     // k2 = 98361 / dist (0 .. 491 for dist >= 200); entry 492 = the default for dist < 200.
     // The reference's double arithmetic, done once per value instead of once per node.
-    for (uint32_t k2 = tid; k2 < 493u; k2 += kDecBlock) {
+    for (uint32_t k2 = tid; k2 < 493u; k2 += NT) {
       int off_q16 = (int)(7.5 * 3.1415926535 * (1 << 16) / 180.0);
       if (k2 < 492u) {
         const int kk = (int)k2;
@@ -336,20 +419,20 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   uint32_t my_err = 0, unframed = 0;
   if (ANS == RPLGPU_ANS_HQ) {  // handler_hqnode.cpp:99-172, a wave per 64 frames
     uint32_t *stg = L.stage + wave_id() * (64u * 17u);
-    for (uint32_t k0 = wave_id() * 64u; k0 < nf; k0 += kDecBlock) {
+    for (uint32_t k0 = wave_id() * 64u; k0 < nf; k0 += NT) {
       const uint32_t k = k0 + lane_id();
       const bool live = k < nf;
       const uint32_t my_off = live ? (FRAMED ? foff[k] : k * S) : 0u;
       const uint32_t res = hq_crc_64frames(base, my_off, min(nf - k0, 64u), stg, L.crc_table);
       if (live) {
         if (!FRAMED && (res >> 8) != 0xA5u) unframed = 1;
-        L.frame[k] = (res & 1u) ? 0x80000000u : 0u;
+        Lframe[k] = (res & 1u) ? 0x80000000u : 0u;
         my_err += (res & 1u) ? 0u : 1u;
       }
     }
   }
   if (ANS == RPLGPU_ANS_MEASUREMENT && !FRAMED) {  // handler_normalnode.cpp:88-112
-    for (uint32_t k = tid; k < nf; k += kDecBlock) {
+    for (uint32_t k = tid; k < nf; k += NT) {
       const uint8_t *f = frame_ptr(k);
       const uint32_t b0 = ld8(f), b1 = ld8(f + 1);
       if (!((((b0 >> 1) ^ b0) & 1u) && (b1 & 1u))) unframed = 1;
@@ -364,24 +447,50 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     // Alone this pass takes 30 k cycles per 801-frame stream; next to other workgroups' node
     // stores it takes 130 k whatever its shape — it queues behind them (decode_study.txt).
     constexpr uint32_t LPF = 8, NDW = (S + 3u) / 4u, TRIPS = (NDW + LPF - 1u) / LPF;
-    constexpr uint32_t FPT = kDecBlock / LPF, DEPTH = 4;  // frames per trip, trips in flight
+    constexpr uint32_t FPT = NT / LPF, DEPTH = 4;  // frames per trip, trips in flight
     const uint32_t j = tid & (LPF - 1u);
-    for (uint32_t k0 = 0; k0 < nf; k0 += DEPTH * FPT) {
+    // STG: out of LDS a lane takes a whole frame (its dwords are an odd number of banks apart from
+    // the neighbour's: no conflicts, no cross-lane reduction)
+    for (uint32_t k = tid; STG && k < nf; k += NT) {
+      const uint32_t f = frame_at(k);
+      uint32_t xw = 0, first = 0;
+#pragma unroll
+      for (uint32_t d = 0; d < NDW; ++d) {
+        uint32_t w = 0;
+        if (4u * d + 4u <= S) {
+          w = src.u32(f + 4u * d);
+        } else {
+#pragma unroll
+          for (uint32_t q = 0; q < (S & 3u); ++q) w |= src.u8(f + 4u * d + q) << (8u * q);
+        }
+        if (d == 0u) first = w;
+        xw ^= w;
+      }
+      const uint32_t b0 = first & 0xFFu, b1 = (first >> 8) & 0xFFu;
+      if ((b0 >> 4) != 0xAu || (b1 >> 4) != 0x5u) unframed = 1;
+      xw ^= xw >> 16;
+      const uint32_t x = ((xw ^ (xw >> 8)) ^ b0 ^ b1) & 0xFFu;
+      const bool ok = (((b0 & 0xFu) | (b1 << 4)) & 0xFFu) == x;
+      my_err += (ok || (carry0 && k == 0u)) ? 0u : 1u;
+      const uint32_t sa = SA_OFF == 2u ? (first >> 16) : src.u16(f + SA_OFF);
+      Lframe[k] = (ok ? 0x80000000u : 0u) | sa;
+    }
+    for (uint32_t k0 = 0; !STG && k0 < nf; k0 += DEPTH * FPT) {
       uint32_t v[DEPTH][TRIPS];
 #pragma unroll
       for (uint32_t u = 0; u < DEPTH; ++u) {
         const uint32_t k = k0 + u * FPT + tid / LPF;
         const bool live = k < nf;
-        const uint8_t *f = frame_ptr(live ? k : 0u);
+        const uint32_t f = frame_at(live ? k : 0u);
 #pragma unroll
         for (uint32_t i = 0; i < TRIPS; ++i) {
           const uint32_t d = j + LPF * i;
           uint32_t w = 0;
           if (live && 4u * d + 4u <= S) {
-            w = ld32(f + 4u * d);
+            w = src.u32(f + 4u * d);
           } else if ((S & 3u) != 0u && live && d == NDW - 1u) {  // the frame's last, partial dword
 #pragma unroll
-            for (uint32_t q = 0; q < (S & 3u); ++q) w |= (uint32_t)f[4u * (NDW - 1u) + q] << (8u * q);
+            for (uint32_t q = 0; q < (S & 3u); ++q) w |= src.u8(f + 4u * (NDW - 1u) + q) << (8u * q);
           }
           v[u][i] = w;
         }
@@ -404,8 +513,8 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
           const uint32_t x = ((xw ^ (xw >> 8)) ^ b0 ^ b1) & 0xFFu;
           const bool ok = (((b0 & 0xFu) | (b1 << 4)) & 0xFFu) == x;
           my_err += (ok || (carry0 && k == 0u)) ? 0u : 1u;
-          const uint32_t sa = SA_OFF == 2u ? (first >> 16) : ld16(frame_ptr(k) + SA_OFF);
-          L.frame[k] = (ok ? 0x80000000u : 0u) | sa;
+          const uint32_t sa = SA_OFF == 2u ? (first >> 16) : src.u16(frame_at(k) + SA_OFF);
+          Lframe[k] = (ok ? 0x80000000u : 0u) | sa;
         }
       }
     }
@@ -425,21 +534,21 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
                                        (1000000u / sample_duration_us)) << 8)
                               : 0;
   if (!DecCfg<ANS>::kTable && !bad_framing) carry_emit = nf;  // every legacy node publishes
-  for (uint32_t k0 = 0; k0 < nf && !bad_framing && DecCfg<ANS>::kTable; k0 += kDecBlock) {
+  for (uint32_t k0 = 0; k0 < nf && !bad_framing && DecCfg<ANS>::kTable; k0 += NT) {
     const uint32_t k = k0 + tid;
     uint32_t emits = 0, resets = 0;
     if (k < nf) {
-      const uint32_t rec = L.frame[k];
+      const uint32_t rec = Lframe[k];
       if (!CAPS) {
         emits = rec >> 31;
       } else if (rec >> 31) {
         resets = (rec >> 15) & 1u;  // revolution start: publishNewScanReset (:160-171)
         if (carry0 && k == 0u) resets = 0u;
-        const bool prev_ok = k > 0 && (L.frame[k - 1] >> 31) && !(fgap && fgap[k]);
+        const bool prev_ok = k > 0 && (Lframe[k - 1] >> 31) && !(fgap && fgap[k]);
         if (prev_ok && !resets) {
           emits = 1;
           if (FILTERED) {  // :750-754 / :971-975: too large an angle step -> discard
-            const int cur_q8 = (int)(rec & 0x7FFFu) << 2, prev_q8 = (int)(L.frame[k - 1] & 0x7FFFu) << 2;
+            const int cur_q8 = (int)(rec & 0x7FFFu) << 2, prev_q8 = (int)(Lframe[k - 1] & 0x7FFFu) << 2;
             int diff = cur_q8 - prev_q8;
             if (prev_q8 > cur_q8) diff += (360 << 8);
             if (diff > thr_q8) emits = 0;
@@ -448,9 +557,9 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       }
     }
     uint32_t tot_e, tot_r;
-    const uint32_t ex_e = dec_block_scan(emits, L.tmp, &tot_e);
-    const uint32_t ex_r = dec_block_scan(resets, L.tmp, &tot_r);
-    if (emits) L.emit_frame[carry_emit + ex_e] = (uint16_t)k;
+    const uint32_t ex_e = dec_block_scan<NT>(emits, L.tmp, &tot_e);
+    const uint32_t ex_r = dec_block_scan<NT>(resets, L.tmp, &tot_r);
+    if (emits) Lemit[carry_emit + ex_e] = (uint16_t)k;
     if (resets) {
       const uint32_t slot = carry_reset + ex_r;
       if (reset_at && slot < reset_stride)
@@ -472,8 +581,8 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   // last node's bit (the state carried to the next call).
   auto sync_filter = [&](auto on_sync) {
     const uint32_t nwords = (carry_nodes + 63u) >> 6;
-    for (uint32_t w = tid; w < nwords && w < kRawBitWords; w += kDecBlock) {
-      unsigned long long m = L.rawbits[w];
+    for (uint32_t w = tid; w < nwords && w < raw_words; w += NT) {
+      unsigned long long m = Lraw[w];
       while (m) {
         const uint32_t bit = (uint32_t)__builtin_ctzll(m);
         m &= m - 1ull;
@@ -482,7 +591,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
         // carried-in state when the run reaches the start of the stream)
         uint32_t run = 0;
         int j = (int)i - 1;
-        while (j >= 0 && ((L.rawbits[j >> 6] >> (j & 63)) & 1ull)) { ++run; --j; }
+        while (j >= 0 && ((Lraw[j >> 6] >> (j & 63)) & 1ull)) { ++run; --j; }
         if (j < 0 && last_sync_in) {
           // s_{-1} = 1 acts like one more raw bit in front of the run
           ++run;
@@ -494,7 +603,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     }
     if (tid == 0 && carry_nodes) {
       const uint32_t i = carry_nodes - 1u;
-      if (!((L.rawbits[i >> 6] >> (i & 63)) & 1ull)) L.misc[3] = 0u;
+      if (!((Lraw[i >> 6] >> (i & 63)) & 1ull)) L.misc[3] = 0u;
     }
   };
 
@@ -504,9 +613,9 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     constexpr uint32_t kSyn = DecCfg<ANS>::kFuseSyn, kRst = DecCfg<ANS>::kFuseRst;
     // every node's raw sync bit: ((angle + step) mod 360 deg) < step (dense: 2 x step), a function
     // of the two start angles of its capsule pair (:246-257 and siblings) — one lane per frame
-    for (uint32_t e = tid; e < n_emit; e += kDecBlock) {
-      const uint32_t k = L.emit_frame[e];
-      const int cur_q8 = (int)(L.frame[k] & 0x7FFFu) << 2, prev_q8 = (int)(L.frame[k - 1] & 0x7FFFu) << 2;
+    for (uint32_t e = tid; e < n_emit; e += NT) {
+      const uint32_t k = Lemit[e];
+      const int cur_q8 = (int)(Lframe[k] & 0x7FFFu) << 2, prev_q8 = (int)(Lframe[k - 1] & 0x7FFFu) << 2;
       int diff_q8 = cur_q8 - prev_q8;
       if (prev_q8 > cur_q8) diff_q8 += (360 << 8);
       const int inc = ANS == RPLGPU_ANS_CAPSULED         ? diff_q8 << 3
@@ -519,7 +628,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
         if (((ang + inc) % (360 << 16)) < lim) {
           const uint32_t i = e * NPF + pos;
           if (FILTERED) {
-            atomicOr(&L.rawbits[i >> 6], 1ull << (i & 63u));
+            atomicOr(&Lraw[i >> 6], 1ull << (i & 63u));
           } else {
             const uint32_t at = atomicAdd(&L.misc[6], 1u);
             if (at < kSyn) L.syn[at] = i;
@@ -561,7 +670,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       }
     }
     uint32_t completed;
-    const uint32_t slot = dec_block_scan(ok, L.tmp, &completed);
+    const uint32_t slot = dec_block_scan<NT>(ok, L.tmp, &completed);
     if (tid < kSyn) L.sslot[tid] = (ok && slot < fz.scan_cap) ? (uint16_t)slot : (uint16_t)0xFFFFu;
     uint32_t st_bits = 0;
     if (ok && slot < fz.scan_cap) {
@@ -571,7 +680,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     }
     if (completed > fz.scan_cap) st_bits |= RPLGPU_STREAM_RESETS_TRUNCATED;
     if (st_bits) atomicOr(&L.misc[0], st_bits);
-    for (uint32_t q = min(completed, fz.scan_cap) + tid; q < fz.scan_cap; q += kDecBlock)
+    for (uint32_t q = min(completed, fz.scan_cap) + tid; q < fz.scan_cap; q += NT)
       fz.n_per_scan[(size_t)b * fz.scan_cap + q] = 0u;
     if (tid == 0) fz.n_scans[b] = min(completed, fz.scan_cap);
     __syncthreads();
@@ -645,7 +754,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       g.live = in_stored || crosses || ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED;
       if (!g.live) return;
     }
-    const uint32_t k = DecCfg<ANS>::kTable ? (uint32_t)L.emit_frame[e] : e;
+    const uint32_t k = DecCfg<ANS>::kTable ? (uint32_t)Lemit[e] : e;
     constexpr bool kPrev = CAPS;  // capsule types decode frame k-1 with frame k's start angle
     if (FRAMED) {
       g.off_cur = foff[k];
@@ -657,8 +766,8 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     if (CAPS) {
       // signed arithmetic throughout, as in the reference: a corrupted-but-checksummed start
       // angle above 360 deg makes the step (and everything derived from it) negative
-      const int cur_q8 = (int)(L.frame[k] & 0x7FFFu) << 2;
-      g.prev_q8 = (int)(L.frame[k - 1] & 0x7FFFu) << 2;
+      const int cur_q8 = (int)(Lframe[k] & 0x7FFFu) << 2;
+      g.prev_q8 = (int)(Lframe[k - 1] & 0x7FFFu) << 2;
       g.diff_q8 = cur_q8 - g.prev_q8;
       if (g.prev_q8 > cur_q8) g.diff_q8 += (360 << 8);
     }
@@ -673,21 +782,21 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       g.a = ld128(f);
       g.c = ld128(f + 16);
     } else {
-      const uint8_t *prev = base + g.off_prev;
+      const uint32_t prev = g.off_prev;
       if (ANS == RPLGPU_ANS_CAPSULED) {  // two cabins of 5 bytes
-        const uint8_t *c = prev + 4u + 5u * (g.pos0 >> 1);
-        g.w = ld64(c);
-        g.w2 = ld16(c + 8);
+        const uint32_t c = prev + 4u + 5u * (g.pos0 >> 1);
+        g.w = src.u64(c);
+        g.w2 = src.u16(c + 8u);
       } else if (ANS == RPLGPU_ANS_CAPSULED_ULTRA) {  // two cabins of 4 bytes + the one behind
         const uint32_t cab0 = g.pos0 / 3u;  // even
-        g.w = ld64(prev + 4u + 4u * cab0);
-        g.w2 = (cab0 + 2u == 32u) ? ld32(base + g.off_cur + 4u) : ld32(prev + 4u + 4u * (cab0 + 2u));
+        g.w = src.u64(prev + 4u + 4u * cab0);
+        g.w2 = (cab0 + 2u == 32u) ? src.u32(g.off_cur + 4u) : src.u32(prev + 4u + 4u * (cab0 + 2u));
       } else if (ANS == RPLGPU_ANS_DENSE_CAPSULED) {  // four 16-bit distances
-        g.w = ld64(prev + 4u + 2u * g.pos0);
+        g.w = src.u64(prev + 4u + 2u * g.pos0);
       } else {  // ultra dense: two cabins of 5 bytes
-        const uint8_t *c = prev + 10u + 5u * (g.pos0 >> 1);
-        g.w = ld64(c);
-        g.w2 = ld16(c + 8);
+        const uint32_t c = prev + 10u + 5u * (g.pos0 >> 1);
+        g.w = src.u64(c);
+        g.w2 = src.u16(c + 8u);
       }
     }
   };
@@ -901,7 +1010,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
       for (uint32_t j = 0; j < G; ++j) {
         if (!((rs >> j) & 1u)) continue;
         if (FILTERED) {
-          if (((i + j) >> 6) < kRawBitWords) atomicOr(&L.rawbits[(i + j) >> 6], 1ull << ((i + j) & 63u));
+          if (((i + j) >> 6) < raw_words) atomicOr(&Lraw[(i + j) >> 6], 1ull << ((i + j) & 63u));
         } else if (i + j < n_out) {
           report_sync(i + j);
         }
@@ -923,16 +1032,16 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
   const uint32_t g_lo = UD ? chunk0 / G : 0u;
   const uint32_t g_hi = UD ? min(n_groups, (chunk0 + kChunk) / G) : n_groups;
   uint32_t t0 = g_lo + tid;
-  for (; t0 + (U - 1u) * kDecBlock < g_hi; t0 += U * kDecBlock) {  // full trips: no conditions
+  for (; t0 + (U - 1u) * NT < g_hi; t0 += U * NT) {  // full trips: no conditions
     GroupIn gi[U];
 #pragma unroll
-    for (uint32_t u = 0; u < U; ++u) locate(t0 + u * kDecBlock, gi[u]);
+    for (uint32_t u = 0; u < U; ++u) locate(t0 + u * NT, gi[u]);
 #pragma unroll
     for (uint32_t u = 0; u < U; ++u) fetch(gi[u]);
 #pragma unroll
-    for (uint32_t u = 0; u < U; ++u) emit(t0 + u * kDecBlock, gi[u]);
+    for (uint32_t u = 0; u < U; ++u) emit(t0 + u * NT, gi[u]);
   }
-  for (; t0 < g_hi; t0 += kDecBlock) {
+  for (; t0 < g_hi; t0 += NT) {
     GroupIn g1;
     locate(t0, g1);
     fetch(g1);
@@ -979,7 +1088,7 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     };
     const uint32_t N = min(kChunk, carry_nodes - chunk0);
     const bool last_chunk = chunk0 + N == carry_nodes;
-    const uint32_t seg = (N + kDecBlock - 1u) / kDecBlock;
+    const uint32_t seg = (N + NT - 1u) / NT;
     const uint32_t i_lo = min(tid * seg, N), i_hi = min(i_lo + seg, N);
     // node i has state st: patch dist_mm_q2 if smoothed; `redo`: a guessed state may have been
     // written before (scale-0 nodes only: the others always have state 4), write what is true
@@ -1108,10 +1217,9 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     } else {  // last node is not scale 0: _last_dist_q2 = its own distance (:1020)
       const uint32_t i = carry_nodes - 1u;
       const uint32_t e = i / NPF, pos = i - e * NPF;
-      const uint8_t *prev = frame_ptr(L.emit_frame[e] - 1u);
-      const uint8_t *c = prev + 10u + 5u * (pos >> 1);
-      const uint32_t q4 = ld8(c + 4);
-      const uint32_t qds = ld16(c + 2u * (pos & 1u)) | (((pos & 1u) ? (q4 >> 4) : (q4 & 0xFu)) << 16);
+      const uint32_t c = frame_at(Lemit[e] - 1u) + 10u + 5u * (pos >> 1);
+      const uint32_t q4 = src.u8(c + 4u);
+      const uint32_t qds = src.u16(c + 2u * (pos & 1u)) | (((pos & 1u) ? (q4 >> 4) : (q4 & 0xFu)) << 16);
       const uint32_t scale = qds & 3u;
       last_dist_out = scale == 1u ? (int)((qds & 0x1FFCu) * 3u + (2046u << 2))
                       : scale == 2u ? (int)((qds & 0x3FFCu) * 4u + (8187u << 2))
@@ -1150,12 +1258,15 @@ __global__ __launch_bounds__(kDecBlock) void k_decode(
     uint32_t st = L.misc[0];
     if (!FUSE && carry_nodes > node_stride) st |= RPLGPU_SCAN_OUT_TRUNCATED;
     if (reset_at && carry_reset > reset_stride) st |= RPLGPU_STREAM_RESETS_TRUNCATED;
-    if (FILTERED && carry_nodes > kRawBitWords * 64u) st |= RPLGPU_STREAM_FRAMES_TRUNCATED;
+    if (FILTERED && carry_nodes > raw_words * 64u) st |= RPLGPU_STREAM_FRAMES_TRUNCATED;
     if (n_nodes) n_nodes[b] = bad_framing ? 0u : n_out;
     if (n_reset) n_reset[b] = bad_framing ? 0u : min(carry_reset, reset_at ? reset_stride : carry_reset);
 #ifdef RPL_DEC_DBG
     if (reset_at && reset_stride >= 8)
+    {
       for (int d = 0; d < 5; ++d) reset_at[(size_t)b * reset_stride + 3 + d] = (uint32_t)(dbg_t[d + 1] - dbg_t[d]);
+      reset_at[(size_t)b * reset_stride + 2] = (uint32_t)(dbg_t[0] - dbg_start);
+    }
 #endif
     if (n_errors) n_errors[b] = L.misc[5];
     if (n_sync) n_sync[b] = bad_framing ? 0u : min(L.misc[6], sync_stride);
@@ -1505,6 +1616,74 @@ __global__ __launch_bounds__(kDecBlock) void k_scans_to_batch(
 }
 
 // ---- launchers ------------------------------------------------------------------------------
+// The LDS-staged instances (back-to-back capsule streams, nodes out): 512-thread workgroups, two
+// per CU — for calls whose streams fit half the CU's LDS together with their tables (max_frames up to
+// decode_staged_frames(ans): 830 DenseBoost frames, 876 express, 557 ultra, 339 ultra-dense).  *done stays false
+// otherwise and the plain kernel takes the call.  Measured and not instantiated
+// (profiles/r04/decode_staged_r04.txt): 1024-thread workgroups (one per CU), staging in windows
+// for longer streams, and the fused decode->scans kernel staged — all slower than the plain kernel.
+constexpr uint32_t kLdsPerCu = 160u * 1024u, kLdsGranule = 1280u;
+template <int ANS>
+static bool dec_stage_fits(uint32_t mf) {  // two workgroups of the staged instance on a CU?
+  const uint32_t need = (uint32_t)sizeof(DecodeLds<ANS, true>) + dec_stage_layout(ANS, mf).total;
+  return 2u * ((need + kLdsGranule - 1u) / kLdsGranule * kLdsGranule) <= kLdsPerCu;
+}
+template <int ANS>
+static uint32_t dec_staged_frames() {  // the largest max_frames the staged instance takes
+  uint32_t lo = 0, hi = DecCfg<ANS>::kMaxFrames;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1u) >> 1;
+    if (dec_stage_fits<ANS>(mid)) lo = mid; else hi = mid - 1u;
+  }
+  return lo;
+}
+uint32_t decode_staged_frames(int ans) {
+  switch (ans) {
+    case RPLGPU_ANS_CAPSULED: return dec_staged_frames<RPLGPU_ANS_CAPSULED>();
+    case RPLGPU_ANS_CAPSULED_ULTRA: return dec_staged_frames<RPLGPU_ANS_CAPSULED_ULTRA>();
+    case RPLGPU_ANS_DENSE_CAPSULED: return dec_staged_frames<RPLGPU_ANS_DENSE_CAPSULED>();
+    case RPLGPU_ANS_ULTRA_DENSE_CAPSULED: return dec_staged_frames<RPLGPU_ANS_ULTRA_DENSE_CAPSULED>();
+    default: return 0u;
+  }
+}
+static hipError_t launch_decode_staged(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
+                                       const uint32_t *n_frames, uint32_t max_frames, uint32_t B,
+                                       uint32_t sample_duration_us, const int32_t *state_in,
+                                       int32_t *state_out, uint2 *nodes, uint32_t node_stride,
+                                       uint32_t *n_nodes, uint32_t *reset_at, uint32_t reset_stride,
+                                       uint32_t *n_reset, uint32_t *n_errors, uint32_t *status,
+                                       uint32_t *sync_at, uint32_t sync_stride, uint32_t *n_sync,
+                                       const DecFuse &fz, bool *done) {
+  *done = false;
+  if (max_frames == 0u) return hipSuccess;
+  auto go = [&](auto kfn, uint32_t nt, bool fits, uint32_t mf_cap) -> hipError_t {
+    if (!fits) return hipSuccess;
+    const DecStageLayout lay = dec_stage_layout(ans, max_frames < mf_cap ? max_frames : mf_cap);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kfn, dim3(B), dim3(nt), lay.total, s, bytes, stream_stride,
+                       (const uint32_t *)nullptr, (const uint8_t *)nullptr, n_frames, max_frames,
+                       sample_duration_us, state_in, state_out, nodes, node_stride, n_nodes, reset_at,
+                       reset_stride, n_reset, n_errors, status, sync_at, sync_stride, n_sync, fz);
+    *done = true;
+    return hipGetLastError();
+  };
+#define RPL_STAGED(A)                                                                           \
+  case A:                                                                                       \
+    return go(k_decode<A, false, false, true, 512>, 512u,                                       \
+              dec_stage_fits<A>(max_frames < DecCfg<A>::kMaxFrames ? max_frames : DecCfg<A>::kMaxFrames), \
+              DecCfg<A>::kMaxFrames);
+  switch (ans) {
+    RPL_STAGED(RPLGPU_ANS_CAPSULED)
+    RPL_STAGED(RPLGPU_ANS_CAPSULED_ULTRA)
+    RPL_STAGED(RPLGPU_ANS_DENSE_CAPSULED)
+    RPL_STAGED(RPLGPU_ANS_ULTRA_DENSE_CAPSULED)
+    default: return hipSuccess;
+  }
+#undef RPL_STAGED
+}
+
 hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
                          const uint32_t *frame_off, const uint8_t *gap, const uint32_t *n_frames,
                          uint32_t max_frames, uint32_t B, uint32_t sample_duration_us,
@@ -1512,7 +1691,7 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
                          uint32_t node_stride, uint32_t *n_nodes, uint32_t *reset_at,
                          uint32_t reset_stride, uint32_t *n_reset, uint32_t *n_errors,
                          uint32_t *status, uint32_t *sync_at, uint32_t sync_stride,
-                         uint32_t *n_sync, const uint32_t *only) {
+                         uint32_t *n_sync, const uint32_t *only, bool staged_ok) {
   if (B == 0) return hipSuccess;
   DecFuse fz{};
   fz.only = only;
@@ -1526,6 +1705,13 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
     if (frame_off) RPL_LAUNCH_DEC3(A, true, false); \
     else RPL_LAUNCH_DEC3(A, false, false);         \
   } while (0)
+  if (!frame_off && staged_ok) {
+    bool done = false;
+    const hipError_t e = launch_decode_staged(s, ans, bytes, stream_stride, n_frames, max_frames, B,
+        sample_duration_us, state_in, state_out, (uint2 *)nodes, node_stride, n_nodes, reset_at,
+        reset_stride, n_reset, n_errors, status, sync_at, sync_stride, n_sync, fz, &done);
+    if (done) return e;
+  }
   switch (ans) {
     case RPLGPU_ANS_MEASUREMENT: RPL_LAUNCH_DEC(RPLGPU_ANS_MEASUREMENT); break;
     case RPLGPU_ANS_CAPSULED: RPL_LAUNCH_DEC(RPLGPU_ANS_CAPSULED); break;

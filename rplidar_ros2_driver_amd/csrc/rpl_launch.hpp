@@ -119,7 +119,9 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
                          uint32_t node_stride, uint32_t *n_nodes, uint32_t *reset_at,
                          uint32_t reset_stride, uint32_t *n_reset, uint32_t *n_errors,
                          uint32_t *status, uint32_t *sync_at = nullptr, uint32_t sync_stride = 0,
-                         uint32_t *n_sync = nullptr, const uint32_t *only = nullptr);
+                         uint32_t *n_sync = nullptr, const uint32_t *only = nullptr,
+                         // back-to-back capsule streams that fit: the LDS-staged instance (rpl_decode.hip)
+                         bool staged_ok = true);
 bool decode_fusable(int ans);
 hipError_t launch_decode_fused(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
                                const uint32_t *frame_off, const uint8_t *gap,
@@ -153,6 +155,7 @@ hipError_t launch_scans_to_batch(hipStream_t s, const void *seg_nodes, uint32_t 
                                  void *batch, uint32_t n_stride, uint32_t max_scans,
                                  uint32_t *n_per_scan);
 uint32_t decode_max_frames(int ans);
+uint32_t decode_staged_frames(int ans);  // largest max_frames of a back-to-back call the LDS-staged decoder takes
 
 // serialised-message assembly (rpl_msg.hip)
 hipError_t launch_msg_laserscan(hipStream_t s, const float *ranges, const float *intens,

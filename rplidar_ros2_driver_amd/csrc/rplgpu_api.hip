@@ -72,6 +72,7 @@ struct rplgpu_ctx {
   uint64_t region_budget = 2560ull << 20;  // RPLGPU_REGION_MB: bytes the region store may take
   int32_t scan_major = 0;             // RPLGPU_RUNS_SCAN_MAJOR (developer aid)
   int32_t force_split = -1;           // RPLGPU_VOXEL_SPLIT: -1 follow the statistics, 0 / 1 forced
+  bool dec_stage = true;              // RPLGPU_DEC_STAGE=0: the plain decoder only (tests / A-B runs)
   int32_t pipe = 0;                   // RPLGPU_VOXEL_PIPE: n > 0: k_voxel_cells next to k_voxel_runs (n producer workgroups per CU); 0: one after the other
   uint32_t *d_pipe_ctr = nullptr;     // task / item counters + per-item ready counts (2 + stage items words)
   uint32_t pipe_items = 0;
@@ -605,6 +606,7 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   if (const char *e = std::getenv("RPLGPU_REGION_MB")) c->region_budget = (uint64_t)std::max(1, std::atoi(e)) << 20;
   if (const char *e = std::getenv("RPLGPU_RUNS_SCAN_MAJOR")) c->scan_major = std::atoi(e) != 0;
   if (const char *e = std::getenv("RPLGPU_VOXEL_PIPE")) c->pipe = std::max(0, std::atoi(e));
+  if (const char *e = std::getenv("RPLGPU_DEC_STAGE")) c->dec_stage = std::atoi(e) != 0;
   if (const char *e = std::getenv("RPLGPU_VOXEL_SPLIT")) c->force_split = std::atoi(e) != 0;  // developer aid
   std::memset(c->h_pin + c->flag_off, 0, kTail);
   if (hipMemset(c->d_small, 0, 128) != hipSuccess) {  // incl. the voxel kernel's scan queue
@@ -1098,6 +1100,9 @@ size_t rplgpu_nodes_per_frame(uint8_t ans_type) {
 uint32_t rplgpu_decode_max_frames(uint8_t ans_type) {
   return rplgpu_frame_size(ans_type) ? rpl::decode_max_frames(ans_type) : 0u;
 }
+uint32_t rplgpu_decode_staged_frames(uint8_t ans_type) {
+  return rplgpu_frame_size(ans_type) ? rpl::decode_staged_frames(ans_type) : 0u;
+}
 
 // Framing = what the first two switch cases of every onData loop decide
 // (handler_capsules.cpp:107-135 and siblings, handler_hqnode.cpp:99-113,
@@ -1167,7 +1172,8 @@ int32_t rplgpu_decode_batch_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
   RPL_HIP(h, rpl::launch_decode(h->stream, ans_type, d_bytes, stream_stride, d_frame_off, d_gap,
                                 d_n_frames, max_frames, B, sample_duration_us, d_state_in,
                                 d_state_out, d_nodes, node_stride, d_n_nodes, d_reset_at,
-                                reset_stride, d_n_reset, d_n_errors, d_status));
+                                reset_stride, d_n_reset, d_n_errors, d_status, nullptr, 0, nullptr,
+                                nullptr, h->dec_stage));
   return RPLGPU_OK;
 }
 
@@ -1249,7 +1255,7 @@ static int32_t decode_scans_impl(rplgpu_handle_t h, uint8_t ans_type, uint32_t s
   RPL_HIP(h, rpl::launch_decode(h->stream, ans_type, d_bytes, stream_stride, d_frame_off, d_gap,
                                 d_n_frames, max_frames, B, sample_duration_us, d_state_in,
                                 d_state_out, t_nodes, node_stride, t_nn, t_rst, reset_stride, t_nr,
-                                d_n_errors, d_status, t_sync, sync_stride, t_ns, only));
+                                d_n_errors, d_status, t_sync, sync_stride, t_ns, only, h->dec_stage));
   RPL_HIP(h, rpl::launch_assemble(h->stream, t_nodes, node_stride, t_nn, t_sync, sync_stride, t_ns,
                                   t_rst, reset_stride, t_nr, B, max_count, d_batch, n_stride,
                                   scan_cap, d_n_per_scan, d_n_scans, d_status, only, d_carry_in,

@@ -678,3 +678,105 @@ def test_decode_full_size_properties(gpu):
             ln = int(d_off[b, 1])
             assert ln == pos[1] - pos[0]
             assert bool((d_seg.view(B, node_stride, 8)[b, :ln] == raw[b, pos[0]: pos[1]]).all())
+
+
+@pytest.fixture(scope="module")
+def gpu_plain_decoder():
+    """A handle whose decode calls never take the LDS-staged instance (RPLGPU_DEC_STAGE=0 is read by
+    rplgpu_create): the plain kernel on the same inputs is the second reference of the test below."""
+    import os
+
+    from rplidar_ros2_driver_amd import RplGpu
+    from tests.conftest import _shared_stream
+    torch = _torch()
+    saved = os.environ.get("RPLGPU_DEC_STAGE")
+    os.environ["RPLGPU_DEC_STAGE"] = "0"
+    try:
+        h = RplGpu(device=0, max_samples_per_scan=32768, max_batch=64)
+    finally:
+        if saved is None:
+            os.environ.pop("RPLGPU_DEC_STAGE", None)
+        else:
+            os.environ["RPLGPU_DEC_STAGE"] = saved
+    h.set_stream(_shared_stream().cuda_stream)
+    yield h
+    torch.cuda.synchronize()
+    h.close()
+
+
+@pytest.mark.parametrize("ans", [0x82, 0x84, 0x85, 0x86])
+@pytest.mark.parametrize("where", ["small", "limit", "beyond"])
+def test_staged_decoder_matches_plain_and_oracle(gpu, gpu_plain_decoder, oracle, ans, where):
+    """Back-to-back capsule streams up to rplgpu_decode_staged_frames frames are decoded out of an
+    LDS copy of the stream (k_decode<..., STG>).  Same nodes, counts, reset positions, error
+    counts, status and carried state as the plain kernel and as the oracle: streams of every
+    length from 0 frames to the limit, payload bytes flipped (checksum failures, broken capsule
+    pairs), a broken sync pattern, an odd stream stride (frames at any byte alignment), carried-in
+    state, and the "frame 0 is the previous call's last frame" flag."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    lib = abi.load_library()
+    S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
+    lim = int(lib.rplgpu_decode_staged_frames(ans))
+    assert 0 < lim <= int(lib.rplgpu_decode_max_frames(ans))
+    max_frames = {"small": 97, "limit": lim, "beyond": min(lim + 1, int(lib.rplgpu_decode_max_frames(ans)))}[where]
+    rng = np.random.default_rng(ans * 131 + max_frames)
+    B = 18
+    nfs = rng.integers(3, max_frames + 1, B).astype(np.int32)
+    nfs[:5] = (0, 1, 2, max_frames, max_frames)
+    stride = max_frames * S + int(rng.integers(0, 3)) * 2 + 1  # odd: streams start at any alignment
+    buf = np.zeros((B, stride), np.uint8)
+    streams = []
+    for b in range(B):
+        s = cp.make_stream(ans, int(nfs[b]), 900 + 17 * b + max_frames, payload="ring" if b % 3 else "random",
+                           frames_per_rev=float(rng.uniform(7.0, 60.0))).copy()
+        if b % 4 == 1 and nfs[b] > 4:  # flipped payload bytes: checksum failures here and there
+            for k in rng.integers(1, nfs[b], 1 + nfs[b] // 40):
+                s[int(k) * S + int(rng.integers(4, S))] ^= 0x5A
+        streams.append(s)
+        buf[b, : len(s)] = s
+    if nfs[7] > 6:
+        buf[7, 5 * S] ^= 0xF0  # broken sync pattern: RPLGPU_STREAM_UNFRAMED, nothing published
+    state_in = np.zeros((B, 4), np.int32)
+    state_in[:, 0] = rng.integers(0, 2, B)
+    state_in[:, 1] = rng.integers(0, 4000, B) * 4
+    state_in[9:12, 2] = 1  # frame 0 only as the predecessor of frame 1
+    d_bytes = torch.from_numpy(buf).to(dev)
+    d_nf = torch.from_numpy(nfs).to(dev)
+    d_sin = torch.from_numpy(state_in).to(dev)
+    node_stride = max_frames * npf
+
+    def run(h):
+        o = {k: torch.full(shape, 0x55, dtype=dt, device=dev) for k, shape, dt in (
+            ("nodes", (B, node_stride * 8), torch.uint8), ("nn", (B,), torch.int32),
+            ("rst", (B, 32), torch.int32), ("nr", (B,), torch.int32), ("ne", (B,), torch.int32),
+            ("st", (B,), torch.int32), ("sout", (B, 4), torch.int32))}
+        o["nodes"].zero_()
+        h.decode_batch_dev(ans, 125, d_bytes.data_ptr(), stride, 0, 0, d_nf.data_ptr(), max_frames, B,
+                           d_sin.data_ptr(), o["sout"].data_ptr(), o["nodes"].data_ptr(), node_stride,
+                           o["nn"].data_ptr(), o["rst"].data_ptr(), 32, o["nr"].data_ptr(),
+                           o["ne"].data_ptr(), o["st"].data_ptr())
+        h.synchronize()
+        return {k: v.cpu().numpy() for k, v in o.items()}
+
+    got, ref = run(gpu), run(gpu_plain_decoder)
+    for b in range(B):
+        n = int(ref["nn"][b])
+        assert int(got["nn"][b]) == n and got["st"][b] == ref["st"][b], (hex(ans), where, b)
+        assert got["nodes"][b, : n * 8].tobytes() == ref["nodes"][b, : n * 8].tobytes(), (hex(ans), where, b)
+        assert got["nr"][b] == ref["nr"][b] and got["ne"][b] == ref["ne"][b], (hex(ans), where, b)
+        k = min(int(ref["nr"][b]), 32)
+        assert list(got["rst"][b, :k]) == list(ref["rst"][b, :k]), (hex(ans), where, b)
+        assert list(got["sout"][b]) == list(ref["sout"][b]), (hex(ans), where, b)
+        if b == 7 and nfs[7] > 6:
+            assert got["st"][b] & abi_status("UNFRAMED") and n == 0
+            continue
+        if state_in[b, 2]:
+            continue  # (the cut-recording flag: plain kernel is the reference, oracle-checked elsewhere)
+        want, w_rst, w_err, w_st = oracle.unpack(ans, buf[b, : int(nfs[b]) * S], 125,
+                                                 state=(int(state_in[b, 0]), int(state_in[b, 1])))
+        assert n == len(want) and got["st"][b] == 0, (hex(ans), where, b)
+        nodes = got["nodes"][b].view(NODE_DTYPE)[:n]
+        assert nodes.tobytes() == want.tobytes(), (hex(ans), where, b)
+        assert list(got["rst"][b, : got["nr"][b]]) == list(w_rst) and int(got["ne"][b]) == w_err
+        assert tuple(int(v) for v in got["sout"][b, :2]) == w_st

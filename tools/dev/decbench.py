@@ -34,9 +34,13 @@ for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334)
         a.record(st); run(); b.record(st); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     nodes = int(d_nn.sum().item())
     t = min(ts)
+    if os.environ.get('DEC_SUM'):
+        w = d_nodes.view(torch.int32).to(torch.int64)
+        k = (torch.arange(w.shape[1], device=dev) % 1021 + 1)
+        print("   checksum", int(w.sum().item()), int((w * k).sum().item()), "resets", int(d_nr.sum().item()))
     if os.environ.get('DEC_DBG'):
         ph = d_rst.cpu().numpy()[:, 3:8].astype(np.float64)
-        print("   phase cycles P1 P2 P3 P4 P5 (mean):", ph.mean(0).round(0), "sum", ph.sum(1).mean().round(0))
+        print("   phase cycles P1 P2 P3 P4 P5 (mean):", ph.mean(0).round(0), "sum", ph.sum(1).mean().round(0), "head (staging)", d_rst.cpu().numpy()[:, 2].astype(np.float64).mean().round(0))
         print("   P1 p10/p50/p90:", np.percentile(ph[:, 0], [10, 50, 90]).round(0), " first 1792 WGs mean", ph[:1792, 0].mean().round(0), "rest", ph[1792:, 0].mean().round(0),
               " P3 p10/p50/p90:", np.percentile(ph[:, 2], [10, 50, 90]).round(0))
     print(f"ans {ans:#x}: {nodes/1e6:.1f} Mnodes in {t:.3f} ms -> {nodes/t/1e6:.1f} Gnodes/s, "
@@ -54,7 +58,14 @@ for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334)
         for _ in range(5):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(st); fused(); b.record(st); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
-        print(f"  segment-fused decode_scans_dev: {min(ts):.3f} ms, scans {int(d_ns2.sum().item())}, nodes in scans {int(d_len.sum().item())}, status {int(d_st2.max().item())}")
+        extra = ""
+        if os.environ.get('DEC_SUM'):
+            d_batch.zero_(); fused(); torch.cuda.synchronize()
+            w = d_batch.view(torch.int32).to(torch.int64)
+            k = (torch.arange(w.shape[1], device=dev) % 1021 + 1)
+            extra = f", checksum {int(w.sum().item())} {int((w * k).sum().item())}"
+            del w
+        print(f"  segment-fused decode_scans_dev: {min(ts):.3f} ms, scans {int(d_ns2.sum().item())}, nodes in scans {int(d_len.sum().item())}, status {int(d_st2.max().item())}" + extra)
         del d_batch
     if ans == 0x85:
         d_seg = torch.empty_like(d_nodes)
