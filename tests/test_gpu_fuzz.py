@@ -157,6 +157,7 @@ def test_fuzz_decode_against_oracle(gpu, oracle, seed):
             assert len(nodes) == len(w_nodes), ctx
             assert nodes.tobytes() == w_nodes.tobytes(), ctx
             assert list(rst) == list(w_rst) and err == w_err and st == w_st, ctx
+            _fuzz_decode_unframed(gpu, oracle, ans, frames, dur, state, rng, ctx)
             _fuzz_decode_scans(gpu, oracle, ans, data, dur, state, w_nodes, w_rst, w_err, w_st, rng, ctx)
             _fuzz_decode_scans_carry(gpu, oracle, ans, data, dur, state, w_nodes, w_rst, w_err, w_st, rng, ctx)
             # the same recording in two pieces, state handed over (cut on a frame boundary of
@@ -168,6 +169,44 @@ def test_fuzz_decode_against_oracle(gpu, oracle, seed):
                 w1 = oracle.unpack(ans, data[:cut], dur, state=state)
                 assert n1.tobytes() == w1[0].tobytes() and list(r1) == list(w1[1]), ctx
                 assert e1 == w1[2] and s1 == w1[3], ctx
+
+
+def _fuzz_decode_unframed(gpu, oracle, ans, frames, dur, state, rng, ctx):
+    """The frames back to back, no offsets (rplgpu_decode_batch_dev with d_frame_off = NULL: the
+    LDS-staged decoder for the capsule types), payload and header bytes flipped but the sync
+    nibbles left alone so that the byte machine of the oracle finds the same frames."""
+    import torch
+    from rplidar_ros2_driver_amd import capsules as cp
+    if ans not in (0x82, 0x84, 0x85, 0x86):
+        return
+    S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
+    f = frames.copy().reshape(-1, S)
+    nf = len(f)
+    for _ in range(int(rng.integers(0, 1 + nf // 8))):
+        k, at = int(rng.integers(0, nf)), int(rng.integers(0, S))
+        f[k, at] ^= np.uint8(int(rng.integers(1, 256)) & (0x0F if at < 2 else 0xFF))
+    data = f.reshape(-1)
+    want, w_rst, w_err, w_st = oracle.unpack(ans, data, dur, state=state)
+    dev = torch.device("cuda:0")
+    pad = int(rng.integers(0, 4))  # the stream starts at any byte alignment
+    d_bytes = torch.from_numpy(np.concatenate([np.zeros(pad, np.uint8), data])).to(dev)
+    d_nf = torch.tensor([nf], dtype=torch.int32, device=dev)
+    d_sin = torch.tensor([[state[0], state[1], 0, 0]], dtype=torch.int32, device=dev)
+    node_stride = nf * npf
+    d_nodes = torch.zeros(node_stride * 8, dtype=torch.uint8, device=dev)
+    d_i = torch.zeros(5, dtype=torch.int32, device=dev)  # n_nodes, n_reset, n_errors, status
+    d_rst = torch.zeros(nf + 2, dtype=torch.int32, device=dev)
+    d_sout = torch.zeros(4, dtype=torch.int32, device=dev)
+    gpu.decode_batch_dev(ans, dur, d_bytes.data_ptr() + pad, len(data), 0, 0, d_nf.data_ptr(), nf, 1,
+                         d_sin.data_ptr(), d_sout.data_ptr(), d_nodes.data_ptr(), node_stride,
+                         d_i.data_ptr(), d_rst.data_ptr(), nf + 2, d_i.data_ptr() + 4,
+                         d_i.data_ptr() + 8, d_i.data_ptr() + 12)
+    gpu.synchronize()
+    n, nr, ne, st = (int(v) for v in d_i.cpu().numpy()[:4])
+    assert st == 0 and n == len(want), ctx
+    assert d_nodes.cpu().numpy()[: n * 8].tobytes() == want.tobytes(), ctx
+    assert list(d_rst.cpu().numpy()[:nr]) == list(w_rst) and ne == w_err, ctx
+    assert tuple(int(v) for v in d_sout.cpu().numpy()[:2]) == w_st, ctx
 
 
 def _fuzz_decode_scans(gpu, oracle, ans, data, dur, state, w_nodes, w_rst, w_err, w_st, rng, ctx):
