@@ -18,8 +18,8 @@ def short(name):
 for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
     print("== kernel stats (rocprofv3 --kernel-trace --stats):", f.split(out)[-1])
     for row in csv.DictReader(open(f)):
-        print("  %-28s calls=%-4s avg_us=%10.1f min_us=%10.1f max_us=%10.1f pct=%s" % (
-            short(row["Name"])[:28], row["Calls"], float(row["AverageNs"]) / 1e3,
+        print("  %-44s calls=%-4s avg_us=%10.1f min_us=%10.1f max_us=%10.1f pct=%s" % (
+            short(row["Name"])[:44], row["Calls"], float(row["AverageNs"]) / 1e3,
             float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3, row["Percentage"]))
 
 agg = defaultdict(lambda: defaultdict(list))
