@@ -120,6 +120,14 @@ def test_host_framer_matches_oracle_framing(oracle):
     lib = abi.load_library()
     assert lib.rplgpu_frame_size(0x42) == 0 and lib.rplgpu_nodes_per_frame(0x85) == 40
     assert lib.rplgpu_decode_max_frames(0x86) == 512 and lib.rplgpu_decode_max_frames(0x85) == 2048
+    # the LDS-staged decoder's reach (two workgroups of stream + tables in a CU's 160 KB): capsule
+    # types only, never more than a call may hold, and a DenseBoost scan of 32 000 nodes (801 frames) fits
+    staged = {a: lib.rplgpu_decode_staged_frames(a) for a in (0x81, 0x82, 0x83, 0x84, 0x85, 0x86, 0x42)}
+    assert staged[0x81] == staged[0x83] == staged[0x42] == 0
+    for a in (0x82, 0x84, 0x85, 0x86):
+        assert 0 < staged[a] <= lib.rplgpu_decode_max_frames(a)
+        assert 160 * 1024 // 2 // 2 < staged[a] * lib.rplgpu_frame_size(a) < 160 * 1024 // 2
+    assert staged[0x85] >= 801
 
 
 def test_product_never_touches_the_oracle():
