@@ -27,6 +27,20 @@ for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334)
     def run():
         gpu.decode_batch_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0,
                              d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8, d_nr.data_ptr())
+    PIECES = int(os.environ.get('DEC_PIECES', '0'))
+    if PIECES > 1:
+        # timing experiment: the call as PIECES calls of nf / PIECES frames (+ the overlap frame), each short
+        # enough for the staged decoder; outputs of the later pieces go to the same buffer (contents unused)
+        W = (nf + PIECES - 1) // PIECES
+        d_nfp = [torch.full((B,), min(W + (1 if p else 0), nf - p * W + (1 if p else 0)), dtype=torch.int32, device=dev) for p in range(PIECES)]
+        d_state = torch.zeros(B, 4, dtype=torch.int32, device=dev)
+        d_state2 = torch.zeros(B, 4, dtype=torch.int32, device=dev); d_state2[:, 2] = 1
+        def run():
+            for p in range(PIECES):
+                first = p * W - (1 if p else 0)
+                gpu.decode_batch_dev(ans, 125, buf.data_ptr() + first * S, nf * S, 0, 0, d_nfp[p].data_ptr(), W + 1, B,
+                                     d_state2.data_ptr() if p else d_state.data_ptr(), 0,
+                                     d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8, d_nr.data_ptr())
     run(); torch.cuda.synchronize()
     ts = []
     for _ in range(5):
