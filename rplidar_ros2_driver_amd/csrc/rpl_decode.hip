@@ -623,16 +623,33 @@ __global__ __launch_bounds__(NT) void k_decode(
                       : ANS == RPLGPU_ANS_DENSE_CAPSULED ? (diff_q8 << 8) / 40
                                                          : (diff_q8 << 8) / 64;
       const int lim = FILTERED ? inc * 2 : inc;
-      for (uint32_t pos = 0; pos < NPF; ++pos) {
-        const int ang = (prev_q8 << 8) + (int)pos * inc;
-        if (((ang + inc) % (360 << 16)) < lim) {
-          const uint32_t i = e * NPF + pos;
-          if (FILTERED) {
-            atomicOr(&Lraw[i >> 6], 1ull << (i & 63u));
-          } else {
-            const uint32_t at = atomicAdd(&L.misc[6], 1u);
-            if (at < kSyn) L.syn[at] = i;
-          }
+      auto mark = [&](uint32_t pos) {
+        const uint32_t i = e * NPF + pos;
+        if (FILTERED) {
+          atomicOr(&Lraw[i >> 6], 1ull << (i & 63u));
+        } else {
+          const uint32_t at = atomicAdd(&L.misc[6], 1u);
+          if (at < kSyn) L.syn[at] = i;
+        }
+      };
+      // v_j = A + j * inc, j = pos + 1 = 1 .. NPF, is tested as (v_j mod 360 deg) < lim.  With a positive
+      // step, a start angle below 360 deg and no second wrap inside the capsule (any stream a sensor
+      // produces) v_j rises through [0, 720 deg) and the test holds where v_j first reaches 360 deg
+      // (j0; dense types: j0 and j0 + 1) and, dense types only, at j = 1 when A < inc — one division
+      // per capsule instead of NPF remainders.  Anything else (corrupted-but-checksummed angles:
+      // negative steps, angles above 360 deg) walks the positions as the reference does.
+      constexpr int kTurn = 360 << 16;
+      const int A = prev_q8 << 8;
+      if (inc > 0 && A < kTurn && A + (int)NPF * inc < 2 * kTurn) {
+        if (FILTERED && A < inc && A + inc < kTurn) mark(0u);
+        const uint32_t t = (uint32_t)(kTurn - A);
+        const uint32_t j0 = (t + (uint32_t)inc - 1u) / (uint32_t)inc;  // (>= 1)
+        if (j0 <= NPF) mark(j0 - 1u);
+        if (FILTERED && j0 + 1u <= NPF) mark(j0);
+      } else {
+        for (uint32_t pos = 0; pos < NPF; ++pos) {
+          const int ang = A + (int)pos * inc;
+          if (((ang + inc) % kTurn) < lim) mark(pos);
         }
       }
     }
