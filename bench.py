@@ -324,14 +324,20 @@ def decode_stage(gpu, dev, stream, cpu_seconds):
     B = 4096
     out = {}
     sync = lambda: torch.cuda.synchronize(dev)
-    for name, ans, nf in (("dense", cp.ANS_DENSE_CAPSULED, 801), ("express", cp.ANS_CAPSULED, 1001),
-                          ("ultra", cp.ANS_CAPSULED_ULTRA, 334),
-                          ("ultra_dense", cp.ANS_ULTRA_DENSE_CAPSULED, 501), ("hq", cp.ANS_HQ, 334),
-                          ("normal", cp.ANS_MEASUREMENT, 4000)):
+    # ("ultra_dense": the generator's 2.5-5.5 m ring clamped to that format's scale 0, i.e. a CONSTANT
+    # 2046 mm — the one input on which the smoothing pass has to walk every segment twice;
+    # "ultra_dense_near": a 0.9-1.9 m ring, distances that vary the way a real target's do)
+    for name, ans, nf, payload in (("dense", cp.ANS_DENSE_CAPSULED, 801, "ring"),
+                                   ("express", cp.ANS_CAPSULED, 1001, "ring"),
+                                   ("ultra", cp.ANS_CAPSULED_ULTRA, 334, "ring"),
+                                   ("ultra_dense", cp.ANS_ULTRA_DENSE_CAPSULED, 501, "ring"),
+                                   ("ultra_dense_near", cp.ANS_ULTRA_DENSE_CAPSULED, 501, "ring_near"),
+                                   ("hq", cp.ANS_HQ, 334, "ring"),
+                                   ("normal", cp.ANS_MEASUREMENT, 4000, "ring")):
         S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
         uniq = 16  # distinct streams (host generation time); the batch repeats them
         # two revolutions per stream so that scan assembly has one complete scan to cut out
-        base = np.stack([cp.make_stream(ans, nf, 10 + s, payload="ring", frames_per_rev=nf / 2.0 + 0.3)
+        base = np.stack([cp.make_stream(ans, nf, 10 + s, payload=payload, frames_per_rev=nf / 2.0 + 0.3)
                          for s in range(uniq)])
         buf = torch.from_numpy(base).to(dev).repeat(B // uniq, 1).contiguous()
         d_nf = torch.full((B,), nf, dtype=torch.int32, device=dev)

@@ -55,7 +55,7 @@ struct DecCfg {
   // ultra-dense: nodes are decoded and smoothed in chunks of kUdChunk (the smoothing pass needs the
   // raw distances of a chunk in LDS: 16 KiB instead of 64 KiB for the whole stream, i.e. six
   // instead of two workgroups per CU)
-  static constexpr uint32_t kUdChunk = 8192u;
+  static constexpr uint32_t kUdChunk = 8192u;  // (1024 .. 6144 measured in round 4: equal or slower)
   static constexpr uint32_t kSmoothSlots = ANS == RPLGPU_ANS_ULTRA_DENSE_CAPSULED ? kUdChunk : 1u;
   static constexpr uint32_t kCrcWords = ANS == RPLGPU_ANS_HQ ? 1024u : 1u;
   // nodes one lane decodes in one go (all of ONE frame): per-frame arithmetic once per group,
@@ -269,7 +269,8 @@ struct DecodeLds {
   uint32_t frame[STG ? 1u : DecCfg<ANS>::kTableSlots];
   uint16_t emit_frame[STG ? 1u : DecCfg<ANS>::kTableSlots];  // compacted list of the frames that publish nodes
   unsigned long long rawbits[STG ? 1u : DecCfg<ANS>::kRawBitWords];  // dense types: raw sync bit per node
-  uint16_t smooth[DecCfg<ANS>::kSmoothSlots];  // ultra-dense: bit15 scale 0, bits 0..13 raw dist_q2
+  alignas(8) uint16_t smooth[DecCfg<ANS>::kSmoothSlots];  // ultra-dense: bit15 scale 0, bits 0..13 raw dist_q2
+  uint8_t fin[DecCfg<ANS>::kSmoothSlots];      // ultra-dense: the smoothing state the walks arrive at (0..8, 4: unsmoothed)
   uint32_t crc_table[DecCfg<ANS>::kCrcWords];  // HQ: slicing-by-4 tables
   uint32_t stage[DecCfg<ANS>::kStageWords];    // HQ: per wave, 64 frames x 16 words (+1 pad)
   int32_t corr[DecCfg<ANS>::kCorrSlots];       // ultra: angle correction (Q16 -> Q6 units) by k2
@@ -706,6 +707,7 @@ __global__ __launch_bounds__(NT) void k_decode(
 #ifdef RPL_DEC_DBG
   __syncthreads();
   dbg_t[2] = __builtin_amdgcn_s_memtime();
+  unsigned long long dbg_p3 = 0, dbg_p5 = 0, dbg_mark = dbg_t[2];
 #endif
   // FUSE: where node ii of the stream was stored (null: in no delivered scan) — the rule of the
   // store loop in emit(), for the few nodes the ultra-dense smoothing patches afterwards
@@ -1067,11 +1069,11 @@ __global__ __launch_bounds__(NT) void k_decode(
 
 #ifdef RPL_DEC_DBG
   __syncthreads();
-  dbg_t[3] = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef RPL_DEC_DBG
-  __syncthreads();
-  dbg_t[4] = __builtin_amdgcn_s_memtime();
+  {  // (ultra-dense: P3 / P5 alternate chunk by chunk; the clocks accumulate each)
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    dbg_p3 += now - dbg_mark;
+    dbg_mark = now;
+  }
 #endif
   // ---- P5 (ultra-dense): distance smoothing (:997-1003, :1020) -------------------------------
   // out_i = smooth(d_i, out_{i-1}) is a recurrence, but a smoothed value stays within +-4 of its
@@ -1107,19 +1109,13 @@ __global__ __launch_bounds__(NT) void k_decode(
     const bool last_chunk = chunk0 + N == carry_nodes;
     const uint32_t seg = (N + NT - 1u) / NT;
     const uint32_t i_lo = min(tid * seg, N), i_hi = min(i_lo + seg, N);
-    // node i has state st: patch dist_mm_q2 if smoothed; `redo`: a guessed state may have been
-    // written before (scale-0 nodes only: the others always have state 4), write what is true
-    auto patch = [&](uint32_t i, int st, bool redo = false) {
-      if ((st != 4 || (redo && is_s0(i))) && chunk0 + i < n_out) {  // (bits 16.. of the packed node)
-        const uint32_t d = (uint32_t)(rawd(i) + st - 4);
-        uint2 *at = FUSE ? fused_dst(chunk0 + i) : out + chunk0 + i;
-        if (at) {
-          uint2 v = *at;
-          v.x = (v.x & 0xFFFFu) | (d << 16);
-          v.y = (v.y & 0xFFFF0000u) | (d >> 16);
-          *at = v;
-        }
-      }
+    // node i has state st (a guess in pass A, overwritten by pass C where the guess was wrong): kept in
+    // LDS; the nodes themselves are corrected in one coalesced pass at the end of the chunk.  (Until
+    // round 4 every walking thread read-modify-wrote its own nodes as it went: a dependent global load
+    // per smoothed node, 64 cache lines per instruction — invisible on the constant-distance bench
+    // payload, which smooths nothing, and 3 x the kernel's time on distances that vary.)
+    auto patch = [&](uint32_t i, int st, bool = false) {
+      L.fin[i] = (uint8_t)st;
       if (i == N - 1u) {
         L.misc[7] = (uint32_t)(rawd(i) + st - 4);  // what this chunk leaves behind (st = 4 unless scale 0)
         if (last_chunk && is_s0(i)) L.misc[4] = (uint32_t)(rawd(i) + st - 4) | 0x80000000u;
@@ -1226,9 +1222,19 @@ __global__ __launch_bounds__(NT) void k_decode(
       }
     }
     __syncthreads();
+    // the smoothed nodes' dist_mm_q2 (bytes 2..5 of the packed node): lane = node, no load.  Only
+    // scale-0 nodes are smoothed and their distance stays below 2^14: bytes 4..5 are zero before
+    // and after, one 2-byte store of bytes 2..3 does it.
+    for (uint32_t i = tid; i < N; i += NT) {
+      const int st = (int)L.fin[i];
+      if (st != 4 && chunk0 + i < n_out) {
+        uint2 *at = FUSE ? fused_dst(chunk0 + i) : out + chunk0 + i;
+        if (at) reinterpret_cast<uint16_t *>(at)[1] = (uint16_t)(rawd(i) + st - 4);
+      }
+    }
     chunk_last = (int)L.misc[7];
+    __syncthreads();  // (the next chunk's P3 overwrites the raw distances and the states)
     if (!last_chunk) {
-      // (the next chunk's P3 overwrites the raw distances: every thread is past its walk here)
     } else if (L.misc[4] & 0x80000000u) {
       last_dist_out = (int)(L.misc[4] & 0x7FFFFFFFu);
     } else {  // last node is not scale 0: _last_dist_q2 = its own distance (:1020)
@@ -1244,7 +1250,20 @@ __global__ __launch_bounds__(NT) void k_decode(
     }
   }
 
+#ifdef RPL_DEC_DBG
+  __syncthreads();
+  {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    dbg_p5 += now - dbg_mark;
+    dbg_mark = now;
+  }
+#endif
   }  // chunks
+#ifdef RPL_DEC_DBG
+  dbg_t[3] = dbg_t[2] + dbg_p3;
+  dbg_t[4] = dbg_t[3];
+  dbg_t[5] = dbg_t[4] + dbg_p5;  // (slot "P4" = 0, slot "P5" = the smoothing passes; the sync filter goes uncounted)
+#endif
 
   // ---- P4 (dense / ultra-dense): the sync-bit filter, s_i = r_i & ~s_{i-1} -------------------
   if (FILTERED) {
@@ -1263,10 +1282,6 @@ __global__ __launch_bounds__(NT) void k_decode(
     if (carry_nodes) last_sync_out = (int)L.misc[3];
   }
 
-#ifdef RPL_DEC_DBG
-  __syncthreads();
-  dbg_t[5] = __builtin_amdgcn_s_memtime();
-#endif
   // ---- per-stream results ---------------------------------------------------------------------
   for (int d = 32; d > 0; d >>= 1) my_err += (uint32_t)__shfl_xor((int)my_err, d, 64);
   if (lane_id() == 0 && my_err) atomicAdd(&L.misc[5], my_err);

@@ -158,7 +158,7 @@ def test_decode_batch_dev_unframed_and_status(gpu, oracle):
     for ans in (0x82, 0x84, 0x85, 0x86, 0x83, 0x81):
         S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
         B, nf = 7, 90
-        streams = [cp.make_stream(ans, nf - 3 * b, 200 + b, payload="ring" if b % 2 else "random",
+        streams = [cp.make_stream(ans, nf - 3 * b, 200 + b, payload=("random", "ring", "ring_near")[b % 3],
                                   frames_per_rev=11.0 + b) for b in range(B)]
         streams[4] = streams[4].copy()
         streams[4][5 * S] ^= 0xF0 if ans != 0x81 else 0x01  # broken sync pattern in frame 5
@@ -335,7 +335,7 @@ def test_decode_scans_matches_oracle_chain(gpu, oracle, ans):
             if ans == 0x81:
                 fpr *= 40
             d = cp.make_stream(ans, nf - 7 * b, 500 + b, corrupt=framed and b % 3 == 1,
-                               payload="ring" if b % 2 else "random", frames_per_rev=fpr)
+                               payload=("random", "ring", "ring_near")[b % 3], frames_per_rev=fpr)
             if framed and b % 2 == 0:  # junk between frames: gaps clear the capsule latch
                 cut = (len(d) // S // 2) * S
                 d = np.concatenate([d[:cut], rng.integers(0, 256, 13, dtype=np.uint8), d[cut:]])
@@ -483,7 +483,7 @@ def test_decode_scans_carried_state_through_the_fused_path(gpu, oracle, ans):
     dev = torch.device("cuda:0")
     S = cp.FRAME_SIZE[ans]
     nf, B = 240, 5
-    streams = [cp.make_stream(ans, nf, 4100 + b, payload="ring" if b % 2 else "random",
+    streams = [cp.make_stream(ans, nf, 4100 + b, payload=("random", "ring", "ring_near")[b % 3],
                               frames_per_rev=(8.3, 21.0, 5.1, 40.0, 12.9)[b]) for b in range(B)]
     cut = (nf // 2) * S
     halves = [[d[:cut] for d in streams], [d[cut:] for d in streams]]
@@ -542,7 +542,7 @@ def test_long_recording_becomes_scans_across_calls(gpu, oracle, ans):
     rng = np.random.default_rng(ans)
     streams = []
     for b in range(B):
-        d = cp.make_stream(ans, nf, 5200 + 17 * b + ans, payload="ring" if b % 2 else "random",
+        d = cp.make_stream(ans, nf, 5200 + 17 * b + ans, payload=("random", "ring", "ring_near")[b % 3],
                            frames_per_rev=(3.3, 9.7, 25.0, 61.0, 130.0, 500.0)[b]).copy()
         if b in (1, 4):  # a few broken frames: checksum failures -> scan-reset requests mid-recording
             for f in rng.choice(nf - 2, 3, replace=False):
@@ -728,7 +728,7 @@ def test_staged_decoder_matches_plain_and_oracle(gpu, gpu_plain_decoder, oracle,
     buf = np.zeros((B, stride), np.uint8)
     streams = []
     for b in range(B):
-        s = cp.make_stream(ans, int(nfs[b]), 900 + 17 * b + max_frames, payload="ring" if b % 3 else "random",
+        s = cp.make_stream(ans, int(nfs[b]), 900 + 17 * b + max_frames, payload=("random", "ring", "ring_near")[b % 3],
                            frames_per_rev=float(rng.uniform(7.0, 60.0))).copy()
         if b % 4 == 1 and nfs[b] > 4:  # flipped payload bytes: checksum failures here and there
             for k in rng.integers(1, nfs[b], 1 + nfs[b] // 40):

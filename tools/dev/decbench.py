@@ -16,7 +16,7 @@ for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334)
         continue
     S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
     uniq = 16
-    base = np.stack([cp.make_stream(ans, nf, 10 + s, payload="ring", frames_per_rev=nf / 2.0 + 0.3) for s in range(uniq)])
+    base = np.stack([cp.make_stream(ans, nf, 10 + s, payload=os.environ.get('DEC_PAYLOAD', 'ring'), frames_per_rev=nf / 2.0 + 0.3) for s in range(uniq)])
     buf = torch.from_numpy(base).to(dev).repeat((B + uniq - 1) // uniq, 1)[:B].contiguous()
     d_nf = torch.full((B,), nf, dtype=torch.int32, device=dev)
     node_stride = nf * npf
