@@ -26,6 +26,8 @@
 //     exactly (phase P5).
 // Timestamps are not produced: the reference stamps nodes with the wall clock of the decoding
 // host (dataunpacker.cpp:164-166), not with anything in the stream.
+#include <type_traits>
+
 #include "rpl_device.hpp"
 #include "rpl_launch.hpp"
 
@@ -710,8 +712,8 @@ __global__ __launch_bounds__(NT) void k_decode(
   unsigned long long dbg_p3 = 0, dbg_p5 = 0, dbg_mark = dbg_t[2];
 #endif
   // FUSE: where node ii of the stream was stored (null: in no delivered scan) — the rule of the
-  // store loop in emit(), for the few nodes the ultra-dense smoothing patches afterwards
-  auto fused_dst = [&](uint32_t ii) -> uint2 * {
+  // store loop in emit(), for the nodes the ultra-dense smoothing corrects afterwards
+  [[maybe_unused]] auto fused_dst = [&](uint32_t ii) -> uint2 * {
     uint32_t j = 0xFFFFFFFFu;
     for (uint32_t q = 0; q < f_nsync && L.spos[q] <= ii; ++q) j = q;
     if (j == 0xFFFFFFFFu || j + 1u >= f_nsync) return nullptr;
@@ -819,7 +821,12 @@ __global__ __launch_bounds__(NT) void k_decode(
       }
     }
   };
-  auto emit = [&](uint32_t t, const GroupIn &g) {
+  // mode 0: decode and store (ultra-dense: and leave the raw distances in LDS for the smoothing
+  // pass).  The plain ultra-dense kernel (kUdTwice) runs it twice per group instead: mode 1 only
+  // leaves the raw distances, mode 2 decodes again from the payload still in registers, takes the
+  // smoothing states from LDS and stores the nodes — once.
+  auto emit = [&](uint32_t t, const GroupIn &g, auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;
     if (FUSE && !g.live) return;
     const uint32_t i = t * G, pos0 = g.pos0;
     const int prev_q8 = g.prev_q8, diff_q8 = g.diff_q8;
@@ -927,16 +934,20 @@ __global__ __launch_bounds__(NT) void k_decode(
         else if (scale == 1u) { quality = (qds >> 13) << 1; dist = (qds & 0x1FFCu) * 3u + (2046u << 2); }
         else if (scale == 2u) { quality = (qds >> 14) << 2; dist = (qds & 0x3FFCu) * 4u + (8187u << 2); }
         else { quality = (qds >> 15) << 3; dist = (qds & 0x7FFCu) * 5u + (24567u << 2); }
-        rs |= ((((ang + inc) % (360 << 16)) < (inc * 2)) ? 1u : 0u) << j;
-        nd[j] = make_node(ang >> 10, dist, quality, 0u);
         // raw distance for the smoothing pass: scale 0 -> bit 15 + value (<= 8184);
         // other scales only matter as "last distance" of a scale-0 successor, whose rule
         // |d - last| <= 8 can hold only if last <= 8192: store min(dist, 0x3FFF)
         sm[j] = scale == 0u ? (0x8000u | dist) : min(dist, 0x3FFFu);
+        if (MODE == 2) dist = (uint32_t)((int)dist + (int)L.fin[i - chunk0 + j] - 4);  // (state 4 unless scale 0)
+        rs |= ((((ang + inc) % (360 << 16)) < (inc * 2)) ? 1u : 0u) << j;
+        nd[j] = make_node(ang >> 10, dist, quality, 0u);
       }
-      if (i - chunk0 + G <= DecCfg<ANS>::kSmoothSlots)  // (always: a chunk is kUdChunk nodes)
-        *reinterpret_cast<uint2 *>(&L.smooth[i - chunk0]) =
-            make_uint2(sm[0] | (sm[G > 1 ? 1 : 0] << 16), sm[G > 2 ? 2 : 0] | (sm[G > 3 ? 3 : 0] << 16));
+      if (MODE != 2) {
+        if (i - chunk0 + G <= DecCfg<ANS>::kSmoothSlots)  // (always: a chunk is kUdChunk nodes)
+          *reinterpret_cast<uint2 *>(&L.smooth[i - chunk0]) =
+              make_uint2(sm[0] | (sm[G > 1 ? 1 : 0] << 16), sm[G > 2 ? 2 : 0] | (sm[G > 3 ? 3 : 0] << 16));
+        if (MODE == 1) return;
+      }
     }
 #ifdef RPL_DEC_NOSTORE
     {
@@ -1050,21 +1061,44 @@ __global__ __launch_bounds__(NT) void k_decode(
   for (chunk0 = 0; chunk0 < (UD ? max(carry_nodes, 1u) : 1u); chunk0 += (UD ? kChunk : 1u)) {
   const uint32_t g_lo = UD ? chunk0 / G : 0u;
   const uint32_t g_hi = UD ? min(n_groups, (chunk0 + kChunk) / G) : n_groups;
+  using mode0 = std::integral_constant<int, 0>;
+  using mode1 = std::integral_constant<int, 1>;
+  using mode2 = std::integral_constant<int, 2>;
+  // ultra-dense, nodes out: the payload of ALL the thread's groups of the chunk stays in registers
+  // across the smoothing pass (kUdChunk / G / NT groups: 8 at 256 threads), so that the nodes are
+  // decoded with their final distances and stored once.  (The fused form keeps storing first and
+  // correcting afterwards: it stores only the nodes of completed scans, and with the payload held
+  // it needs 133 registers — measured 0.77 against 0.64 ms.)
+  constexpr bool kUdTwice = UD && !FUSE;
+  constexpr uint32_t GPT = kUdTwice ? DecCfg<ANS>::kUdChunk / G / NT : 1u;
+  static_assert(!kUdTwice || GPT * G * NT == DecCfg<ANS>::kUdChunk, "a chunk is a whole number of groups per thread");
+  GroupIn ud_gi[GPT];
   uint32_t t0 = g_lo + tid;
-  for (; t0 + (U - 1u) * NT < g_hi; t0 += U * NT) {  // full trips: no conditions
+  if (kUdTwice) {
+#pragma unroll
+    for (uint32_t u = 0; u < GPT; ++u)
+      if (t0 + u * NT < g_hi) locate(t0 + u * NT, ud_gi[u]);
+#pragma unroll
+    for (uint32_t u = 0; u < GPT; ++u)
+      if (t0 + u * NT < g_hi) fetch(ud_gi[u]);
+#pragma unroll
+    for (uint32_t u = 0; u < GPT; ++u)
+      if (t0 + u * NT < g_hi) emit(t0 + u * NT, ud_gi[u], mode1{});
+  }
+  for (; !kUdTwice && t0 + (U - 1u) * NT < g_hi; t0 += U * NT) {  // full trips: no conditions
     GroupIn gi[U];
 #pragma unroll
     for (uint32_t u = 0; u < U; ++u) locate(t0 + u * NT, gi[u]);
 #pragma unroll
     for (uint32_t u = 0; u < U; ++u) fetch(gi[u]);
 #pragma unroll
-    for (uint32_t u = 0; u < U; ++u) emit(t0 + u * NT, gi[u]);
+    for (uint32_t u = 0; u < U; ++u) emit(t0 + u * NT, gi[u], mode0{});
   }
-  for (; t0 < g_hi; t0 += NT) {
+  for (; !kUdTwice && t0 < g_hi; t0 += NT) {
     GroupIn g1;
     locate(t0, g1);
     fetch(g1);
-    emit(t0, g1);
+    emit(t0, g1, mode0{});
   }
 
 #ifdef RPL_DEC_DBG
@@ -1222,18 +1256,20 @@ __global__ __launch_bounds__(NT) void k_decode(
       }
     }
     __syncthreads();
-    // the smoothed nodes' dist_mm_q2 (bytes 2..5 of the packed node): lane = node, no load.  Only
-    // scale-0 nodes are smoothed and their distance stays below 2^14: bytes 4..5 are zero before
-    // and after, one 2-byte store of bytes 2..3 does it.
-    for (uint32_t i = tid; i < N; i += NT) {
-      const int st = (int)L.fin[i];
-      if (st != 4 && chunk0 + i < n_out) {
-        uint2 *at = FUSE ? fused_dst(chunk0 + i) : out + chunk0 + i;
-        if (at) reinterpret_cast<uint16_t *>(at)[1] = (uint16_t)(rawd(i) + st - 4);
+    if (!kUdTwice) {
+      // the smoothed nodes' dist_mm_q2 (bytes 2..5 of the packed node): lane = node, no load.  Only
+      // scale-0 nodes are smoothed and their distance stays below 2^14: bytes 4..5 are zero before
+      // and after, one 2-byte store of bytes 2..3 does it.
+      for (uint32_t i = tid; i < N; i += NT) {
+        const int st = (int)L.fin[i];
+        if (st != 4 && chunk0 + i < n_out) {
+          uint2 *at = FUSE ? fused_dst(chunk0 + i) : out + chunk0 + i;
+          if (at) reinterpret_cast<uint16_t *>(at)[1] = (uint16_t)(rawd(i) + st - 4);
+        }
       }
     }
     chunk_last = (int)L.misc[7];
-    __syncthreads();  // (the next chunk's P3 overwrites the raw distances and the states)
+    if (!kUdTwice) __syncthreads();  // (the next chunk's P3 overwrites the raw distances and the states)
     if (!last_chunk) {
     } else if (L.misc[4] & 0x80000000u) {
       last_dist_out = (int)(L.misc[4] & 0x7FFFFFFFu);
@@ -1248,6 +1284,11 @@ __global__ __launch_bounds__(NT) void k_decode(
                       : scale == 2u ? (int)((qds & 0x3FFCu) * 4u + (8187u << 2))
                                     : (int)((qds & 0x7FFCu) * 5u + (24567u << 2));
     }
+  }
+  if (kUdTwice) {  // the chunk's nodes with their final distances (states: L.fin, complete since the barrier above)
+#pragma unroll
+    for (uint32_t u = 0; u < GPT; ++u)
+      if (t0 + u * NT < g_hi) emit(t0 + u * NT, ud_gi[u], mode2{});
   }
 
 #ifdef RPL_DEC_DBG
