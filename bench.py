@@ -326,12 +326,14 @@ def decode_stage(gpu, dev, stream, cpu_seconds):
     sync = lambda: torch.cuda.synchronize(dev)
     # ("ultra_dense": the generator's 2.5-5.5 m ring clamped to that format's scale 0, i.e. a CONSTANT
     # 2046 mm — the one input on which the smoothing pass has to walk every segment twice;
-    # "ultra_dense_near": a 0.9-1.9 m ring, distances that vary the way a real target's do)
+    # "ultra_dense_near": a noiseless 0.9-1.9 m ring — runs of equal 2 mm codes, the smoothing pass's
+    # hardest input; "ultra_dense_noisy": the same ring with 4 mm of range noise, what a sensor sends)
     for name, ans, nf, payload in (("dense", cp.ANS_DENSE_CAPSULED, 801, "ring"),
                                    ("express", cp.ANS_CAPSULED, 1001, "ring"),
                                    ("ultra", cp.ANS_CAPSULED_ULTRA, 334, "ring"),
                                    ("ultra_dense", cp.ANS_ULTRA_DENSE_CAPSULED, 501, "ring"),
                                    ("ultra_dense_near", cp.ANS_ULTRA_DENSE_CAPSULED, 501, "ring_near"),
+                                   ("ultra_dense_noisy", cp.ANS_ULTRA_DENSE_CAPSULED, 501, "ring_noisy"),
                                    ("hq", cp.ANS_HQ, 334, "ring"),
                                    ("normal", cp.ANS_MEASUREMENT, 4000, "ring")):
         S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]

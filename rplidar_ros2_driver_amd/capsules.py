@@ -63,15 +63,19 @@ def make_frames(ans: int, n_frames: int, seed: int, *, payload: str = "random",
         o = _START_ANGLE_OFF[ans]
         f[:, o] = sa & 0xFF
         f[:, o + 1] = sa >> 8
-        if payload in ("ring", "ring_near"):
+        if payload in ("ring", "ring_near", "ring_noisy"):
             npf = NODES_PER_FRAME[ans]
             theta = (deg[:, None] + np.arange(npf)[None, :] * (360.0 / frames_per_rev / npf))
             r_mm = 4000.0 + 1500.0 * np.sin(np.deg2rad(theta) * 3.0 + 0.7)
-            if payload == "ring_near":
+            if payload in ("ring_near", "ring_noisy"):
                 # a target inside the ultra-dense format's scale 0 (< 2.046 m, the only scale its
                 # distance smoothing applies to): "ring" clamps that type's 2.5-5.5 m ring to a
-                # CONSTANT 2046 mm, the one input on which two smoothing states never merge
+                # CONSTANT 2046 mm.  "ring_near" is noiseless: long runs of equal 2 mm codes with an
+                # occasional step, the input that keeps smoothing chains one apart longest;
+                # "ring_noisy" adds the +-4 mm of range noise a real return has.
                 r_mm = 1400.0 + 500.0 * np.sin(np.deg2rad(theta) * 3.0 + 0.7)
+                if payload == "ring_noisy":
+                    r_mm = r_mm + rng.normal(0.0, 4.0, r_mm.shape)
             drop = rng.random(r_mm.shape) < 0.08
             r_mm[drop] = 0.0
             d = r_mm.astype(np.uint32)

@@ -710,6 +710,7 @@ __global__ __launch_bounds__(NT) void k_decode(
   __syncthreads();
   dbg_t[2] = __builtin_amdgcn_s_memtime();
   unsigned long long dbg_p3 = 0, dbg_p5 = 0, dbg_mark = dbg_t[2];
+  unsigned long long dbg_ud[4] = {0, 0, 0, 0}, dbg_u0 = 0;  // ultra-dense: walk, map scan, second walk, final decode
 #endif
   // FUSE: where node ii of the stream was stored (null: in no delivered scan) — the rule of the
   // store loop in emit(), for the nodes the ultra-dense smoothing corrects afterwards
@@ -1118,16 +1119,31 @@ __global__ __launch_bounds__(NT) void k_decode(
   // writes the smoothed distances.  Exact for any input, O(n / 256) steps per thread.
   if (UD && carry_nodes) {  // (indices below are relative to the chunk)
     __syncthreads();
+#ifdef RPL_DEC_DBG
+    dbg_u0 = __builtin_amdgcn_s_memtime();
+#endif
     auto rawd = [&](uint32_t i) -> int { return (int)(L.smooth[i] & 0x3FFFu); };
     auto is_s0 = [&](uint32_t i) -> bool { return (L.smooth[i] & 0x8000u) != 0u; };
-    // state of node i given the value `last` its predecessor left behind
-    auto step = [&](uint32_t i, int last) -> int {
-      if (!is_s0(i)) return 4;
-      const int d = rawd(i);
-      int ad = d - last;
-      if (ad < 0) ad = -ad;
-      if (last != 0 && ad <= 8) return ((d + last) >> 1) - d + 4;
-      return 4;
+    // state of node i given the value `last` its predecessor left behind (:997-1003):
+    //   scale 0 and last != 0 and |d - last| <= 8  ->  ((d + last) >> 1) - d + 4,  else 4
+    // The same rule with the per-node part taken out: with x = last - d = (pd - 4 - d) + e for entry
+    // state e (pd: the predecessor's raw distance), (d + last) >> 1 = d + (x >> 1), so the new state
+    // is (x >> 1) + 4 when |x| <= 8 and last != 0 (e != 4 - pd), else 4.  One LDS word per node.
+    struct NodeCtx {
+      int base, ez;
+      bool s0;
+    };
+    auto node_ctx = [&](uint32_t i, int pd) -> NodeCtx {
+      const uint32_t w = L.smooth[i];
+      NodeCtx c;
+      c.s0 = (w & 0x8000u) != 0u;
+      c.base = pd - 4 - (int)(w & 0x3FFFu);
+      c.ez = 4 - pd;
+      return c;
+    };
+    auto stepc = [](const NodeCtx &c, int e) -> int {
+      const int x = c.base + e;
+      return (c.s0 && (uint32_t)(x + 8) <= 16u && e != c.ez) ? (x >> 1) + 4 : 4;
     };
     constexpr unsigned long long kIdent = 0x876543210ull;
     auto compose = [](unsigned long long first, unsigned long long then) -> unsigned long long {
@@ -1175,16 +1191,18 @@ __global__ __launch_bounds__(NT) void k_decode(
       int va = 0, vb = 0;
       uint32_t in_b = 0;  // entry states that lead to vb (the others lead to va)
       bool two = false;
+      int pd = i_lo ? rawd(i_lo - 1u) : chunk_last;  // the predecessor's raw distance, carried along
       for (; i < i_hi && !two; ++i) {
-        if (i == 0u) {
-          const int st0 = step(0u, chunk_last);
+        const NodeCtx nc = node_ctx(i, pd);
+        if (i == 0u) {  // (pd = what the previous chunk left behind: its final value, i.e. entry state 4)
+          const int st0 = stepc(nc, 4);
 #pragma unroll
           for (int c = 0; c < 9; ++c) cur[c] = st0;
         } else {
-          const int pd = rawd(i - 1u);
 #pragma unroll
-          for (int c = 0; c < 9; ++c) cur[c] = step(i, pd + cur[c] - 4);
+          for (int c = 0; c < 9; ++c) cur[c] = stepc(nc, cur[c]);
         }
+        pd = pd - 4 - nc.base;  // (= this node's raw distance: base = pd - 4 - d)
         patch(i, cur[4]);  // (the guess)
         va = cur[0];
         vb = va;
@@ -1201,16 +1219,19 @@ __global__ __launch_bounds__(NT) void k_decode(
       if (two) {
         const bool guess_b = ((in_b >> 4) & 1u) != 0u;  // entry state 4 leads to vb
         for (; i < i_hi && va != vb; ++i) {
-          const int pd = rawd(i - 1u);
-          va = step(i, pd + va - 4);
-          vb = step(i, pd + vb - 4);
+          const NodeCtx nc = node_ctx(i, pd);
+          va = stepc(nc, va);
+          vb = stepc(nc, vb);
+          pd = pd - 4 - nc.base;
           patch(i, guess_b ? vb : va);
         }
         if (va == vb) {
           i_open = i - 1u;  // node i-1 merged the last two states: it has state va whatever the entry
           // (already written: every chain, the guessed one included, has state va there)
           for (; i < i_hi; ++i) {
-            va = step(i, rawd(i - 1u) + va - 4);
+            const NodeCtx nc = node_ctx(i, pd);
+            va = stepc(nc, va);
+            pd = pd - 4 - nc.base;
             patch(i, va);
           }
           vb = va;
@@ -1222,40 +1243,70 @@ __global__ __launch_bounds__(NT) void k_decode(
 #pragma unroll
       for (int c = 0; c < 9; ++c) M |= (unsigned long long)(uint32_t)cur[c] << (4 * c);
     }
-    // pass B: exclusive scan of the maps over the block (composition, earlier segment first)
+#ifdef RPL_DEC_DBG
+    __syncthreads();
+    { const unsigned long long now = __builtin_amdgcn_s_memtime(); dbg_ud[0] += now - dbg_u0; dbg_u0 = now; }
+#endif
+    // pass B: exclusive scan of the maps over the block (composition, earlier segment first).
+    // A segment whose states merged has a CONSTANT map, and "anything, then a constant" is that
+    // constant: when every segment of the wave is constant — distances that vary merge within a
+    // few nodes — the inclusive scan is the lane's own map and nothing is composed (the 6-step scan
+    // is ~400 of the pass's ~600 vector instructions per thread).
+    auto is_const = [](unsigned long long m) -> bool { return m == (m & 15ull) * 0x111111111ull; };
+    const bool wave_const = __all(is_const(M) ? 1 : 0) != 0;
     unsigned long long inc = M;
+    if (!wave_const) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d, 64);
-      const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d, 64);
-      const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-      if ((int)lane_id() >= d) inc = compose(other, inc);
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, d, 64);
+        const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d, 64);
+        const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+        if ((int)lane_id() >= d) inc = compose(other, inc);
+      }
     }
     unsigned long long *wmap = reinterpret_cast<unsigned long long *>(L.tmp);  // one map per wave
     if (lane_id() == 63) wmap[wave_id()] = inc;
     __syncthreads();
     unsigned long long before = kIdent;  // everything in front of this wave
-    for (uint32_t w = 0; w < wave_id(); ++w) before = compose(before, wmap[w]);
+    for (uint32_t w = 0; w < wave_id(); ++w) {
+      const unsigned long long m = wmap[w];  // (the same for the whole wave)
+      before = is_const(m) ? m : compose(before, m);
+    }
     unsigned long long excl;
     {
       const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)inc, 1, 64);
       const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), 1, 64);
       excl = lane_id() == 0 ? kIdent : (((unsigned long long)hi << 32) | lo);
     }
-    excl = compose(before, excl);
+    if (wave_const) {
+      if (lane_id() == 0) excl = before;  // (lanes >= 1: their predecessor's constant)
+    } else {
+      excl = compose(before, excl);
+    }
     // every map in front of a non-empty segment starts with node 0's constant map, so any
     // entry state (take 4) gives the state its predecessor node really has
     int sp = (int)((excl >> (4 * 4)) & 15ull);
+#ifdef RPL_DEC_DBG
+    __syncthreads();
+    { const unsigned long long now = __builtin_amdgcn_s_memtime(); dbg_ud[1] += now - dbg_u0; dbg_u0 = now; }
+#endif
     // pass C: the (usually empty) head of the segment again, if its true entry state is not the
     // guessed one
     if (sp != 4) {
+      int pd = i_lo ? rawd(i_lo - 1u) : chunk_last;
       for (uint32_t i = i_lo; i < min(i_open, i_hi); ++i) {
-        const int last = (i == 0u) ? chunk_last : rawd(i - 1u) + sp - 4;
-        sp = step(i, last);
+        const NodeCtx nc = node_ctx(i, pd);
+        sp = stepc(nc, i == 0u ? 4 : sp);
+        pd = pd - 4 - nc.base;
+        // the true chain has met the guessed one: from here on what pass A wrote is true
+        if (sp == (int)L.fin[i]) break;
         patch(i, sp, true);
       }
     }
     __syncthreads();
+#ifdef RPL_DEC_DBG
+    { const unsigned long long now = __builtin_amdgcn_s_memtime(); dbg_ud[2] += now - dbg_u0; dbg_u0 = now; }
+#endif
     if (!kUdTwice) {
       // the smoothed nodes' dist_mm_q2 (bytes 2..5 of the packed node): lane = node, no load.  Only
       // scale-0 nodes are smoothed and their distance stays below 2^14: bytes 4..5 are zero before
@@ -1297,6 +1348,7 @@ __global__ __launch_bounds__(NT) void k_decode(
     const unsigned long long now = __builtin_amdgcn_s_memtime();
     dbg_p5 += now - dbg_mark;
     dbg_mark = now;
+    (void)dbg_u0;
   }
 #endif
   }  // chunks
@@ -1339,6 +1391,8 @@ __global__ __launch_bounds__(NT) void k_decode(
     {
       for (int d = 0; d < 5; ++d) reset_at[(size_t)b * reset_stride + 3 + d] = (uint32_t)(dbg_t[d + 1] - dbg_t[d]);
       reset_at[(size_t)b * reset_stride + 2] = (uint32_t)(dbg_t[0] - dbg_start);
+      if (reset_stride >= 16)
+        for (int d = 0; d < 4; ++d) reset_at[(size_t)b * reset_stride + 8 + d] = (uint32_t)dbg_ud[d];
     }
 #endif
     if (n_errors) n_errors[b] = L.misc[5];

@@ -138,7 +138,7 @@ def test_fuzz_decode_against_oracle(gpu, oracle, seed):
             state = (int(rng.integers(0, 2)), int(rng.integers(0, 2)) * int(rng.integers(0, 40000)))
             mode = int(rng.integers(0, 4))
             frames = cp.make_frames(ans, nf, int(rng.integers(0, 1 << 30)),
-                                    payload=str(rng.choice(["random", "ring", "ring_near"])),
+                                    payload=str(rng.choice(["random", "ring", "ring_near", "ring_noisy"])),
                                     frames_per_rev=float(rng.choice([1.5, 3.1, 12.3, 40.0, 300.0])),
                                     first_sync=bool(rng.integers(0, 2)))
             if mode == 0:

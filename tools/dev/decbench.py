@@ -22,11 +22,12 @@ for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334)
     node_stride = nf * npf
     d_nodes = torch.empty(B, node_stride * 8, dtype=torch.uint8, device=dev)
     d_nn = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_rst = torch.zeros(B, 8, dtype=torch.int32, device=dev)
+    RS = 16 if os.environ.get('DEC_DBG') else 8
+    d_rst = torch.zeros(B, RS, dtype=torch.int32, device=dev)
     d_nr = torch.zeros(B, dtype=torch.int32, device=dev)
     def run():
         gpu.decode_batch_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0,
-                             d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8, d_nr.data_ptr())
+                             d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), RS, d_nr.data_ptr())
     PIECES = int(os.environ.get('DEC_PIECES', '0'))
     if PIECES > 1:
         # timing experiment: the call as PIECES calls of nf / PIECES frames (+ the overlap frame), each short
@@ -40,7 +41,7 @@ for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334)
                 first = p * W - (1 if p else 0)
                 gpu.decode_batch_dev(ans, 125, buf.data_ptr() + first * S, nf * S, 0, 0, d_nfp[p].data_ptr(), W + 1, B,
                                      d_state2.data_ptr() if p else d_state.data_ptr(), 0,
-                                     d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), 8, d_nr.data_ptr())
+                                     d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), RS, d_nr.data_ptr())
     run(); torch.cuda.synchronize()
     ts = []
     for _ in range(5):
@@ -55,6 +56,8 @@ for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334)
     if os.environ.get('DEC_DBG'):
         ph = d_rst.cpu().numpy()[:, 3:8].astype(np.float64)
         print("   phase cycles P1 P2 P3 P4 P5 (mean):", ph.mean(0).round(0), "sum", ph.sum(1).mean().round(0), "head (staging)", d_rst.cpu().numpy()[:, 2].astype(np.float64).mean().round(0))
+        if ans == 0x86:
+            print("   ultra-dense smoothing: [walk, map scan, second walk, -] (mean cycles):", d_rst.cpu().numpy()[:, 8:12].astype(np.float64).mean(0).round(0))
         print("   P1 p10/p50/p90:", np.percentile(ph[:, 0], [10, 50, 90]).round(0), " first 1792 WGs mean", ph[:1792, 0].mean().round(0), "rest", ph[1792:, 0].mean().round(0),
               " P3 p10/p50/p90:", np.percentile(ph[:, 2], [10, 50, 90]).round(0))
     print(f"ans {ans:#x}: {nodes/1e6:.1f} Mnodes in {t:.3f} ms -> {nodes/t/1e6:.1f} Gnodes/s, "
