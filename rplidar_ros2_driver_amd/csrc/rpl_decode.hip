@@ -712,26 +712,6 @@ __global__ __launch_bounds__(NT) void k_decode(
   unsigned long long dbg_p3 = 0, dbg_p5 = 0, dbg_mark = dbg_t[2];
   unsigned long long dbg_ud[4] = {0, 0, 0, 0}, dbg_u0 = 0;  // ultra-dense: walk, map scan, second walk, final decode
 #endif
-  // FUSE: where node ii of the stream was stored (null: in no delivered scan) — the rule of the
-  // store loop in emit(), for the nodes the ultra-dense smoothing corrects afterwards
-  [[maybe_unused]] auto fused_dst = [&](uint32_t ii) -> uint2 * {
-    uint32_t j = 0xFFFFFFFFu;
-    for (uint32_t q = 0; q < f_nsync && L.spos[q] <= ii; ++q) j = q;
-    if (j == 0xFFFFFFFFu || j + 1u >= f_nsync) return nullptr;
-    const uint32_t slot = L.sslot[j];
-    if (slot == 0xFFFFu) return nullptr;
-    const uint32_t s0 = L.spos[j], total = L.spos[j + 1u] - s0;
-    const uint32_t full = min(total, fz.max_count), len = min(full, fz.n_stride);
-    const uint32_t off = ii - s0;
-    uint32_t pos = off;
-    if (off + 1u >= len) {
-      const uint32_t last_src = (len == full && total > full) ? total - 1u : len - 1u;
-      if (off != last_src) return nullptr;
-      pos = len - 1u;
-    }
-    return fz.batch + ((size_t)b * fz.scan_cap + slot) * fz.n_stride + pos;
-  };
-
   // ---- P3: the nodes ----------------------------------------------------------------------
   // A lane decodes G consecutive nodes of ONE frame: the per-frame arithmetic (table look-ups,
   // angle step, the divisions) is paid once per group, the payload arrives in one or two wide
@@ -822,10 +802,9 @@ __global__ __launch_bounds__(NT) void k_decode(
       }
     }
   };
-  // mode 0: decode and store (ultra-dense: and leave the raw distances in LDS for the smoothing
-  // pass).  The plain ultra-dense kernel (kUdTwice) runs it twice per group instead: mode 1 only
-  // leaves the raw distances, mode 2 decodes again from the payload still in registers, takes the
-  // smoothing states from LDS and stores the nodes — once.
+  // mode 0: decode and store.  Ultra-dense runs it twice per group: mode 1 only leaves the raw
+  // distances in LDS for the smoothing pass, mode 2 decodes again from the payload still in
+  // registers, takes the smoothing states from LDS and stores the nodes — once.
   auto emit = [&](uint32_t t, const GroupIn &g, auto mode_c) {
     constexpr int MODE = decltype(mode_c)::value;
     if (FUSE && !g.live) return;
@@ -1065,26 +1044,32 @@ __global__ __launch_bounds__(NT) void k_decode(
   using mode0 = std::integral_constant<int, 0>;
   using mode1 = std::integral_constant<int, 1>;
   using mode2 = std::integral_constant<int, 2>;
-  // ultra-dense, nodes out: the payload of ALL the thread's groups of the chunk stays in registers
-  // across the smoothing pass (kUdChunk / G / NT groups: 8 at 256 threads), so that the nodes are
-  // decoded with their final distances and stored once.  (The fused form keeps storing first and
-  // correcting afterwards: it stores only the nodes of completed scans, and with the payload held
-  // it needs 133 registers — measured 0.77 against 0.64 ms.)
-  constexpr bool kUdTwice = UD && !FUSE;
+  // ultra-dense: the payload of ALL the thread's groups of the chunk stays in registers across the
+  // smoothing pass (kUdChunk / G / NT groups: 8 at 256 threads, 3 registers each), so that the nodes
+  // are decoded with their final distances and stored once.  (Storing first and correcting the
+  // smoothed nodes afterwards — a coalesced 2-byte store per node — writes the lines twice: on a
+  // near ring with range noise 0.67 against 0.54 ms for the fused form, 0.86 against 0.51 for this
+  // one; only input that smooths nothing is 5-10 % faster that way.)
+  constexpr bool kUdTwice = UD;
   constexpr uint32_t GPT = kUdTwice ? DecCfg<ANS>::kUdChunk / G / NT : 1u;
   static_assert(!kUdTwice || GPT * G * NT == DecCfg<ANS>::kUdChunk, "a chunk is a whole number of groups per thread");
-  GroupIn ud_gi[GPT];
+  uint64_t ud_w[GPT];   // (only the payload is kept: the frame look-ups are cheap to repeat)
+  uint32_t ud_w2[GPT];
   uint32_t t0 = g_lo + tid;
   if (kUdTwice) {
+    GroupIn gi[GPT];
 #pragma unroll
     for (uint32_t u = 0; u < GPT; ++u)
-      if (t0 + u * NT < g_hi) locate(t0 + u * NT, ud_gi[u]);
+      if (t0 + u * NT < g_hi) locate(t0 + u * NT, gi[u]);
 #pragma unroll
     for (uint32_t u = 0; u < GPT; ++u)
-      if (t0 + u * NT < g_hi) fetch(ud_gi[u]);
+      if (t0 + u * NT < g_hi) fetch(gi[u]);
 #pragma unroll
-    for (uint32_t u = 0; u < GPT; ++u)
-      if (t0 + u * NT < g_hi) emit(t0 + u * NT, ud_gi[u], mode1{});
+    for (uint32_t u = 0; u < GPT; ++u) {
+      if (t0 + u * NT < g_hi) emit(t0 + u * NT, gi[u], mode1{});
+      ud_w[u] = gi[u].w;
+      ud_w2[u] = gi[u].w2;
+    }
   }
   for (; !kUdTwice && t0 + (U - 1u) * NT < g_hi; t0 += U * NT) {  // full trips: no conditions
     GroupIn gi[U];
@@ -1307,20 +1292,7 @@ __global__ __launch_bounds__(NT) void k_decode(
 #ifdef RPL_DEC_DBG
     { const unsigned long long now = __builtin_amdgcn_s_memtime(); dbg_ud[2] += now - dbg_u0; dbg_u0 = now; }
 #endif
-    if (!kUdTwice) {
-      // the smoothed nodes' dist_mm_q2 (bytes 2..5 of the packed node): lane = node, no load.  Only
-      // scale-0 nodes are smoothed and their distance stays below 2^14: bytes 4..5 are zero before
-      // and after, one 2-byte store of bytes 2..3 does it.
-      for (uint32_t i = tid; i < N; i += NT) {
-        const int st = (int)L.fin[i];
-        if (st != 4 && chunk0 + i < n_out) {
-          uint2 *at = FUSE ? fused_dst(chunk0 + i) : out + chunk0 + i;
-          if (at) reinterpret_cast<uint16_t *>(at)[1] = (uint16_t)(rawd(i) + st - 4);
-        }
-      }
-    }
     chunk_last = (int)L.misc[7];
-    if (!kUdTwice) __syncthreads();  // (the next chunk's P3 overwrites the raw distances and the states)
     if (!last_chunk) {
     } else if (L.misc[4] & 0x80000000u) {
       last_dist_out = (int)(L.misc[4] & 0x7FFFFFFFu);
@@ -1338,8 +1310,15 @@ __global__ __launch_bounds__(NT) void k_decode(
   }
   if (kUdTwice) {  // the chunk's nodes with their final distances (states: L.fin, complete since the barrier above)
 #pragma unroll
-    for (uint32_t u = 0; u < GPT; ++u)
-      if (t0 + u * NT < g_hi) emit(t0 + u * NT, ud_gi[u], mode2{});
+    for (uint32_t u = 0; u < GPT; ++u) {
+      if (t0 + u * NT < g_hi) {
+        GroupIn g;
+        locate(t0 + u * NT, g);
+        g.w = ud_w[u];
+        g.w2 = ud_w2[u];
+        emit(t0 + u * NT, g, mode2{});
+      }
+    }
   }
 
 #ifdef RPL_DEC_DBG
