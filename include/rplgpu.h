@@ -182,11 +182,14 @@ int32_t rplgpu_pack_clouds_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t 
 size_t rplgpu_frame_size(uint8_t ans_type);      /* bytes per frame, 0 = unknown type */
 size_t rplgpu_nodes_per_frame(uint8_t ans_type); /* nodes a frame can publish */
 uint32_t rplgpu_decode_max_frames(uint8_t ans_type); /* frames of one stream per decode call */
-/* Performance hint, no change of results: rplgpu_decode_batch_dev calls with back-to-back frames
- * (d_frame_off == NULL) of a capsule type and max_frames up to this value take the LDS-staged
- * decoder (the workgroup copies its stream into LDS once and decodes from there; 15-25 % faster
- * on full batches); longer pieces, framed input and the other types take the
- * plain one.  0: the type has no staged decoder. */
+/* Performance hint, no change of results: rplgpu_decode_batch_dev calls of a capsule type with
+ * max_frames up to this value take the LDS-staged decoder (the workgroup copies its stream into
+ * LDS once and decodes from there: 15-30 % faster on full batches) — with
+ * back-to-back frames (d_frame_off == NULL) always; with frame offsets for every stream whose
+ * frames lie in ascending order, at most 16383 rejected bytes behind their back-to-back place and
+ * within the LDS the call reserves (rplgpu_frame_stream's output of a link that loses a few bytes
+ * now and then), the other streams of the call going through the plain kernel.  Longer pieces
+ * and the other types take the plain one.  0: the type has no staged decoder. */
 uint32_t rplgpu_decode_staged_frames(uint8_t ans_type);
 /* Host framing: the position-0/1 rules of every onData loop.  frame_off[k] = byte offset of
  * frame k; gap[k] = 1 when bytes were rejected between frame k-1 and frame k (that clears the

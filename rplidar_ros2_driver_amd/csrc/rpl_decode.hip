@@ -311,6 +311,9 @@ struct DecFuse {
   uint32_t *todo;           // FUSE: [B], set to 1 when this stream has to take the unfused path
   const uint32_t *only;     // plain kernel: streams with only[b] == 0 are skipped (null: all)
   uint32_t n_stride, scan_cap, max_count;
+  // STG with frame offsets: [B], 1 = this stream's frames do not lie the way the staged kernel
+  // needs them (see its head) and the plain kernel has to take it, 0 = done here
+  uint32_t *stage_todo;
 };
 
 // FRAMED: frame offsets (and gaps) given; else back to back.  STG: the workgroup (NT threads) copies
@@ -334,16 +337,26 @@ __global__ __launch_bounds__(NT) void k_decode(
   __shared__ DecodeLds<ANS, STG> L;
 
   const uint32_t b = blockIdx.x, tid = threadIdx.x;
-  if (!FUSE && fz.only && fz.only[b] == 0u) return;  // (the fused kernel dealt with this stream)
+  if (!FUSE && fz.only && fz.only[b] == 0u) {  // (the fused / the staged kernel dealt with this stream)
+    if (STG && FRAMED && tid == 0) fz.stage_todo[b] = 0u;
+    return;
+  }
   const uint8_t *base = bytes + (size_t)b * stream_stride;
   const uint32_t *foff = FRAMED ? frame_off + (size_t)b * max_frames : nullptr;
   const uint8_t *fgap = (FRAMED && gap) ? gap + (size_t)b * max_frames : nullptr;
   const uint32_t nf = min(n_frames[b], min(max_frames, DecCfg<ANS>::kMaxFrames));
   uint2 *out = FUSE ? nullptr : nodes_out + (size_t)b * node_stride;
+  uint32_t *Lframe_ = nullptr;  // (= Lframe, declared below)
   auto frame_ptr = [&](uint32_t k) -> const uint8_t * {
     return base + (FRAMED ? (size_t)foff[k] : (size_t)k * S);
   };
-  auto frame_at = [&](uint32_t k) -> uint32_t { return FRAMED ? foff[k] : k * S; };
+  // byte offset of frame k in the stream.  STG with frame offsets: in the staged copy, which starts
+  // at frame 0 — k * S plus the bytes rejected in front of frame k, kept in bits 16..29 of the frame's
+  // table entry by P1 (with the gap flag in bit 30), so that nothing after P1 loads an offset again
+  auto frame_at = [&](uint32_t k) -> uint32_t {
+    if (STG && FRAMED) return k * S + ((Lframe_[k] >> 16) & 0x3FFFu);
+    return FRAMED ? foff[k] : k * S;
+  };
 #ifdef RPL_DEC_DBG
   const unsigned long long dbg_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -354,28 +367,44 @@ __global__ __launch_bounds__(NT) void k_decode(
   // wait that queue out once per trip.  Here the stream crosses it ONCE, as one burst of 16-byte
   // loads issued before this workgroup has stored anything, and both passes read LDS.
   extern __shared__ uint4 dec_stage[];
-  static_assert(!STG || (CAPS && !FRAMED), "STG: back-to-back capsule streams");
+  static_assert(!STG || (CAPS && !FUSE), "STG: capsule streams, nodes out");
   static_assert(ANS != RPLGPU_ANS_HQ || NT == 256, "HQ: one CRC table entry per thread");
   const DecStageLayout lay = dec_stage_layout(ANS, STG ? min(max_frames, DecCfg<ANS>::kMaxFrames) : 0u);
   uint8_t *dyn = reinterpret_cast<uint8_t *>(dec_stage);
   const uint32_t raw_words = STG ? lay.raw_words : DecCfg<ANS>::kRawBitWords;
   unsigned long long *Lraw = STG ? reinterpret_cast<unsigned long long *>(dyn + lay.raw_at) : L.rawbits;
   uint32_t *Lframe = STG ? reinterpret_cast<uint32_t *>(dyn + lay.frame_at) : L.frame;
+  Lframe_ = Lframe;
   uint16_t *Lemit = STG ? reinterpret_cast<uint16_t *>(dyn + lay.emit_at) : L.emit_frame;
   const DecSrc<STG> src{base, reinterpret_cast<const uint32_t *>(dec_stage)};
+  // With frame offsets the staged range is [offset of frame 0, end of the last frame): as long as
+  // it fits the LDS the call reserved (rejected bytes between the frames count) and, checked per
+  // frame in P1, every frame lies inside it at most 16383 rejected bytes behind its back-to-back
+  // place — offsets as rplgpu_frame_stream produces them.  Otherwise nothing is written,
+  // fz.stage_todo[b] is raised and the plain kernel takes the stream.
+  uint32_t stage_lo = 0, stage_hi = nf * S;
+  if (STG && FRAMED && nf) {
+    stage_lo = foff[0];
+    stage_hi = foff[nf - 1u] + S;
+    if (stage_hi < stage_lo + nf * S || stage_hi - stage_lo > lay.raw_at - 16u) {  // (block-uniform)
+      if (tid == 0) fz.stage_todo[b] = 1u;
+      return;
+    }
+  }
   if (STG) {
-    const uint32_t nbytes = nf * S, n16 = nbytes >> 4;
+    const uint8_t *from = base + stage_lo;
+    const uint32_t nbytes = stage_hi - stage_lo, n16 = nbytes >> 4;
     constexpr uint32_t UN = 4;
     uint32_t i = tid;
     for (; i + (UN - 1u) * NT < n16; i += UN * NT) {
       uint4 v[UN];
 #pragma unroll
-      for (uint32_t u = 0; u < UN; ++u) v[u] = ld128(base + 16u * (size_t)(i + u * NT));
+      for (uint32_t u = 0; u < UN; ++u) v[u] = ld128(from + 16u * (size_t)(i + u * NT));
 #pragma unroll
       for (uint32_t u = 0; u < UN; ++u) dec_stage[i + u * NT] = v[u];
     }
-    for (; i < n16; i += NT) dec_stage[i] = ld128(base + 16u * (size_t)i);
-    for (uint32_t q = (n16 << 4) + tid; q < nbytes; q += NT) dyn[q] = base[q];
+    for (; i < n16; i += NT) dec_stage[i] = ld128(from + 16u * (size_t)i);
+    for (uint32_t q = (n16 << 4) + tid; q < nbytes; q += NT) dyn[q] = from[q];
   }
 
   // state word 2, bit 0: frame 0 is the previous call's last frame, handed over again only as
@@ -455,7 +484,16 @@ __global__ __launch_bounds__(NT) void k_decode(
     // STG: out of LDS a lane takes a whole frame (its dwords are an odd number of banks apart from
     // the neighbour's: no conflicts, no cross-lane reduction)
     for (uint32_t k = tid; STG && k < nf; k += NT) {
-      const uint32_t f = frame_at(k);
+      uint32_t f = k * S, place = 0;  // place: bits 16..30 of the table entry (rejected bytes, gap flag)
+      if (FRAMED) {
+        const uint32_t off = foff[k], rej = off - stage_lo - k * S;
+        if (off < stage_lo || off + S > stage_hi || rej > 0x3FFFu) {
+          L.misc[1] = 1u;  // (not where the staged kernel needs it: the plain kernel takes the stream)
+          continue;
+        }
+        f = off - stage_lo;
+        place = (rej << 16) | ((fgap && fgap[k]) ? 0x40000000u : 0u);
+      }
       uint32_t xw = 0, first = 0;
 #pragma unroll
       for (uint32_t d = 0; d < NDW; ++d) {
@@ -470,13 +508,13 @@ __global__ __launch_bounds__(NT) void k_decode(
         xw ^= w;
       }
       const uint32_t b0 = first & 0xFFu, b1 = (first >> 8) & 0xFFu;
-      if ((b0 >> 4) != 0xAu || (b1 >> 4) != 0x5u) unframed = 1;
+      if (!FRAMED && ((b0 >> 4) != 0xAu || (b1 >> 4) != 0x5u)) unframed = 1;
       xw ^= xw >> 16;
       const uint32_t x = ((xw ^ (xw >> 8)) ^ b0 ^ b1) & 0xFFu;
       const bool ok = (((b0 & 0xFu) | (b1 << 4)) & 0xFFu) == x;
       my_err += (ok || (carry0 && k == 0u)) ? 0u : 1u;
       const uint32_t sa = SA_OFF == 2u ? (first >> 16) : src.u16(f + SA_OFF);
-      Lframe[k] = (ok ? 0x80000000u : 0u) | sa;
+      Lframe[k] = (ok ? 0x80000000u : 0u) | place | sa;
     }
     for (uint32_t k0 = 0; !STG && k0 < nf; k0 += DEPTH * FPT) {
       uint32_t v[DEPTH][TRIPS];
@@ -524,6 +562,11 @@ __global__ __launch_bounds__(NT) void k_decode(
   }
   if (unframed) atomicOr(&L.misc[0], RPLGPU_STREAM_UNFRAMED);
   __syncthreads();
+  if (STG && FRAMED) {
+    const bool misplaced = L.misc[1] != 0u;  // (block-uniform; nothing has left the workgroup yet)
+    if (tid == 0) fz.stage_todo[b] = misplaced ? 1u : 0u;
+    if (misplaced) return;
+  }
   const bool bad_framing = (L.misc[0] & RPLGPU_STREAM_UNFRAMED) != 0u;
 
 #ifdef RPL_DEC_DBG
@@ -547,7 +590,8 @@ __global__ __launch_bounds__(NT) void k_decode(
       } else if (rec >> 31) {
         resets = (rec >> 15) & 1u;  // revolution start: publishNewScanReset (:160-171)
         if (carry0 && k == 0u) resets = 0u;
-        const bool prev_ok = k > 0 && (Lframe[k - 1] >> 31) && !(fgap && fgap[k]);
+        const bool gap_k = (STG && FRAMED) ? ((rec >> 30) & 1u) != 0u : (fgap && fgap[k]);
+        const bool prev_ok = k > 0 && (Lframe[k - 1] >> 31) && !gap_k;
         if (prev_ok && !resets) {
           emits = 1;
           if (FILTERED) {  // :750-754 / :971-975: too large an angle step -> discard
@@ -758,7 +802,10 @@ __global__ __launch_bounds__(NT) void k_decode(
     }
     const uint32_t k = DecCfg<ANS>::kTable ? (uint32_t)Lemit[e] : e;
     constexpr bool kPrev = CAPS;  // capsule types decode frame k-1 with frame k's start angle
-    if (FRAMED) {
+    if (STG && FRAMED) {
+      g.off_cur = frame_at(k);
+      g.off_prev = kPrev ? frame_at(k - 1u) : 0u;
+    } else if (FRAMED) {
       g.off_cur = foff[k];
       g.off_prev = kPrev ? foff[k - 1u] : 0u;
     } else {
@@ -1722,8 +1769,8 @@ __global__ __launch_bounds__(kDecBlock) void k_scans_to_batch(
 }
 
 // ---- launchers ------------------------------------------------------------------------------
-// The LDS-staged instances (back-to-back capsule streams, nodes out): 512-thread workgroups, two
-// per CU — for calls whose streams fit half the CU's LDS together with their tables (max_frames up to
+// The LDS-staged instances (capsule streams, nodes out; back to back or with frame offsets):
+// 512-thread workgroups, two per CU — for calls whose streams fit half the CU's LDS together with their tables (max_frames up to
 // decode_staged_frames(ans): 830 DenseBoost frames, 876 express, 557 ultra, 339 ultra-dense).  *done stays false
 // otherwise and the plain kernel takes the call.  Measured and not instantiated
 // (profiles/r04/decode_staged_r04.txt): 1024-thread workgroups (one per CU), staging in windows
@@ -1752,7 +1799,9 @@ uint32_t decode_staged_frames(int ans) {
     default: return 0u;
   }
 }
+template <bool FRAMED>
 static hipError_t launch_decode_staged(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
+                                       const uint32_t *frame_off, const uint8_t *gap,
                                        const uint32_t *n_frames, uint32_t max_frames, uint32_t B,
                                        uint32_t sample_duration_us, const int32_t *state_in,
                                        int32_t *state_out, uint2 *nodes, uint32_t node_stride,
@@ -1769,7 +1818,7 @@ static hipError_t launch_decode_staged(hipStream_t s, int ans, const uint8_t *by
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(B), dim3(nt), lay.total, s, bytes, stream_stride,
-                       (const uint32_t *)nullptr, (const uint8_t *)nullptr, n_frames, max_frames,
+                       frame_off, gap, n_frames, max_frames,
                        sample_duration_us, state_in, state_out, nodes, node_stride, n_nodes, reset_at,
                        reset_stride, n_reset, n_errors, status, sync_at, sync_stride, n_sync, fz);
     *done = true;
@@ -1777,7 +1826,7 @@ static hipError_t launch_decode_staged(hipStream_t s, int ans, const uint8_t *by
   };
 #define RPL_STAGED(A)                                                                           \
   case A:                                                                                       \
-    return go(k_decode<A, false, false, true, 512>, 512u,                                       \
+    return go(k_decode<A, FRAMED, false, true, 512>, 512u,                                      \
               dec_stage_fits<A>(max_frames < DecCfg<A>::kMaxFrames ? max_frames : DecCfg<A>::kMaxFrames), \
               DecCfg<A>::kMaxFrames);
   switch (ans) {
@@ -1797,10 +1846,11 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
                          uint32_t node_stride, uint32_t *n_nodes, uint32_t *reset_at,
                          uint32_t reset_stride, uint32_t *n_reset, uint32_t *n_errors,
                          uint32_t *status, uint32_t *sync_at, uint32_t sync_stride,
-                         uint32_t *n_sync, const uint32_t *only, bool staged_ok) {
+                         uint32_t *n_sync, const uint32_t *only, bool staged_ok, uint32_t *stage_todo) {
   if (B == 0) return hipSuccess;
   DecFuse fz{};
   fz.only = only;
+  fz.stage_todo = stage_todo;
 #define RPL_LAUNCH_DEC3(A, F, Z)                                                                 \
   hipLaunchKernelGGL((k_decode<A, F, Z>), dim3(B), dim3(kDecBlock), 0, s, bytes, stream_stride, \
                      frame_off, gap, n_frames, max_frames, sample_duration_us, state_in,         \
@@ -1811,12 +1861,21 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
     if (frame_off) RPL_LAUNCH_DEC3(A, true, false); \
     else RPL_LAUNCH_DEC3(A, false, false);         \
   } while (0)
-  if (!frame_off && staged_ok) {
+  if (staged_ok && !frame_off) {
     bool done = false;
-    const hipError_t e = launch_decode_staged(s, ans, bytes, stream_stride, n_frames, max_frames, B,
-        sample_duration_us, state_in, state_out, (uint2 *)nodes, node_stride, n_nodes, reset_at,
-        reset_stride, n_reset, n_errors, status, sync_at, sync_stride, n_sync, fz, &done);
+    const hipError_t e = launch_decode_staged<false>(s, ans, bytes, stream_stride, nullptr, nullptr, n_frames,
+        max_frames, B, sample_duration_us, state_in, state_out, (uint2 *)nodes, node_stride, n_nodes,
+        reset_at, reset_stride, n_reset, n_errors, status, sync_at, sync_stride, n_sync, fz, &done);
     if (done) return e;
+  } else if (staged_ok && stage_todo) {
+    // frame offsets given: the staged kernel takes every stream whose frames lie the way it needs
+    // them and lists the others in stage_todo; the plain kernel below then runs over that list
+    bool done = false;
+    const hipError_t e = launch_decode_staged<true>(s, ans, bytes, stream_stride, frame_off, gap, n_frames,
+        max_frames, B, sample_duration_us, state_in, state_out, (uint2 *)nodes, node_stride, n_nodes,
+        reset_at, reset_stride, n_reset, n_errors, status, sync_at, sync_stride, n_sync, fz, &done);
+    if (e != hipSuccess) return e;
+    if (done) fz.only = stage_todo;  // (0 where `only` was 0: those streams were someone else's)
   }
   switch (ans) {
     case RPLGPU_ANS_MEASUREMENT: RPL_LAUNCH_DEC(RPLGPU_ANS_MEASUREMENT); break;

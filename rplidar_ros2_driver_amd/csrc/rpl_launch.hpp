@@ -120,8 +120,9 @@ hipError_t launch_decode(hipStream_t s, int ans, const uint8_t *bytes, uint64_t 
                          uint32_t reset_stride, uint32_t *n_reset, uint32_t *n_errors,
                          uint32_t *status, uint32_t *sync_at = nullptr, uint32_t sync_stride = 0,
                          uint32_t *n_sync = nullptr, const uint32_t *only = nullptr,
-                         // back-to-back capsule streams that fit: the LDS-staged instance (rpl_decode.hip)
-                         bool staged_ok = true);
+                         // capsule streams that fit: the LDS-staged instance (rpl_decode.hip); with frame
+                         // offsets it needs B words of scratch for the streams it leaves to the plain kernel
+                         bool staged_ok = true, uint32_t *stage_todo = nullptr);
 bool decode_fusable(int ans);
 hipError_t launch_decode_fused(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
                                const uint32_t *frame_off, const uint8_t *gap,

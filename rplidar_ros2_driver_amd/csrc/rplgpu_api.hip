@@ -84,6 +84,8 @@ struct rplgpu_ctx {
   size_t dec_cap = 0;
   unsigned char *d_scans = nullptr;   // rplgpu_decode_scans_dev scratch (node streams, sync lists)
   size_t scans_cap = 0;
+  uint32_t *d_dec_todo = nullptr;     // rplgpu_decode_batch_dev with frame offsets: streams the staged decoder leaves to the plain one
+  size_t dec_todo_cap = 0;            // (words)
   bool check_ptrs = true;             // batch entry points verify that buffers are device memory
   // multi-GPU exchange (include/rplgpu_comm.h)
   void *comm = nullptr;               // ncclComm_t
@@ -293,6 +295,7 @@ void free_ctx(rplgpu_ctx *c) {
   if (c->d_need_sort) (void)hipFree(c->d_need_sort);
   if (c->d_dec) (void)hipFree(c->d_dec);
   if (c->d_scans) (void)hipFree(c->d_scans);
+  if (c->d_dec_todo) (void)hipFree(c->d_dec_todo);
   if (c->d_vstore) (void)hipFree(c->d_vstore);
   if (c->d_regions) (void)hipFree(c->d_regions);
   if (c->d_rcount) (void)hipFree(c->d_rcount);
@@ -1169,11 +1172,23 @@ int32_t rplgpu_decode_batch_dev(rplgpu_handle_t h, uint8_t ans_type, uint32_t sa
   if (B && (!device_readable(h, d_bytes, "d_bytes") || !device_readable(h, d_n_frames, "d_n_frames") ||
             (d_frame_off && !device_readable(h, d_frame_off, "d_frame_off"))))
     return RPLGPU_ERR_INVALID_ARG;
+  uint32_t *stage_todo = nullptr;
+  if (d_frame_off && h->dec_stage && max_frames <= rpl::decode_staged_frames(ans_type)) {
+    if (h->dec_todo_cap < B) {  // (grows when a larger call arrives, never shrinks)
+      RPL_HIP(h, hipStreamSynchronize(h->stream));
+      if (h->d_dec_todo) (void)hipFree(h->d_dec_todo);
+      h->d_dec_todo = nullptr;
+      h->dec_todo_cap = 0;
+      RPL_HIP(h, hipMalloc((void **)&h->d_dec_todo, (size_t)B * sizeof(uint32_t)));
+      h->dec_todo_cap = B;
+    }
+    stage_todo = h->d_dec_todo;
+  }
   RPL_HIP(h, rpl::launch_decode(h->stream, ans_type, d_bytes, stream_stride, d_frame_off, d_gap,
                                 d_n_frames, max_frames, B, sample_duration_us, d_state_in,
                                 d_state_out, d_nodes, node_stride, d_n_nodes, d_reset_at,
                                 reset_stride, d_n_reset, d_n_errors, d_status, nullptr, 0, nullptr,
-                                nullptr, h->dec_stage));
+                                nullptr, h->dec_stage, stage_todo));
   return RPLGPU_OK;
 }
 
@@ -1223,7 +1238,7 @@ static int32_t decode_scans_impl(rplgpu_handle_t h, uint8_t ans_type, uint32_t s
   auto up256 = [](size_t v) { return (v + 255) & ~size_t(255); };
   const size_t sz_nodes = up256((size_t)B * node_stride * 8), sz_sync = up256((size_t)B * sync_stride * 4);
   const size_t sz_rst = up256((size_t)B * reset_stride * 4), sz_cnt = up256((size_t)B * 4);
-  const size_t need = sz_nodes + sz_sync + sz_rst + 4 * sz_cnt;
+  const size_t need = sz_nodes + sz_sync + sz_rst + 5 * sz_cnt;
   if (h->scans_cap < need) {
     RPL_HIP(h, hipStreamSynchronize(h->stream));
     if (h->d_scans) (void)hipFree(h->d_scans);
@@ -1238,6 +1253,7 @@ static int32_t decode_scans_impl(rplgpu_handle_t h, uint8_t ans_type, uint32_t s
   uint32_t *t_rst = reinterpret_cast<uint32_t *>(p + sz_nodes + sz_sync);
   uint32_t *t_nn = reinterpret_cast<uint32_t *>(p + sz_nodes + sz_sync + sz_rst);
   uint32_t *t_nr = t_nn + sz_cnt / 4, *t_ns = t_nr + sz_cnt / 4, *t_todo = t_ns + sz_cnt / 4;
+  uint32_t *t_stage_todo = t_todo + sz_cnt / 4;  // (the staged decoder's own list, see launch_decode)
   // express / ultra / dense: the fused decoder knows the scan boundaries from the capsule headers
   // and writes the nodes of completed scans straight into their batch slots; a stream with more
   // sync nodes / reset requests than its tables hold raises t_todo[b] and takes the general path
@@ -1255,7 +1271,8 @@ static int32_t decode_scans_impl(rplgpu_handle_t h, uint8_t ans_type, uint32_t s
   RPL_HIP(h, rpl::launch_decode(h->stream, ans_type, d_bytes, stream_stride, d_frame_off, d_gap,
                                 d_n_frames, max_frames, B, sample_duration_us, d_state_in,
                                 d_state_out, t_nodes, node_stride, t_nn, t_rst, reset_stride, t_nr,
-                                d_n_errors, d_status, t_sync, sync_stride, t_ns, only, h->dec_stage));
+                                d_n_errors, d_status, t_sync, sync_stride, t_ns, only, h->dec_stage,
+                                d_frame_off ? t_stage_todo : nullptr));
   RPL_HIP(h, rpl::launch_assemble(h->stream, t_nodes, node_stride, t_nn, t_sync, sync_stride, t_ns,
                                   t_rst, reset_stride, t_nr, B, max_count, d_batch, n_stride,
                                   scan_cap, d_n_per_scan, d_n_scans, d_status, only, d_carry_in,

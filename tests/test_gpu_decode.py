@@ -780,3 +780,93 @@ def test_staged_decoder_matches_plain_and_oracle(gpu, gpu_plain_decoder, oracle,
         assert nodes.tobytes() == want.tobytes(), (hex(ans), where, b)
         assert list(got["rst"][b, : got["nr"][b]]) == list(w_rst) and int(got["ne"][b]) == w_err
         assert tuple(int(v) for v in got["sout"][b, :2]) == w_st
+
+
+@pytest.mark.parametrize("ans", [0x82, 0x84, 0x85, 0x86])
+def test_staged_decoder_with_frame_offsets(gpu, gpu_plain_decoder, oracle, ans):
+    """The same with frame offsets and gap flags (rplgpu_frame_stream's output): the staged kernel
+    copies [first frame, end of last frame) and takes a stream only when every frame lies inside
+    that copy at most 16383 rejected bytes behind its back-to-back place; the others (a huge hole,
+    a span longer than the LDS the call reserved, offsets that go backwards) are listed for the
+    plain kernel.  Either way: the plain kernel's and the oracle's nodes, counts and state."""
+    torch = _torch()
+    dev = torch.device("cuda:0")
+    lib = abi.load_library()
+    S, npf = cp.FRAME_SIZE[ans], cp.NODES_PER_FRAME[ans]
+    lim = int(lib.rplgpu_decode_staged_frames(ans))
+    max_frames = min(lim, 300)
+    rng = np.random.default_rng(ans * 977 + 5)
+    B = 14
+    nfs = rng.integers(3, max_frames + 1, B).astype(np.int32)
+    nfs[:4] = (0, 1, 2, max_frames)
+    offs = np.zeros((B, max_frames), np.uint32)
+    gaps = np.zeros((B, max_frames), np.uint8)
+    blobs = []
+    for b in range(B):
+        nf = int(nfs[b])
+        fr = cp.make_frames(ans, nf, 4000 + 13 * b, payload=("random", "ring", "ring_noisy")[b % 3],
+                            frames_per_rev=float(rng.uniform(7.0, 40.0)))
+        if b % 4 == 1 and nf > 4:
+            for k in rng.integers(1, nf, 1 + nf // 30):
+                fr[int(k), int(rng.integers(4, S))] ^= 0x3C
+        # rejected bytes in front of some frames (flagged as gaps, as the framer would)
+        junk = np.where(rng.random(nf) < 0.15, rng.integers(1, 40, nf), 0).astype(np.int64)
+        if nf:
+            junk[0] = int(rng.integers(0, 7))
+        if b == 5 and nf > 10:
+            junk[7] = 20000        # a hole the table entry cannot hold: plain kernel
+        if b == 6 and nf > 10:
+            junk[3:] += 400        # span beyond the reserved LDS for a long stream: plain kernel (or fits: fine)
+        pos = np.cumsum(junk + S) - S
+        if b == 7 and nf > 10:     # offsets that go backwards: plain kernel
+            pos[[4, 5]] = pos[[5, 4]]
+        blob = np.zeros(int(pos.max() + S) if nf else 1, np.uint8)
+        blob[:] = rng.integers(0, 256, len(blob), dtype=np.uint8)
+        for k in range(nf):
+            blob[pos[k]: pos[k] + S] = fr[k]
+        offs[b, :nf] = pos
+        gaps[b, :nf] = (junk > 0) & (np.arange(nf) > 0)
+        blobs.append(blob)
+    stride = max(len(x) for x in blobs) + 3
+    buf = np.zeros((B, stride), np.uint8)
+    for b, x in enumerate(blobs):
+        buf[b, : len(x)] = x
+    state_in = np.zeros((B, 4), np.int32)
+    state_in[:, 0] = rng.integers(0, 2, B)
+    state_in[:, 1] = rng.integers(0, 4000, B) * 4
+    d_bytes, d_nf = torch.from_numpy(buf).to(dev), torch.from_numpy(nfs).to(dev)
+    d_off, d_gap = torch.from_numpy(offs).to(dev), torch.from_numpy(gaps).to(dev)
+    d_sin = torch.from_numpy(state_in).to(dev)
+    node_stride = max_frames * npf
+
+    def run(h):
+        o = {k: torch.full(shape, 0x55, dtype=dt, device=dev) for k, shape, dt in (
+            ("nodes", (B, node_stride * 8), torch.uint8), ("nn", (B,), torch.int32),
+            ("rst", (B, 32), torch.int32), ("nr", (B,), torch.int32), ("ne", (B,), torch.int32),
+            ("st", (B,), torch.int32), ("sout", (B, 4), torch.int32))}
+        o["nodes"].zero_()
+        h.decode_batch_dev(ans, 125, d_bytes.data_ptr(), stride, d_off.data_ptr(), d_gap.data_ptr(),
+                           d_nf.data_ptr(), max_frames, B, d_sin.data_ptr(), o["sout"].data_ptr(),
+                           o["nodes"].data_ptr(), node_stride, o["nn"].data_ptr(), o["rst"].data_ptr(), 32,
+                           o["nr"].data_ptr(), o["ne"].data_ptr(), o["st"].data_ptr())
+        h.synchronize()
+        return {k: v.cpu().numpy() for k, v in o.items()}
+
+    got, ref = run(gpu), run(gpu_plain_decoder)
+    for b in range(B):
+        n = int(ref["nn"][b])
+        assert int(got["nn"][b]) == n and got["st"][b] == ref["st"][b], (hex(ans), b)
+        assert got["nodes"][b, : n * 8].tobytes() == ref["nodes"][b, : n * 8].tobytes(), (hex(ans), b)
+        assert got["nr"][b] == ref["nr"][b] and got["ne"][b] == ref["ne"][b], (hex(ans), b)
+        k = min(int(ref["nr"][b]), 32)
+        assert list(got["rst"][b, :k]) == list(ref["rst"][b, :k]), (hex(ans), b)
+        assert list(got["sout"][b]) == list(ref["sout"][b]), (hex(ans), b)
+        if b == 7:
+            continue  # (offsets out of order: the oracle walks them in the order given too, but keep it simple)
+        nf = int(nfs[b])
+        want, w_rst, w_err, w_st = oracle.unpack_frames(ans, buf[b], offs[b, :nf], gaps[b, :nf], 125,
+                                                        state=(int(state_in[b, 0]), int(state_in[b, 1])))
+        assert n == len(want), (hex(ans), b)
+        assert got["nodes"][b].view(NODE_DTYPE)[:n].tobytes() == want.tobytes(), (hex(ans), b)
+        assert list(got["rst"][b, : got["nr"][b]]) == list(w_rst) and int(got["ne"][b]) == w_err
+        assert tuple(int(v) for v in got["sout"][b, :2]) == w_st

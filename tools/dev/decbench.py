@@ -25,8 +25,13 @@ for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334)
     RS = 16 if os.environ.get('DEC_DBG') else 8
     d_rst = torch.zeros(B, RS, dtype=torch.int32, device=dev)
     d_nr = torch.zeros(B, dtype=torch.int32, device=dev)
+    FRAMED = os.environ.get('DEC_FRAMED')  # the same frames, their offsets (k * S) and zero gap flags given
+    if FRAMED:
+        d_off = (torch.arange(nf, dtype=torch.int32, device=dev) * S).repeat(B, 1).contiguous()
+        d_gap = torch.zeros(B, nf, dtype=torch.uint8, device=dev)
     def run():
-        gpu.decode_batch_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0,
+        gpu.decode_batch_dev(ans, 125, buf.data_ptr(), nf * S, d_off.data_ptr() if FRAMED else 0,
+                             d_gap.data_ptr() if FRAMED else 0, d_nf.data_ptr(), nf, B, 0, 0,
                              d_nodes.data_ptr(), node_stride, d_nn.data_ptr(), d_rst.data_ptr(), RS, d_nr.data_ptr())
     PIECES = int(os.environ.get('DEC_PIECES', '0'))
     if PIECES > 1:
