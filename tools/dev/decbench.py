@@ -74,7 +74,8 @@ for ans, nf in ((0x85, 801), (0x82, 1001), (0x84, 334), (0x86, 501), (0x83, 334)
         d_ns2 = torch.zeros(B, dtype=torch.int32, device=dev)
         d_st2 = torch.zeros(B, dtype=torch.int32, device=dev)
         def fused():
-            gpu.decode_scans_dev(ans, 125, buf.data_ptr(), nf * S, 0, 0, d_nf.data_ptr(), nf, B, 0, 0, 32768,
+            gpu.decode_scans_dev(ans, 125, buf.data_ptr(), nf * S, d_off.data_ptr() if FRAMED else 0,
+                                 d_gap.data_ptr() if FRAMED else 0, d_nf.data_ptr(), nf, B, 0, 0, 32768,
                                  d_batch.data_ptr(), n_stride, scan_cap, d_len.data_ptr(), d_ns2.data_ptr(), 0, d_st2.data_ptr())
         fused(); torch.cuda.synchronize(); ts = []
         for _ in range(5):
