@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NT) void k_decode(
   // wait that queue out once per trip.  Here the stream crosses it ONCE, as one burst of 16-byte
   // loads issued before this workgroup has stored anything, and both passes read LDS.
   extern __shared__ uint4 dec_stage[];
-  static_assert(!STG || (CAPS && !FUSE), "STG: capsule streams, nodes out");
+  static_assert(!STG || (CAPS && (!FUSE || FRAMED)), "STG: capsule streams; the fused form only with frame offsets");
   static_assert(ANS != RPLGPU_ANS_HQ || NT == 256, "HQ: one CRC table entry per thread");
   const DecStageLayout lay = dec_stage_layout(ANS, STG ? min(max_frames, DecCfg<ANS>::kMaxFrames) : 0u);
   uint8_t *dyn = reinterpret_cast<uint8_t *>(dec_stage);
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NT) void k_decode(
     stage_lo = foff[0];
     stage_hi = foff[nf - 1u] + S;
     if (stage_hi < stage_lo + nf * S || stage_hi - stage_lo > lay.raw_at - 16u) {  // (block-uniform)
-      if (tid == 0) fz.stage_todo[b] = 1u;
+      if (tid == 0) (FUSE ? fz.todo : fz.stage_todo)[b] = 1u;  // (FUSE: the general path takes the stream)
       return;
     }
   }
@@ -564,7 +564,10 @@ __global__ __launch_bounds__(NT) void k_decode(
   __syncthreads();
   if (STG && FRAMED) {
     const bool misplaced = L.misc[1] != 0u;  // (block-uniform; nothing has left the workgroup yet)
-    if (tid == 0) fz.stage_todo[b] = misplaced ? 1u : 0u;
+    if (tid == 0) {
+      if (!FUSE) fz.stage_todo[b] = misplaced ? 1u : 0u;
+      else if (misplaced) fz.todo[b] = 1u;  // (0 is written further down, once the scans are judged)
+    }
     if (misplaced) return;
   }
   const bool bad_framing = (L.misc[0] & RPLGPU_STREAM_UNFRAMED) != 0u;
@@ -1799,7 +1802,7 @@ uint32_t decode_staged_frames(int ans) {
     default: return 0u;
   }
 }
-template <bool FRAMED>
+template <bool FRAMED, bool FUSE = false>
 static hipError_t launch_decode_staged(hipStream_t s, int ans, const uint8_t *bytes, uint64_t stream_stride,
                                        const uint32_t *frame_off, const uint8_t *gap,
                                        const uint32_t *n_frames, uint32_t max_frames, uint32_t B,
@@ -1826,7 +1829,7 @@ static hipError_t launch_decode_staged(hipStream_t s, int ans, const uint8_t *by
   };
 #define RPL_STAGED(A)                                                                           \
   case A:                                                                                       \
-    return go(k_decode<A, FRAMED, false, true, 512>, 512u,                                      \
+    return go(k_decode<A, FRAMED, FUSE, true, 512>, 512u,                                       \
               dec_stage_fits<A>(max_frames < DecCfg<A>::kMaxFrames ? max_frames : DecCfg<A>::kMaxFrames), \
               DecCfg<A>::kMaxFrames);
   switch (ans) {
@@ -1904,7 +1907,7 @@ hipError_t launch_decode_fused(hipStream_t s, int ans, const uint8_t *bytes, uin
                                int32_t *state_out, uint32_t *n_errors, uint32_t *status,
                                uint32_t max_count, void *batch, uint32_t n_stride,
                                uint32_t scan_cap, uint32_t *n_per_scan, uint32_t *n_scans,
-                               uint32_t *todo) {
+                               uint32_t *todo, bool staged_ok) {
   if (B == 0) return hipSuccess;
   DecFuse fz{};
   fz.batch = (uint2 *)batch;
@@ -1917,6 +1920,16 @@ hipError_t launch_decode_fused(hipStream_t s, int ans, const uint8_t *bytes, uin
   uint2 *nodes = nullptr;
   const uint32_t node_stride = 0xFFFFFFFFu, reset_stride = 0, sync_stride = 0;
   uint32_t *n_nodes = nullptr, *reset_at = nullptr, *n_reset = nullptr, *sync_at = nullptr, *n_sync = nullptr;
+  if (frame_off && staged_ok) {
+    // with frame offsets the staged form wins (the plain kernel's per-group offset loads queue
+    // behind the node stores: 0.33 against 0.24 ms without offsets); a stream whose frames do
+    // not lie the way it needs them raises todo[b] like one with too many sync nodes
+    bool done = false;
+    const hipError_t e = launch_decode_staged<true, true>(s, ans, bytes, stream_stride, frame_off, gap,
+        n_frames, max_frames, B, sample_duration_us, state_in, state_out, nodes, node_stride, n_nodes,
+        reset_at, reset_stride, n_reset, n_errors, status, sync_at, sync_stride, n_sync, fz, &done);
+    if (done || e != hipSuccess) return e;
+  }
 #define RPL_LAUNCH_FUSED(A)                         \
   do {                                              \
     if (frame_off) RPL_LAUNCH_DEC3(A, true, true);  \

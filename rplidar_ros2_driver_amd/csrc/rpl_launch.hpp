@@ -131,7 +131,7 @@ hipError_t launch_decode_fused(hipStream_t s, int ans, const uint8_t *bytes, uin
                                int32_t *state_out, uint32_t *n_errors, uint32_t *status,
                                uint32_t max_count, void *batch, uint32_t n_stride,
                                uint32_t scan_cap, uint32_t *n_per_scan, uint32_t *n_scans,
-                               uint32_t *todo);
+                               uint32_t *todo, bool staged_ok = true);
 hipError_t launch_segment(hipStream_t s, const void *nodes, uint32_t node_stride,
                           const uint32_t *n_nodes, const uint32_t *reset_at, uint32_t reset_stride,
                           const uint32_t *n_reset, uint32_t B, uint32_t max_count, void *out_nodes,

@@ -1265,7 +1265,8 @@ static int32_t decode_scans_impl(rplgpu_handle_t h, uint8_t ans_type, uint32_t s
     RPL_HIP(h, rpl::launch_decode_fused(h->stream, ans_type, d_bytes, stream_stride, d_frame_off,
                                         d_gap, d_n_frames, max_frames, B, sample_duration_us,
                                         d_state_in, d_state_out, d_n_errors, d_status, max_count,
-                                        d_batch, n_stride, scan_cap, d_n_per_scan, d_n_scans, t_todo));
+                                        d_batch, n_stride, scan_cap, d_n_per_scan, d_n_scans, t_todo,
+                                        h->dec_stage));
     only = t_todo;
   }
   RPL_HIP(h, rpl::launch_decode(h->stream, ans_type, d_bytes, stream_stride, d_frame_off, d_gap,
