@@ -127,6 +127,12 @@ UNPACK_CASES = [  # (answer type, frames, seed, corrupt, payload, frames_per_rev
     (0x85, 48, 3, False, "random", 300.0, 2, 0),
     (0x86, 40, 1, False, "ring", 12.3, 125, 170),
     (0x86, 40, 2, True, "random", 7.7, 20, 13),
+    # round 4: ultra-dense streams on which the distance smoothing really acts (a target inside scale 0,
+    # distances that vary; "ring" is a constant for this type) — pins the smoothing of the restatement
+    # and of the kernels against the genuine unpacker on chains of every length
+    (0x86, 120, 3, False, "ring_near", 12.3, 125, 170),
+    (0x86, 120, 4, False, "ring_noisy", 9.1, 125, 57),
+    (0x86, 90, 5, True, "ring_near", 21.0, 125, 170),
 ]
 
 
