@@ -55,15 +55,20 @@ namespace rpl {
 #ifndef RPL_VOXEL_THREADS
 #define RPL_VOXEL_THREADS 1024
 #endif
+#ifndef RPL_VOXEL_WGS_PER_CU  // resident workgroups per compute unit the LDS layout is sized for
+#define RPL_VOXEL_WGS_PER_CU (RPL_VOXEL_THREADS == 512 ? 2 : 1)
+#endif
 constexpr int kVB = RPL_VOXEL_THREADS;                   // threads of a voxel workgroup
 constexpr int kVW = kVB / 64;                            // its waves
-constexpr uint32_t kRecCap = kVB == 512 ? 4096u : 7168u;  // run records the LDS queue holds
-constexpr uint32_t kRecPerThread = kRecCap / kVB;        // 8
-constexpr uint32_t kRowCap = 2u * kVB;                   // rows the counting sort of a band handles
+constexpr int kVWG = RPL_VOXEL_WGS_PER_CU;               // workgroups per compute unit
+constexpr uint32_t kRecCap = kVWG == 2 ? 4096u : 7168u;  // run records the LDS queue holds
+constexpr uint32_t kRecPerThread = kRecCap / kVB;        // 7 (one workgroup per CU), 8 or 4
+constexpr uint32_t kRowCap = kVWG == 2 ? 1024u : 2u * kVB;  // rows the counting sort of a band handles
+constexpr uint32_t kRowsPerThread = kRowCap / kVB;       // rows a thread scans: 2, or 1 (1024 threads x 2)
 constexpr uint32_t kBucketCap = kRecCap + 3u * kRowCap;  // row lists padded to multiples of 4
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
 constexpr float kKeyMagic = 8421376.0f;                  // 2^23 + 32768
-static_assert(kRowCap == 2u * kVB, "the row scan handles two rows per thread");
+static_assert(kRowsPerThread == 1u || kRowsPerThread == 2u, "the row scan handles one or two rows per thread");
 static_assert(kBucketCap * 4u <= kRecCap * 16u, "the row lists live inside the record array");
 static_assert(kRecCap * 2u <= 2u * kRowCap * 4u, "the cell-head list (u16) lives in the row arrays");
 
@@ -109,7 +114,7 @@ struct VoxelLds {
   uint32_t tmp[32];
   double rcp[256];  // RN(1/count) for count < 256 (copied once per workgroup from the host table)
 };
-static_assert(kVB != 512 || sizeof(VoxelLds) <= 80u * 1024u, "two workgroups per compute unit");
+static_assert(kVWG != 2 || sizeof(VoxelLds) <= 80u * 1024u, "two workgroups per compute unit");
 
 // Exclusive scan of one value per thread over the kVB threads.  `tmp` = kVW + 1 words of LDS.
 __device__ __forceinline__ uint32_t vx_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
@@ -568,16 +573,18 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
        // sums in one word: compact positions (low half) and positions with every row padded
        // to a multiple of four entries (high half: the rank step reads whole 16-byte blocks
        // and needs no position masks)
-      const uint32_t p0 = (2u * threadIdx.x + rmin) & (kRowCap - 1u);
-      const uint32_t p1 = (2u * threadIdx.x + 1u + rmin) & (kRowCap - 1u);
-      const uint32_t r0 = rowstart[p0], r1 = rowstart[p1];
+      const uint32_t p0 = (kRowsPerThread * threadIdx.x + rmin) & (kRowCap - 1u);
+      const uint32_t p1 = (kRowsPerThread * threadIdx.x + 1u + rmin) & (kRowCap - 1u);
+      const uint32_t r0 = rowstart[p0], r1 = kRowsPerThread == 2u ? rowstart[p1] : 0u;
       const uint32_t w0 = r0 | (((r0 + 3u) & ~3u) << 16), w1 = r1 | (((r1 + 3u) & ~3u) << 16);
       uint32_t tot;
       const uint32_t ex = vx_excl_scan(w0 + w1, L.tmp, &tot);
       rowstart[p0] = ex;
-      rowstart[p1] = ex + w0;
       rowfill[p0] = ex >> 16;
-      rowfill[p1] = (ex + w0) >> 16;
+      if (kRowsPerThread == 2u) {
+        rowstart[p1] = ex + w0;
+        rowfill[p1] = (ex + w0) >> 16;
+      }
       pad_total = tot >> 16;
       nreal = tot & 0xFFFFu;  // records of the band (the queue entries minus the markers)
     }
@@ -1193,7 +1200,7 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
 // launch (T.voxel_stats), so a clean batch runs code without a trace of that path.
 // ------------------------------------------------------------------------------
 template <bool FAST_DIV, bool SAFE, bool DBG, bool SPLIT>
-__global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_cloud_voxel(
+__global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(kVB * kVWG / 256, kVB * kVWG / 256))) void k_cloud_voxel(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
     float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
@@ -1227,9 +1234,28 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
       const ScanSide sd = scan_side(sc, keepmask, mask_stride, motion, pose2d);
       const uint32_t blk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
+#ifdef RPL_VOXEL_PRIO_STAGGER  // (developer experiment: the waves of a SIMD at different priorities)
+      {
+        const uint32_t pr = (blk0 >> 2) & 3u;
+        if (pr == 1u) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2u) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3u) __builtin_amdgcn_s_setprio(3);
+      }
+#endif
+#ifdef RPL_VOXEL_SLEEP_STAGGER  // (developer experiment: the waves of a SIMD start a fraction of a trip apart)
+      {
+        const uint32_t pr = (blk0 >> 2) & 3u;
+        if (pr == 1u) __builtin_amdgcn_s_sleep(RPL_VOXEL_SLEEP_STAGGER);
+        else if (pr == 2u) __builtin_amdgcn_s_sleep(2 * RPL_VOXEL_SLEEP_STAGGER);
+        else if (pr == 3u) __builtin_amdgcn_s_sleep(3 * RPL_VOXEL_SLEEP_STAGGER);
+      }
+#endif
       voxel_stream_dispatch<FAST_DIV, SAFE, SPLIT, DBG, kVW, RPL_VOXEL_AHEAD>(
           sink, p, cs, scan_rsrc, blk0, (n + 127u) >> 7, sd, mask_stride, use_xf, q_min16, ibfe_off,
           ibfe_w, flags, (DBG && p.dbg) ? p.dbg + 16 * b : nullptr);
+#ifdef RPL_VOXEL_PRIO_STAGGER
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
   };
   voxel_work_loop<DBG>(L, p, T, G, xyzi, out_stride, n_points, status, B, 0u, arena, phase_s);
@@ -1505,7 +1531,7 @@ hipError_t launch_validate_div(hipStream_t s, float d, float rd, uint32_t e_lo, 
   return hipGetLastError();
 }
 
-uint32_t voxel_max_workgroups(uint32_t n_cu) { return (kVB == 512 ? 2u : 1u) * (n_cu ? n_cu : 256u); }
+uint32_t voxel_max_workgroups(uint32_t n_cu) { return (uint32_t)kVWG * (n_cu ? n_cu : 256u); }
 
 uint32_t voxel_regions_per_item(uint32_t group, uint32_t n_stride) {
   const uint32_t s = n_stride < kMaxN ? n_stride : kMaxN;
@@ -1571,7 +1597,7 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
     if (T.voxel_pipe) stage = std::min<uint32_t>(stage, T.voxel_pipe_items);
     if (T.voxel_two_kernel < 2 && (uint64_t)stage * qn < 4096u) stage = 0;  // too few waves per stage
   }
-  if (kVB == 512 && group > 1 && !stage) return hipErrorInvalidValue;  // (fused groups: 16-wave geometry only)
+  if (kVWG == 2 && group > 1 && !stage) return hipErrorInvalidValue;  // (fused groups: 16-wave geometry only)
   // persistent workgroups of the handle's device (no more than the handle owns record stores
   // for); the item queue is cleared by a memset ahead of every launch (an aborted launch can
   // therefore not poison the next one)

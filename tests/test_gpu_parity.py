@@ -747,3 +747,42 @@ def test_mode_a_tie_rule(gpu, oracle):
             want_i[hit] = (best[hit] & 0xFF).astype(np.float32)
             assert np.array_equal(np.isfinite(gr), hit)
             assert gi.tobytes() == want_i.tobytes()
+
+
+# ----------------------------------------------------- a-ext against the SECOND writer's vectors
+def _ext_gold():
+    from tests.golden.make_ext_golden import EXT_PARAM_SETS, FULL_MAX_POINTS
+    gold = np.load(oracle_lib.ROOT / "tests" / "golden" / "ext_golden.npz")
+    return gold, EXT_PARAM_SETS, FULL_MAX_POINTS
+
+
+@pytest.mark.parametrize("tag", ["cloud", "cloud_inv_new", "cloud_q48", "voxel", "voxel_inv",
+                                 "voxel_leaf10_q48", "ror_voxel", "ror_cloud"])
+def test_hip_path_matches_second_writer_golden(gpu, tag):
+    """The extension kernels (E1 / E2 / E4 / E5) against tests/golden/ext_golden.npz: the committed
+    outputs of oracle/ext_second_writer.py, an independent numpy / scipy writer of SURVEY.md
+    §8(a-ext) — vectors that neither the kernels' author's C++ oracle nor the kernels produced.
+    Small cases are compared point by point (count, intensity bits, x / y within 1e-6 m; the
+    unvoxelised cloud bit for bit), every case by its point count."""
+    gold, sets, full_max = _ext_gold()
+    kw = dict(sets)[tag]
+    p = Params.defaults(**{k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()})
+    checked = 0
+    for name, nodes in CASES.items():
+        key = f"{name}__{tag}"
+        if key + "__n" not in gold:
+            continue  # (ROR on the largest cases is not in the file)
+        got, status = gpu.scan_to_cloud(nodes, p)
+        assert status == 0, key
+        assert len(got) == int(gold[key + "__n"]), key
+        if key + "__pts" not in gold:
+            continue
+        want = gold[key + "__pts"]
+        assert got[:, 3].tobytes() == want[:, 3].tobytes(), key
+        assert np.all(got[:, 2] == 0), key
+        if len(want):
+            assert np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2])) <= XYZ_TOL, key
+        if not kw.get("voxel_enable"):
+            assert got.tobytes() == want.tobytes(), key
+        checked += 1
+    assert checked >= 20

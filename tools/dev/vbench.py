@@ -18,6 +18,8 @@ kind = sys.argv[4] if len(sys.argv) > 4 else "ring"
 n = 32000
 dev = torch.device("cuda:0")
 kw = {"kind": kind} if kind != "ring" else ({"noise_m": noise} if noise else {})
+if os.environ.get("VB_R0MAX"):
+    kw["r0_range"] = (1.0, float(os.environ["VB_R0MAX"]))
 batch = synth.make_batch(2026, B, n, **kw)
 d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
 d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
