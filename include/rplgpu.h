@@ -149,6 +149,23 @@ int32_t rplgpu_laserscan_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nod
                                    uint32_t n_stride, const uint32_t *d_n_per_scan, uint32_t B,
                                    const rplgpu_params_t *p, float *d_ranges,
                                    float *d_intensities, uint32_t *d_beam_count);
+/* == S1 -> S3 as the node runs them: RealLidarDriver::grab_scan_data with
+ * apply_geometric_correction (src/lidar_driver_wrapper.cpp:328-337: ascendScanData in place, result
+ * ignored, nodes copied to the caller) followed by RPlidarNode::publish_scan on those nodes
+ * (src/rplidar_node.cpp:568-680), for a batch, in ONE pass over the raw nodes.  publish_scan drops
+ * every node with dist_mm_q2 == 0 (:584) — the only nodes whose angle ascendScanData rewrites
+ * (src/sdk/src/sl_lidar_driver.cpp:171-178) — and sorts what is left by angle itself (:607-609), so
+ * the LaserScan of the ascended scan IS the LaserScan of the raw scan (this library's order inside
+ * a run of equal angles is the input order before and after the ascend step, which is a stable
+ * sort): d_ranges / d_intensities / d_beam_count as rplgpu_laserscan_batch_dev.  write_ascended != 0
+ * also leaves the ascended nodes in d_nodes (what the caller's vector holds after grab_scan_data)
+ * and the per-scan ascend status in d_status (RPLGPU_SCAN_ALL_INVALID = SL_RESULT_OPERATION_FAIL,
+ * buffer untouched); with write_ascended == 0 d_nodes is only read and d_status is not written. */
+int32_t rplgpu_ascend_laserscan_batch_dev(rplgpu_handle_t h, rplgpu_node_t *d_nodes,
+                                          uint32_t n_stride, const uint32_t *d_n_per_scan,
+                                          uint32_t B, const rplgpu_params_t *p, float *d_ranges,
+                                          float *d_intensities, uint32_t *d_beam_count,
+                                          int32_t write_ascended, uint32_t *d_status);
 /* d_xyzi: B*out_stride points of 4 floats; d_n_points, d_status: B. */
 int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
                                const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,

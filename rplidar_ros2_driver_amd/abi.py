@@ -50,6 +50,7 @@ ABI_SYMBOLS = [
     "rplgpu_scan_to_cloud",
     "rplgpu_ascend_batch_dev",
     "rplgpu_laserscan_batch_dev",
+    "rplgpu_ascend_laserscan_batch_dev",
     "rplgpu_cloud_batch_dev",
     "rplgpu_pack_clouds_dev",
     "rplgpu_cloud_arena_dev",
@@ -216,6 +217,8 @@ def load_library() -> C.CDLL:
         vp, vp, sz, C.POINTER(Params), vp, C.POINTER(u32), C.POINTER(u32)]
     lib.rplgpu_ascend_batch_dev.argtypes = [vp, vp, u32, vp, u32, vp]
     lib.rplgpu_laserscan_batch_dev.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), vp, vp, vp]
+    lib.rplgpu_ascend_laserscan_batch_dev.argtypes = [vp, vp, u32, vp, u32, C.POINTER(Params), vp, vp,
+                                                      vp, C.c_int32, vp]
     lib.rplgpu_cloud_batch_dev.argtypes = [
         vp, vp, u32, vp, u32, C.POINTER(Params), vp, u32, vp, vp]
     lib.rplgpu_pack_clouds_dev.argtypes = [vp, vp, u32, vp, u32, vp, vp]
@@ -390,6 +393,14 @@ class RplGpu:
         self._check(self._lib.rplgpu_laserscan_batch_dev(
             self._h, d_nodes, n_stride, d_n_per_scan, B, C.byref(params),
             d_ranges, d_intens, d_beam_count))
+
+    def ascend_laserscan_batch_dev(self, d_nodes: int, n_stride: int, d_n_per_scan: int, B: int,
+                                   params: Params, d_ranges: int, d_intens: int, d_beam_count: int,
+                                   write_ascended: bool = False, d_status: int = 0):
+        """S1 -> S3 (grab_scan_data with geometric correction, then publish_scan) in one pass."""
+        self._check(self._lib.rplgpu_ascend_laserscan_batch_dev(
+            self._h, d_nodes, n_stride, d_n_per_scan, B, C.byref(params),
+            d_ranges, d_intens, d_beam_count, int(bool(write_ascended)), d_status))
 
     def cloud_batch_dev(self, d_nodes: int, n_stride: int, d_n_per_scan: int, B: int,
                         params: Params, d_xyzi: int, out_stride: int, d_n_points: int,

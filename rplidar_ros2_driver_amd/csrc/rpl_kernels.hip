@@ -187,7 +187,8 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
                                            const uint32_t *__restrict__ n_per_scan,
                                            uint32_t *__restrict__ status,
                                            uint32_t *__restrict__ need_sort, uint32_t *s_keys,
-                                           uint32_t *s_misc, SortLds &s_sort, uint32_t mark = 0u);
+                                           uint32_t *s_misc, SortLds &s_sort, uint32_t mark = 0u,
+                                           bool prefilled = false);
 
 // mark: a status bit the queueing kernels set on a scan they hand to the sorting kernel — a
 // single-scan call launches that kernel only when the bit came back (kAscendUnsorted, internal)
@@ -195,7 +196,8 @@ template <bool SORT>
 __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, uint32_t n_stride,
                                                    const uint32_t *__restrict__ n_per_scan,
                                                    uint32_t *__restrict__ status,
-                                                   uint32_t *__restrict__ need_sort, uint32_t mark) {
+                                                   uint32_t *__restrict__ need_sort, uint32_t mark,
+                                                   uint32_t prefilled) {
   __shared__ uint32_t s_keys[kMaxN];
   __shared__ uint32_t s_misc[8];
   __shared__ SortLds s_sort;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
     }
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
       ascend_one<SORT>(need_sort[1u + k], nodes, n_stride, n_per_scan, status, need_sort, s_keys,
-                       s_misc, s_sort);
+                       s_misc, s_sort, 0u, prefilled != 0u);
       __syncthreads();  // LDS is reused by the next scan
     }
   } else {
@@ -222,12 +224,40 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
                                            const uint32_t *__restrict__ n_per_scan,
                                            uint32_t *__restrict__ status,
                                            uint32_t *__restrict__ need_sort, uint32_t *s_keys,
-                                           uint32_t *s_misc, SortLds &s_sort, uint32_t mark) {
+                                           uint32_t *s_misc, SortLds &s_sort, uint32_t mark,
+                                           bool prefilled) {
   const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   uint2 *scan = nodes + (size_t)b * n_stride;
 
   uint2 v[kIters];
   load_scan(scan, n, v);
+  if (SORT && prefilled) {
+    // The scan comes from k_ascend_stream: every filled angle word is already in place (that kernel
+    // writes the fills of a scan it queues, too) and nodes may have MOVED since (its local repair),
+    // so an invalid node's index no longer says which angle it was given — the stored words are the
+    // truth.  What is left of :171-181 is the sort; ties stay in the order they are in (the repair
+    // is a stable permutation, so that is still the input order).
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t i = sample_index(j);
+      if (i < n) s_keys[i] = (nd_q14(v[j]) << 16) | i;
+    }
+    __syncthreads();
+    sort_keys_to_positions(s_keys, n, s_sort);
+    load_scan(scan, n, v);
+    // every thread has its samples back IN REGISTERS before anybody overwrites the buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kIters; ++j) {
+      const uint32_t i = sample_index(j);
+      if (i < n) {
+        const uint32_t pos = s_keys[i];
+        if (pos != i) scan[pos] = v[j];
+      }
+    }
+    return;
+  }
 
   // first valid index (block min)
   if (threadIdx.x == 0) s_misc[0] = 0xFFFFFFFFu;
@@ -345,14 +375,44 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
 // kernel already wrote in place do not disturb it.
 // ------------------------------------------------------------------------------
 constexpr int kAscT = 256;
+constexpr int kAscW = kAscT / 64;
 typedef uint32_t asc_u32x4 __attribute__((ext_vector_type(4)));
+
+// Local repair (round 5).  On a real sensor the interpolated angles of the invalid nodes do not mesh
+// with their measured neighbours, and measured angles jitter: the filled scan is ALMOST ascending —
+// neighbouring samples swapped, every node within a few places of where :181's sort puts it — and
+// sending every such scan through k_ascend<true> (a full counting sort of 32 000 keys by one
+// workgroup) cost 8 x the streaming pass.  The streaming kernel now repairs local disorder itself:
+//   phase A  a 128-sample chunk (one wave trip) whose angle words are not ascending goes through a
+//            few rounds of odd-even transposition on 32-bit tokens (angle word << 8 | slot in the
+//            chunk) held two per lane — min / max inside the lane, then against the neighbour
+//            lanes by DPP — and the nodes follow their tokens through 1 KiB of wave-private LDS;
+//   phase B  after the scan's last chunk: a chunk boundary whose two sides are out of order
+//            (last word of chunk k - 1 > first word of chunk k) is repaired in the 16-sample window
+//            across it, one sample per lane, odd-even transposition inside a DPP row, the nodes
+//            following by ds_bpermute.
+// Both are stable permutations (a swap only where the left token is strictly larger, tokens carry
+// the original place), nothing is ever dropped, and the result is CHECKED: every chunk must come out
+// ascending, every repaired window too, with its two end samples still in place (they anchor the
+// window to the sorted chunks around it).  A scan that fails a check — disorder reaching farther than
+// the rounds — is queued for k_ascend<true> as before, which then trusts the stored angle words
+// (`prefilled`).  Ties keep their input order, the library's tie rule (tests/canon.py).
+constexpr int kAscRounds = 6;    // phase A: pairs of (inside the lane, across lanes) rounds
+constexpr int kAscRoundsB = 8;   // phase B: pairs of (even, odd) rounds on 16 samples
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t asc_dpp_mov(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
+}
 
 __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nodes, uint32_t n_stride,
                                                          const uint32_t *__restrict__ n_per_scan,
                                                          uint32_t *__restrict__ status,
                                                          uint32_t *__restrict__ need_sort, uint32_t mark) {
-  __shared__ uint32_t s_misc[4];                  // 0 first valid, 1 front word, 2 not ascending
+  __shared__ uint32_t s_misc[8];                  // 0 first valid, 1 front word, 2 not ascending, 3 wrap zone, 4 W
   __shared__ uint32_t s_edge[2 * (kMaxN / 128)];  // first / last angle word of every 128-sample chunk
+  __shared__ uint4 s_xch[kAscW][64];              // phase A: the nodes of a chunk, by slot (wave-private)
+  __shared__ uint2 s_wrap[64];                    // the wrapped fills at the scan's end (they go to its front)
   const uint32_t b = blockIdx.x;
   const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(
       (int)min(n_per_scan[b], min(n_stride, kMaxN)));  // never past the slot
@@ -365,7 +425,7 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
     return make_uint4(t.x, t.y, t.z, t.w);
   };
   const uint32_t npairs = (n + 1u) >> 1;
-  if (threadIdx.x == 0) { s_misc[0] = 0xFFFFFFFFu; s_misc[2] = 0u; }
+  if (threadIdx.x == 0) { s_misc[0] = 0xFFFFFFFFu; s_misc[2] = 0u; s_misc[4] = 0u; }
   __syncthreads();
   // ---- first valid sample (block-uniform loop; found in the first round for any real scan)
   for (uint32_t base = 0; base < npairs; base += kAscT) {
@@ -400,11 +460,41 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
       q = deg_to_q14(e);
     }
     s_misc[1] = q;
+    // The wrap zone: the last indices whose interpolated angle passes 360 degrees (:174-176).  An
+    // invalid node there is given an angle near ZERO and belongs at the FRONT of the sorted scan —
+    // every other node then moves up by one place, which no local repair can do.  (front + i * inc
+    // is non-decreasing in i: the zone is a suffix of the index range; 65 = longer than handled.)
+    const float fr = q14_to_deg(q);
+    uint32_t tl = 0u;
+    while (tl < 65u && tl + 1u < n) {
+      const float e = fr + (float)(n - 1u - tl) * inc;
+      if (!(e > 360.0f)) break;
+      ++tl;
+    }
+    s_misc[3] = tl;
   }
   __syncthreads();
   const uint32_t front_q = s_misc[1];
   const float front = q14_to_deg(front_q);  // :171
-  // ---- the fill pass (:171-178) + "is it ascending?" (:181 would not move anything then)
+  // W: the scan ends with W wrapped fills and the wrap zone holds no other invalid node — the one
+  // non-local move this kernel handles itself: those W nodes go to the front (in index order: their
+  // angles ascend), the others move up by W.  Anything else in the wrap zone is left to the checks
+  // below (the scan then comes out not ascending and goes to the sorting kernel).
+  {
+    const uint32_t tl = s_misc[3];
+    if (tl >= 1u && tl <= 64u && threadIdx.x < 64u) {  // wave 0
+      const bool inv = lane_id() < tl && nd_dist(scan[n - tl + lane_id()]) == 0u;
+      const uint64_t m = __builtin_amdgcn_ballot_w64(inv);  // bit j: index n - tl + j
+      const uint64_t top = ~(m << (64u - tl));               // leading zeros = invalid nodes at the very end
+      uint32_t W = top ? (uint32_t)__builtin_clzll(top) : 64u;
+      W = min(W, tl);
+      if (lane_id() == 0u) s_misc[4] = ((uint32_t)__popcll(m) == W) ? W : 0u;
+    }
+  }
+  __syncthreads();
+  const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_misc[4]);
+  const uint32_t nm = n - W;  // the nodes [0, nm) keep their order relative to each other (up to local repair)
+  // ---- the fill pass (:171-178) + the order of the result (:181 moves nothing when it ascends)
   auto new_angle = [&](uint2 v, uint32_t i) -> uint32_t {
     uint32_t nq = nd_q14(v);
     if (nd_dist(v) == 0u) {
@@ -418,23 +508,71 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
     }
     return nq;
   };
-  uint32_t bad = 0u;
+  uint32_t bad = 0u;  // this lane saw an order violation that the repairs did not remove
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
   constexpr int kDeep = 4;  // loads in flight per thread
-  for (uint32_t base = 0; base < npairs; base += kDeep * kAscT) {
+  constexpr uint32_t kTrip = (uint32_t)kDeep * kAscT;  // pairs per trip of the workgroup
+  // The chunks are taken from the END of the scan to its front: with W > 0 a node is written W places
+  // above where it was read, i.e. into places that were read in this trip (after the barrier below)
+  // or in an earlier one.
+  for (uint32_t trip = (npairs + kTrip - 1u) / kTrip; trip-- > 0u;) {
+    const uint32_t base = trip * kTrip;
     uint4 w[kDeep];
 #pragma unroll
     for (int k = 0; k < kDeep; ++k) w[k] = load_pair(base + (uint32_t)k * kAscT + threadIdx.x);
+    if (W) {  // block-uniform: every wave has its nodes in registers before any wave stores
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < kDeep; ++k) {
       const uint32_t pair = base + (uint32_t)k * kAscT + threadIdx.x, i = 2u * pair;
       const uint2 a = make_uint2(w[k].x, w[k].y), c = make_uint2(w[k].z, w[k].w);
-      // (samples beyond the scan compare as "larger than any angle word": never out of order)
-      const uint32_t qa = i < n ? new_angle(a, i) : 0x10000u;
-      const uint32_t qc = i + 1u < n ? new_angle(c, i + 1u) : 0x10000u;
-      if (i < n && qa != nd_q14(a)) scan[i] = make_uint2((a.x & 0xFFFF0000u) | qa, a.y);
-      if (i + 1u < n && qc != nd_q14(c)) scan[i + 1u] = make_uint2((c.x & 0xFFFF0000u) | qc, c.y);
-      // the sample before this pair: the lane to the left (lane 0: the chunk before, via LDS)
-      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qc, 0x138, 0xF, 0xF, false);
+      // the nodes with their new angle words
+      const uint32_t fa = i < n ? new_angle(a, i) : 0u, fc = i + 1u < n ? new_angle(c, i + 1u) : 0u;
+      uint2 na = make_uint2((a.x & 0xFFFF0000u) | fa, a.y);
+      uint2 nc = make_uint2((c.x & 0xFFFF0000u) | fc, c.y);
+      if (W) {  // the wrapped fills wait in LDS until the front of the scan has been read
+        if (i >= nm && i < n) s_wrap[i - nm] = na;
+        if (i + 1u >= nm && i + 1u < n) s_wrap[i + 1u - nm] = nc;
+      }
+      // (the wrapped fills and the samples beyond the scan compare as "larger than any angle word":
+      // they sit at the end of the last chunk and stay there)
+      uint32_t qa = i < nm ? fa : 0x10000u;
+      uint32_t qc = i + 1u < nm ? fc : 0x10000u;
+      // ---- phase A: is the chunk in order?  (lane l + 1's first word against this lane's second)
+      const uint32_t nxt_q = asc_dpp_mov<0x130>(0xFFFFFFFFu, qa);  // wave_shl:1; lane 63: no successor here
+      if (__builtin_amdgcn_ballot_w64((qa > qc) | (qc > nxt_q))) {  // wave-uniform: local repair
+        uint32_t ta = (qa << 8) | (2u * lane_id()), tc = (qc << 8) | (2u * lane_id() + 1u);
+#pragma unroll
+        for (int r = 0; r < kAscRounds; ++r) {
+          const uint32_t lo = min(ta, tc), hi = max(ta, tc);
+          const uint32_t nx = asc_dpp_mov<0x130>(0xFFFFFFFFu, lo);  // lane l + 1's smaller token
+          const uint32_t pv = asc_dpp_mov<0x138>(0u, hi);           // lane l - 1's larger token (wave_shr:1)
+          ta = max(lo, pv);
+          tc = min(hi, nx);
+        }
+        {  // (the last exchange across lanes may leave a lane's two tokens swapped)
+          const uint32_t lo = min(ta, tc), hi = max(ta, tc);
+          ta = lo;
+          tc = hi;
+        }
+        // the nodes follow their tokens (slot = low 7 bits) through the wave's 1 KiB of LDS
+        s_xch[wv][lane_id()] = make_uint4(na.x, na.y, nc.x, nc.y);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint2 *slots = reinterpret_cast<const uint2 *>(&s_xch[wv][0]);
+        na = slots[ta & 127u];
+        nc = slots[tc & 127u];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (read before the next chunk overwrites it)
+        qa = ta >> 8;
+        qc = tc >> 8;
+      }
+      if (i < nm && (W || na.x != a.x || na.y != a.y)) scan[i + W] = na;
+      if (i + 1u < nm && (W || nc.x != c.x || nc.y != c.y)) scan[i + 1u + W] = nc;
+      // what is left out of order inside the chunk after the repair (nothing, normally)
+      const uint32_t prev = asc_dpp_mov<0x138>(0u, qc);  // the lane to the left (lane 0: nothing before it here)
       bad |= (qa > qc) | (prev > qa);
       const uint32_t chunk = pair >> 6;  // wave-uniform: 64 pairs = 128 samples
       if (pair < npairs) {
@@ -443,13 +581,84 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
       }
     }
   }
-  __syncthreads();
+  __syncthreads();  // (also: the nodes every wave wrote are visible to the whole workgroup)
+  // ---- phase B: chunk boundaries whose two sides are out of order
   const uint32_t nchunks = (npairs + 63u) >> 6;
-  for (uint32_t c = threadIdx.x; c + 1u < nchunks; c += kAscT)
-    bad |= s_edge[2u * c + 1u] > s_edge[2u * c + 2u];
+  const uint32_t row = lane_id() >> 4, col = lane_id() & 15u;
+  for (uint32_t base = 1u; base < nchunks; base += (uint32_t)kAscT / 16u) {
+    const uint32_t kb = base + wv * 4u + row;  // the boundary between chunk kb - 1 and chunk kb
+    const bool need = kb < nchunks && s_edge[2u * kb - 1u] > s_edge[2u * kb];
+    if (!__builtin_amdgcn_ballot_w64(need)) continue;  // wave-uniform
+    const uint32_t pos = 128u * kb - 8u + col;  // (place among the nm nodes; W above that in the buffer)
+    uint2 v = make_uint2(0u, 0u);
+    if (need && pos < nm) v = scan[pos + W];
+    const uint32_t q = (need && pos < nm) ? nd_q14(v) : 0x10000u;
+    uint32_t t = (q << 8) | col;
+    const bool odd = (col & 1u) != 0u;
+#pragma unroll
+    for (int r = 0; r < kAscRoundsB; ++r) {
+      {  // pairs (0,1) (2,3) ...: the even lane keeps the smaller token
+        const uint32_t nx = asc_dpp_mov<0x101>(t, t);  // row_shl:1 (lane 15 of a row: its own)
+        const uint32_t pv = asc_dpp_mov<0x111>(t, t);  // row_shr:1 (lane 0 of a row: its own)
+        t = odd ? max(t, pv) : min(t, nx);
+      }
+      {  // pairs (1,2) (3,4) ...: the odd lane keeps the smaller token; lanes 0 and 15 stay
+        const uint32_t nx = asc_dpp_mov<0x101>(t, t);
+        const uint32_t pv = asc_dpp_mov<0x111>(t, t);
+        t = odd ? min(t, nx) : max(t, pv);
+      }
+    }
+    // checks: the window ascends, its end samples did not move
+    const uint32_t pv = asc_dpp_mov<0x111>(0u, t);
+    bad |= need & ((pv > t) | ((col == 0u || col == 15u) && (t & 15u) != col));
+    // the nodes follow: source lane = same row, column = the token's low bits
+    const uint32_t src = ((lane_id() & 48u) | (t & 15u)) * 4u;
+    const uint32_t mx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.x);
+    const uint32_t my = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.y);
+    if (need && pos < nm && (t & 15u) != col) scan[pos + W] = make_uint2(mx, my);
+  }
+  // ---- the wrapped fills: to the front, in index order
+  if (W >= 16u) {
+    // The node behind them must be LARGER: with an equal word it would have to come first (ties keep
+    // the input order, and it has the smaller index).
+    if (threadIdx.x < W) scan[threadIdx.x] = s_wrap[threadIdx.x];
+    if (threadIdx.x == 0u && nd_q14(s_wrap[W - 1u]) >= s_edge[0]) bad |= 1u;
+  } else if (W && wv == 0u) {
+    // A few wrapped fills, whose angles may interleave with the first samples' (jitter): the first 16
+    // places of the result — the W fills, then the nodes that lead the rest — are one more window of
+    // the phase-B kind (wave 0, row 0).  A token's tie-break field puts a wrapped fill behind a node
+    // of equal angle (its index is the larger one); only the window's last place is an anchor.
+    const uint32_t c16 = lane_id();  // (rows 1-3 work on copies of nothing and store nothing)
+    const bool inwin = c16 < 16u && c16 < n;
+    uint2 v = make_uint2(0u, 0u);
+    if (inwin) v = c16 < W ? s_wrap[c16] : scan[c16];
+    const uint32_t tie = c16 < W ? 16u + c16 : c16 - W;
+    uint32_t t = ((inwin ? nd_q14(v) : 0x10000u) << 10) | ((tie & 31u) << 5) | (c16 & 15u);
+    const bool odd = (c16 & 1u) != 0u;
+#pragma unroll
+    for (int r = 0; r < kAscRoundsB; ++r) {
+      {
+        const uint32_t nx = asc_dpp_mov<0x101>(t, t);
+        const uint32_t pv = asc_dpp_mov<0x111>(t, t);
+        t = odd ? max(t, pv) : min(t, nx);
+      }
+      {
+        const uint32_t nx = asc_dpp_mov<0x101>(t, t);
+        const uint32_t pv = asc_dpp_mov<0x111>(t, t);
+        t = odd ? min(t, nx) : max(t, pv);
+      }
+    }
+    const uint32_t pv = asc_dpp_mov<0x111>(0u, t);
+    if (c16 < 16u) bad |= (pv > t) | (c16 == 15u && (t & 15u) != 15u);
+    const uint32_t src = (t & 15u) * 4u;
+    const uint32_t mx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.x);
+    const uint32_t my = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.y);
+    if (inwin) scan[c16] = make_uint2(mx, my);
+  }
+  // ---- boundaries that needed no repair are in order by construction of `need`; the rest was checked
   if (__builtin_amdgcn_ballot_w64(bad != 0u) && lane_id() == 0u) atomicOr(&s_misc[2], 1u);
   __syncthreads();
-  // not ascending: queue the scan for the sorting kernel (need_sort[0] = count, then the list)
+  // still not ascending: queue the scan for the sorting kernel (need_sort[0] = count, then the list)
   if (threadIdx.x == 0 && s_misc[2]) {
     need_sort[1u + atomicAdd(&need_sort[0], 1u)] = b;
     if (mark && status) status[b] |= mark;
@@ -633,6 +842,9 @@ __global__ __launch_bounds__(256) void k_pack(const float4 *__restrict__ xyzi, u
 // ------------------------------------------------------------------------------
 // host-side launchers (declared in rpl_launch.hpp)
 // ------------------------------------------------------------------------------
+// which first kernel a call takes: the streaming kernel, or (a handful of LONG scans) k_ascend<false>
+static bool ascend_streams(uint32_t B, uint32_t n_stride) { return !(B <= 8u && n_stride > 8192u); }
+
 hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
                          uint32_t B, uint32_t *status, uint32_t *need_sort, bool defer_sort) {
   if (B == 0) return hipSuccess;
@@ -649,9 +861,9 @@ hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const ui
   // and one 1024-thread workgroup that holds the scan in registers finishes a 32 000-sample scan in
   // a quarter less time than one 256-thread workgroup streaming it (46 vs 62 us per call; at 360
   // samples the streaming kernel is the faster one, 18 vs 24 us); batches stream.
-  if (B <= 8u && n_stride > 8192u)
+  if (!ascend_streams(B, n_stride))
     hipLaunchKernelGGL(k_ascend<false>, dim3(B), dim3(kBlock), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
-                       status, need_sort, mark);
+                       status, need_sort, mark, 0u);
   else
     hipLaunchKernelGGL(k_ascend_stream, dim3(B), dim3(kAscT), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
                        status, need_sort, mark);
@@ -663,8 +875,11 @@ hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const ui
 hipError_t launch_ascend_sort(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
                               uint32_t B, uint32_t *status, uint32_t *need_sort) {
   if (B == 0) return hipSuccess;
+  // (scans queued by the streaming kernel have their filled angle words in place and may have been
+  // permuted by its local repair: the sort then trusts the stored words)
+  const uint32_t prefilled = ascend_streams(B, n_stride) ? 1u : 0u;
   hipLaunchKernelGGL(k_ascend<true>, dim3(std::min<uint32_t>(B, 256u)), dim3(kBlock), 0, s,
-                     (uint2 *)nodes, n_stride, n_per_scan, status, need_sort, 0u);
+                     (uint2 *)nodes, n_stride, n_per_scan, status, need_sort, 0u, prefilled);
   if (B != 1u)  // (invariant between calls: the list is empty)
     if (hipError_t e = hipMemsetAsync(need_sort, 0, 4, s); e != hipSuccess) return e;
   return hipGetLastError();

@@ -710,6 +710,26 @@ int32_t rplgpu_laserscan_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nod
                        d_beam_count);
 }
 
+// S1 -> S3 in one pass (see include/rplgpu.h): the LaserScan does not depend on the ascend step, so
+// the binning kernel reads the raw nodes; the ascend kernels run behind it only when the caller
+// wants the ascended nodes as well.
+int32_t rplgpu_ascend_laserscan_batch_dev(rplgpu_handle_t h, rplgpu_node_t *d_nodes,
+                                          uint32_t n_stride, const uint32_t *d_n_per_scan,
+                                          uint32_t B, const rplgpu_params_t *p, float *d_ranges,
+                                          float *d_intensities, uint32_t *d_beam_count,
+                                          int32_t write_ascended, uint32_t *d_status) {
+  int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
+  if (rc) return rc;
+  if (!p || !d_ranges || !d_intensities || !d_beam_count) return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  rc = run_laserscan(h, d_nodes, n_stride, d_n_per_scan, B, *p, d_ranges, d_intensities,
+                     d_beam_count);
+  if (rc || !write_ascended) return rc;
+  RPL_HIP(h, rpl::launch_ascend(h->stream, d_nodes, n_stride, d_n_per_scan, B, d_status,
+                                h->d_need_sort));
+  return RPLGPU_OK;
+}
+
 // The two-kernel voxel path (rpl_voxel.hip) needs a region store: one region per 2048-sample chunk
 // of every scan of a STAGE of work items.  It is allocated (grown) here, by the first batch call
 // whose stages would fill the device, within the handle's byte budget; smaller batches and

@@ -786,3 +786,165 @@ def test_hip_path_matches_second_writer_golden(gpu, tag):
             assert got.tobytes() == want.tobytes(), key
         checked += 1
     assert checked >= 20
+
+
+# ------------------------------------------------- ascendScanData on almost-ascending scans
+@pytest.mark.parametrize("jitter", [1, 2, 3, 5, 8, 12, 40])
+def test_ascend_batch_local_repair_regimes(gpu, oracle, jitter):
+    """What a real sensor delivers: measured angles jitter and the interpolated angles of invalid nodes
+    (src/sdk/src/sl_lidar_driver.cpp:171-178) do not mesh with their neighbours, so the filled scan is
+    almost, not quite, ascending.  Small disorder is repaired inside the streaming kernel (odd-even
+    transposition in registers, chunk boundaries in 16-sample windows), larger disorder falls back
+    to the sorting kernel; either way the result must be ascendScanData's, with this library's tie
+    rule (equal angle words keep their input order)."""
+    torch = _torch()
+    B, n = 40, 32000
+    batch = synth.make_batch(4242 + jitter, B, n, jitter=jitter)
+    lens = np.full(B, n, np.uint32)
+    lens[1], lens[2], lens[3], lens[4] = 31999, 129, 128, 127  # odd length, chunk-sized scans
+    lens[5] = 8191
+    dev = torch.device("cuda:0")
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8).copy()).to(dev)
+    d_len = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    gpu.ascend_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, d_st.data_ptr())
+    gpu.synchronize()
+    asc = d_nodes.cpu().numpy().view(NODE_DTYPE).reshape(B, n)
+    assert np.all(d_st.cpu().numpy() == 0)
+    for b in range(B):
+        src = batch[b, : lens[b]]
+        want, res = oracle.ascend(src)
+        got = asc[b, : lens[b]]
+        assert res == 0
+        assert np.array_equal(got["angle_z_q14"], want["angle_z_q14"]), (jitter, b)
+        assert oracle_lib.canon_equal_angle_runs(got).tobytes() == \
+            oracle_lib.canon_equal_angle_runs(want).tobytes(), (jitter, b)
+        # stability: the valid samples (whose angle words the fill never touches) in stable order
+        v = src[src["dist_mm_q2"] != 0]
+        assert got[got["dist_mm_q2"] != 0].tobytes() == \
+            v[np.argsort(v["angle_z_q14"], kind="stable")].tobytes(), (jitter, b)
+        assert asc[b, lens[b]:].tobytes() == batch[b, lens[b]:].tobytes()  # the slot's tail untouched
+
+
+def test_ascend_then_laserscan_equals_laserscan(gpu, oracle):
+    """rplgpu_ascend_laserscan_batch_dev: grab_scan_data (ascendScanData in place,
+    src/lidar_driver_wrapper.cpp:328-337) followed by publish_scan (src/rplidar_node.cpp:568-680) in
+    one pass.  publish_scan drops the invalid nodes — the only ones ascendScanData rewrites — and
+    sorts by angle itself, so the LaserScan must be the one of the raw nodes, bit for bit, in every
+    mode; checked against the two-step pipeline on the device and against the oracle's two steps."""
+    torch = _torch()
+    B, n = 32, 8000
+    dev = torch.device("cuda:0")
+    for jitter, kw in ((0, {}), (3, {}), (50, {"rotate": True}), (0, {"kind": "uniform"})):
+        batch = synth.make_batch(99 + jitter, B, n, jitter=jitter, **kw)
+        batch[5]["dist_mm_q2"] = 0  # an all-invalid scan: ascend fails, nothing is published
+        lens = np.array([n - 7 * b for b in range(B)], np.uint32)
+        d_len = torch.from_numpy(lens.astype(np.int32)).to(dev)
+        for sp in (1, 0):
+            for inv in (0, 1):
+                p = Params.defaults(range_max=40.0, scan_processing=sp, inverted=inv)
+                d_raw = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8).copy()).to(dev)
+                out = [[torch.zeros(B, n, dtype=torch.float32, device=dev) for _ in range(2)] +
+                       [torch.zeros(B, dtype=torch.int32, device=dev)] for _ in range(3)]
+                d_st = torch.full((B,), -1, dtype=torch.int32, device=dev)
+                # (a) one pass, nodes only read
+                before = d_raw.clone()
+                gpu.ascend_laserscan_batch_dev(d_raw.data_ptr(), n, d_len.data_ptr(), B, p,
+                                               out[0][0].data_ptr(), out[0][1].data_ptr(),
+                                               out[0][2].data_ptr())
+                gpu.synchronize()
+                assert torch.equal(before, d_raw) and int(d_st.max()) == -1
+                # (b) two steps: ascend in place, then the LaserScan of the ascended nodes
+                d_two = d_raw.clone()
+                gpu.ascend_batch_dev(d_two.data_ptr(), n, d_len.data_ptr(), B, 0)
+                gpu.laserscan_batch_dev(d_two.data_ptr(), n, d_len.data_ptr(), B, p,
+                                        out[1][0].data_ptr(), out[1][1].data_ptr(), out[1][2].data_ptr())
+                # (c) one call that also leaves the ascended nodes
+                d_both = d_raw.clone()
+                gpu.ascend_laserscan_batch_dev(d_both.data_ptr(), n, d_len.data_ptr(), B, p,
+                                               out[2][0].data_ptr(), out[2][1].data_ptr(),
+                                               out[2][2].data_ptr(), True, d_st.data_ptr())
+                gpu.synchronize()
+                assert torch.equal(d_both, d_two)
+                st = d_st.cpu().numpy()
+                assert st[5] & abi.SCAN_ALL_INVALID and np.all(np.delete(st, 5) == 0)
+                cnt = out[0][2].cpu().numpy()
+                assert cnt[5] == 0
+                for o in out[1:]:
+                    assert np.array_equal(o[2].cpu().numpy(), cnt)
+                r0, i0 = out[0][0].cpu().numpy(), out[0][1].cpu().numpy()
+                for o in out[1:]:
+                    r, i = o[0].cpu().numpy(), o[1].cpu().numpy()
+                    for b in range(B):
+                        assert r[b, : cnt[b]].tobytes() == r0[b, : cnt[b]].tobytes(), (jitter, sp, inv, b)
+                        assert i[b, : cnt[b]].tobytes() == i0[b, : cnt[b]].tobytes(), (jitter, sp, inv, b)
+                # the oracle's two steps on a few scans (ties canonicalised as everywhere: Mode A
+                # ranges are order-free, the rest is compared where no angle word repeats)
+                for b in (0, 7, 31):
+                    src = batch[b, : lens[b]]
+                    asc_nodes, res = oracle.ascend(src)
+                    wr, wi, wm = oracle.publish_scan(asc_nodes if res == 0 else src,
+                                                     oracle_lib.copy_params(p), 0.1)
+                    assert cnt[b] == wm.count
+                    if sp == 1:
+                        assert r0[b, : cnt[b]].tobytes() == wr.tobytes()
+
+
+def test_ascend_wrap_zone(gpu, oracle):
+    """Invalid nodes at the end of a scan whose interpolated angle passes 360 degrees are given an
+    angle near zero (src/sdk/src/sl_lidar_driver.cpp:174-176) and belong at the FRONT of the sorted
+    scan: every other node moves up.  The streaming kernel does that move itself when the wrapped
+    fills are the scan's last W nodes (W <= 64); other shapes of the wrap zone go to the sorting
+    kernel.  Both must give ascendScanData's result."""
+    torch = _torch()
+    n = 32000
+    # (angle offset of the whole scan / of sample 0 alone, indices made invalid, indices forced valid, length)
+    shapes = []
+    for q0, k in ((5, 1), (9, 2), (40, 5), (200, 64), (200, 65), (131, 40)):
+        shapes.append((q0, 0, list(range(n - k, n)), [], n))       # the wrapped fills go to the very front
+    for q0, k in ((5, 1), (40, 5), (200, 64)):
+        shapes.append((0, q0, list(range(n - k, n)), [], n))       # ... or in between the first samples
+    shapes.append((40, 0, [n - 1, n - 2, n - 4], [n - 3], n))      # a valid node inside the zone
+    shapes.append((3000, 0, list(range(n - 30, n)), [], n))        # a zone of ~1500 samples
+    shapes.append((40, 0, list(range(20000 - 3, 20000)), [], 20000))  # shorter scans
+    shapes.append((40, 0, [298, 299], [], 300))
+    shapes.append((40, 0, [128], [], 129))
+    shapes.append((40, 0, [127], [], 128))
+    shapes.append((0, 0, list(range(n - 4, n)), [], n))            # front 0: nothing wraps
+    for jitter in (0, 3):
+        B = len(shapes)
+        batch = synth.make_batch(777 + jitter, B, n, jitter=jitter)
+        lens = np.zeros(B, np.uint32)
+        for b, (qall, q0, inv, val, ln) in enumerate(shapes):
+            lens[b] = ln
+            batch[b]["angle_z_q14"] = np.minimum(batch[b]["angle_z_q14"].astype(np.uint32) + qall, 65535)
+            if q0:
+                batch[b]["angle_z_q14"][0] = q0
+            if batch[b]["dist_mm_q2"][0] == 0:
+                batch[b]["dist_mm_q2"][0] = 4000
+            batch[b]["dist_mm_q2"][inv] = 0
+            for v in val:
+                batch[b]["dist_mm_q2"][v] = 8000
+        dev = torch.device("cuda:0")
+        d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8).copy()).to(dev)
+        d_len = torch.from_numpy(lens.astype(np.int32)).to(dev)
+        d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+        gpu.ascend_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, d_st.data_ptr())
+        gpu.synchronize()
+        asc = d_nodes.cpu().numpy().view(NODE_DTYPE).reshape(B, n)
+        assert np.all(d_st.cpu().numpy() == 0)
+        moved_front = 0
+        for b in range(B):
+            src = batch[b, : lens[b]]
+            want, res = oracle.ascend(src)
+            got = asc[b, : lens[b]]
+            assert res == 0
+            assert np.array_equal(got["angle_z_q14"], want["angle_z_q14"]), (jitter, b)
+            assert oracle_lib.canon_equal_angle_runs(got).tobytes() == \
+                oracle_lib.canon_equal_angle_runs(want).tobytes(), (jitter, b)
+            v = src[src["dist_mm_q2"] != 0]
+            assert got[got["dist_mm_q2"] != 0].tobytes() == \
+                v[np.argsort(v["angle_z_q14"], kind="stable")].tobytes(), (jitter, b)
+            assert asc[b, lens[b]:].tobytes() == batch[b, lens[b]:].tobytes()
+            moved_front += int(got["dist_mm_q2"][0] == 0 and src["dist_mm_q2"][0] != 0)
+        assert moved_front >= 5  # the cases really exercise the wrap
