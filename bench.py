@@ -92,6 +92,10 @@ def parse_args():
     ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1: pieces a rank's block is cut into (gather of piece k overlaps "
                          "compute of piece k + 1)")
+    ap.add_argument("--exchange", choices=["allgather", "gather"], default="allgather",
+                    help="N > 1: every rank ends up with the whole voxelised cloud (all-gather, BASELINE "
+                         "config 4) or only rank 0 does (gather to root, config 5's fused message: "
+                         "rplgpu_gather_clouds_dev, one slot per link instead of one per link and direction)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target wall time of the CPU baseline sample (0 disables)")
     ap.add_argument("--no-laserscan", action="store_true",
@@ -513,7 +517,7 @@ def main():
     import torch.distributed as dist
 
     from rplidar_ros2_driver_amd import Params, RplGpu, synth
-    from rplidar_ros2_driver_amd.sharding import CloudExchange, shard_range
+    from rplidar_ros2_driver_amd.sharding import CloudExchange, predicted_step_ms, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -581,8 +585,11 @@ def main():
         # chunks; chunk k is voxelised into arena half (k & 1) while chunk k - 1 is gathered
         # (auto: with one rank there is no transfer to hide, so one chunk = one launch; with peers
         # two chunks, so that the first half's clouds travel while the second half is voxelised)
-        n_chunks = args.chunks if args.chunks > 0 else (1 if world == 1 else 2)
-        exch = CloudExchange(gpu, dist, dev, world, rank, B, n, out_stride, n_chunks)
+        # (round 5: four chunks with peers — by DESIGN.md §7's model the exchange of all but the LAST
+        # chunk can hide under compute, so 3/4 instead of 1/2 of it; sharding.predicted_step_ms)
+        n_chunks = args.chunks if args.chunks > 0 else (1 if world == 1 else 4)
+        exch = CloudExchange(gpu, dist, dev, world, rank, B, n, out_stride, n_chunks,
+                             root=0 if args.exchange == "gather" else None)
         if exch.native and exch.comm_ranks != world:
             raise SystemExit(f"--gpus {args.gpus}: the RCCL communicator spans {exch.comm_ranks} rank(s), "
                              f"not {world}")
@@ -636,7 +643,12 @@ def main():
                         "overlapped_ms": round(elapsed / args.steps * 1e3, 4),
                         "gathered_bytes_per_rank": exch.last_bytes(),
                         "exchange_backend": exch.backend, "chunks": exch.chunks,
-                        "comm_ranks": exch.comm_ranks,
+                        "comm_ranks": exch.comm_ranks, "exchange": args.exchange,
+                        "model_ms_per_step": round(predicted_step_ms(
+                            world, ms_c * world, 12.0 * world * exch.chunks * (exch.slot or 0), exch.chunks,
+                            gather_root=args.exchange == "gather"), 4),
+                        "model_note": "DESIGN.md section 7: per rank compute/chunks per piece, a piece's slot "
+                                      "on one 76.8 GB/s link, pieces pipelined; measured = overlapped_ms",
                         "note": "compute = the rank's whole block in one launch, no exchange; "
                                 "exchange_only = RCCL all-gather of the last step's clouds; "
                                 "overlapped = the timed step (chunked, two streams)"}

@@ -70,6 +70,22 @@ int32_t rplgpu_allgather_clouds_dev(rplgpu_handle_t h, const float *d_points_loc
                                     uint64_t slot_points, const uint32_t *d_meta_local,
                                     uint32_t meta_words, float *d_points_all,
                                     uint32_t *d_meta_all);
+/* Gather to ONE rank ("for C5 a gather-to-root + per-sensor rigid transform
+ * suffices" — the fused message of the eight sensors is built on one GPU; the node only ever
+ * publishes the identity base_link -> frame_id, /root/reference src/rplidar_node.cpp:183-197):
+ * grouped ncclSend / ncclRecv on the exchange stream.  Rank `root` receives every rank's slot and
+ * META block into the layout of the all-gather (rank r's slot at d_points_all +
+ * r * slot_points * point_floats floats, its META block at d_meta_all + r * meta_words), its own
+ * by a device copy (none when d_points_local already IS its slot of the receive buffer); the other
+ * ranks only send, d_points_all / d_meta_all may be NULL there.  A link then carries ONE slot, into
+ * the root, where the all-gather puts one slot on every link in every direction and the whole
+ * cloud in every rank's memory.  point_floats: 4 (16-byte points) or 3 (the compact slots below).
+ * rplgpu_unpack_gathered_dev / _xyi_dev on the root afterwards, as behind the all-gather.
+ * Ordering and fences exactly as rplgpu_allgather_clouds_dev. */
+int32_t rplgpu_gather_clouds_dev(rplgpu_handle_t h, int32_t root, const float *d_points_local,
+                                 uint64_t slot_points, uint32_t point_floats,
+                                 const uint32_t *d_meta_local, uint32_t meta_words,
+                                 float *d_points_all, uint32_t *d_meta_all);
 /* main stream waits (on the device, no host synchronisation) for the last exchange enqueued ... */
 int32_t rplgpu_comm_fence(rplgpu_handle_t h);
 /* ... or for the one `lag` exchanges before it (0 <= lag <= 3): with two arenas used in turn,

@@ -93,6 +93,7 @@ ABI_SYMBOLS = [
     "rplgpu_cloud_meta_words",
     "rplgpu_pack_cloud_meta_dev",
     "rplgpu_allgather_clouds_dev",
+    "rplgpu_gather_clouds_dev",
     "rplgpu_comm_fence",
     "rplgpu_comm_fence_lag",
     "rplgpu_unpack_gathered_dev",
@@ -284,6 +285,7 @@ def load_library() -> C.CDLL:
     lib.rplgpu_cloud_meta_words.restype = u32
     lib.rplgpu_pack_cloud_meta_dev.argtypes = [vp, vp, vp, vp, u32, u64, u32, vp]
     lib.rplgpu_allgather_clouds_dev.argtypes = [vp, vp, u64, vp, u32, vp, vp]
+    lib.rplgpu_gather_clouds_dev.argtypes = [vp, i32, vp, u64, u32, vp, u32, vp, vp]
     lib.rplgpu_comm_fence.argtypes = [vp]
     lib.rplgpu_comm_fence_lag.argtypes = [vp, u32]
     lib.rplgpu_unpack_gathered_dev.argtypes = [vp, vp, u64, vp, u32, u32, u32, vp, vp, vp, vp, vp]
@@ -582,6 +584,13 @@ class RplGpu:
 
     def pack_cloud_xyi_dev(self, d_arena: int, d_cursor: int, slot_points: int, d_slot: int):
         self._check(self._lib.rplgpu_pack_cloud_xyi_dev(self._h, d_arena, d_cursor, slot_points, d_slot))
+
+    def gather_clouds_dev(self, root: int, d_points_local: int, slot_points: int, point_floats: int,
+                          d_meta_local: int, meta_words: int, d_points_all: int = 0, d_meta_all: int = 0):
+        """Gather to one rank (grouped ncclSend / ncclRecv): the all-gather's layout on `root` only."""
+        self._check(self._lib.rplgpu_gather_clouds_dev(
+            self._h, root, d_points_local, slot_points, point_floats, d_meta_local, meta_words,
+            d_points_all, d_meta_all))
 
     def allgather_clouds_xyi_dev(self, d_slot_local: int, slot_points: int, d_meta_local: int,
                                  meta_words: int, d_slots_all: int, d_meta_all: int):

@@ -1892,6 +1892,8 @@ struct RcclApi {
   int (*CommCount)(void *, int *) = nullptr;
   int (*CommUserRank)(void *, int *) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
@@ -1913,6 +1915,8 @@ RcclApi &rccl() {
     a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(a.lib, "ncclCommCount"));
     a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(a.lib, "ncclCommUserRank"));
     a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.lib, "ncclAllGather"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(a.lib, "ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(a.lib, "ncclRecv"));
     a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.lib, "ncclGroupStart"));
     a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.lib, "ncclGroupEnd"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
@@ -2090,6 +2094,68 @@ int32_t allgather_slots(rplgpu_handle_t h, const float *d_points_local, uint64_t
   return RPLGPU_OK;
 }
 }  // namespace
+
+int32_t rplgpu_gather_clouds_dev(rplgpu_handle_t h, int32_t root, const float *d_points_local,
+                                 uint64_t slot_points, uint32_t point_floats,
+                                 const uint32_t *d_meta_local, uint32_t meta_words,
+                                 float *d_points_all, uint32_t *d_meta_all) {
+  if (!h || !d_points_local || !d_meta_local || meta_words == 0 || (point_floats != 3u && point_floats != 4u))
+    return RPLGPU_ERR_INVALID_ARG;
+  if (!h->comm) {
+    h->err = "rplgpu_comm_init has not been called";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
+  if (root < 0 || root >= h->comm_world) return RPLGPU_ERR_INVALID_ARG;
+  if (!rccl().Send || !rccl().Recv) {
+    h->err = "this RCCL has no ncclSend / ncclRecv";
+    return RPLGPU_ERR_NO_DEVICE;
+  }
+  const bool is_root = h->comm_rank == root;
+  if (is_root && (!d_points_all || !d_meta_all)) return RPLGPU_ERR_INVALID_ARG;
+  if (!device_readable(h, d_points_local, "d_points_local") ||
+      !device_readable(h, d_meta_local, "d_meta_local") ||
+      (is_root && (!device_readable(h, d_points_all, "d_points_all") ||
+                   !device_readable(h, d_meta_all, "d_meta_all"))))
+    return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, hipEventRecord(h->ev_main, h->stream));
+  RPL_HIP(h, hipStreamWaitEvent(h->xstream, h->ev_main, 0));
+  const size_t slot_floats = (size_t)slot_points * point_floats;
+  int rs = 0;
+  hipError_t hs = hipSuccess;
+  const int g0 = rccl().GroupStart();
+  if (is_root) {
+    for (int r = 0; r < h->comm_world && rs == 0; ++r) {
+      if (r == root) continue;
+      rs = rccl().Recv(d_meta_all + (size_t)r * meta_words, meta_words, kNcclUint32, r, h->comm, h->xstream);
+      if (rs == 0 && slot_floats)
+        rs = rccl().Recv(d_points_all + (size_t)r * slot_floats, slot_floats, kNcclFloat32, r, h->comm,
+                         h->xstream);
+    }
+  } else {
+    rs = rccl().Send(d_meta_local, meta_words, kNcclUint32, root, h->comm, h->xstream);
+    if (rs == 0 && slot_floats)
+      rs = rccl().Send(d_points_local, slot_floats, kNcclFloat32, root, h->comm, h->xstream);
+  }
+  const int g1 = rccl().GroupEnd();
+  if (is_root) {  // the root's own slot and META block (in place: nothing to move)
+    float *own = d_points_all + (size_t)root * slot_floats;
+    uint32_t *own_meta = d_meta_all + (size_t)root * meta_words;
+    if (own != d_points_local && slot_floats)
+      hs = hipMemcpyAsync(own, d_points_local, slot_floats * 4u, hipMemcpyDeviceToDevice, h->xstream);
+    if (hs == hipSuccess && own_meta != d_meta_local)
+      hs = hipMemcpyAsync(own_meta, d_meta_local, (size_t)meta_words * 4u, hipMemcpyDeviceToDevice,
+                          h->xstream);
+  }
+  // (as in the all-gather: the ring event is recorded whatever happened above)
+  RPL_HIP(h, hipEventRecord(h->ev_x[h->n_exchanges & 3u], h->xstream));
+  ++h->n_exchanges;
+  RPL_NCCL(h, g0);
+  RPL_NCCL(h, rs);
+  RPL_NCCL(h, g1);
+  RPL_HIP(h, hs);
+  return RPLGPU_OK;
+}
 
 int32_t rplgpu_comm_fence_lag(rplgpu_handle_t h, uint32_t lag) {
   if (!h || lag > 3u) return RPLGPU_ERR_INVALID_ARG;

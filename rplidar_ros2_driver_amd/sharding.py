@@ -171,6 +171,41 @@ def unpack_gathered(points_all: torch.Tensor, meta_all: torch.Tensor, slot_point
     return packed, starts, npts, status
 
 
+def gather_slots_to_root(slot: torch.Tensor, meta: torch.Tensor, root: int, group=None):
+    """Twin of ``rplgpu_gather_clouds_dev`` over ``torch.distributed`` (gloo on CPU, RCCL on GPU):
+    every rank's fixed-size slot and META block meet on ``root`` in the layout of the all-gather
+    (rank-major); the other ranks only send and get ``(None, None)``.  One slot per link, into the
+    root — what BASELINE config 5 needs (the fused message is built on one GPU)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if rank == root:
+        slots = [torch.empty_like(slot) for _ in range(world)]
+        metas = [torch.empty_like(meta) for _ in range(world)]
+        dist.gather(slot, slots, dst=root, group=group)
+        dist.gather(meta, metas, dst=root, group=group)
+        return torch.stack(slots), torch.stack(metas)
+    dist.gather(slot, None, dst=root, group=group)
+    dist.gather(meta, None, dst=root, group=group)
+    return None, None
+
+
+def predicted_step_ms(world: int, compute_ms_one_gpu: float, cloud_bytes_total: float, chunks: int,
+                      gather_root: bool = False, link_gbs: float = 76.8) -> float:
+    """DESIGN.md §7's model of a step on `world` GPUs (strong scaling of one batch): every rank
+    computes 1/world of the batch in `chunks` pieces; a piece's exchange starts when the piece is
+    computed and pieces follow one another on the links.  All-gather: a link carries one rank's
+    share of a piece (the links of a rank work in parallel); gather to root: the root's links carry
+    the same (one slot each) but nothing else moves.  Returns milliseconds."""
+    if world <= 1:
+        return compute_ms_one_gpu
+    comp = compute_ms_one_gpu / world / chunks            # one piece on one rank
+    exch = cloud_bytes_total / world / chunks / (link_gbs * 1e6)  # one piece on one link, ms
+    t_c = t_x = 0.0
+    for _ in range(chunks):
+        t_c += comp
+        t_x = max(t_x, t_c) + exch
+    return t_x
+
+
 class CloudExchange:
     """bench.py's N > 1 step through the library's own exchange: the rank's block of scans is cut
     into `chunks`; chunk c is voxelised as 12-byte points (x, y, intensity: z is 0 for every point
@@ -183,7 +218,10 @@ class CloudExchange:
     never overrun), so a timed step has no host synchronisation: counts travel in the META blocks
     on the device."""
 
-    def __init__(self, gpu, dist_mod, dev, world, rank, B, n, out_stride, chunks):
+    def __init__(self, gpu, dist_mod, dev, world, rank, B, n, out_stride, chunks, root=None):
+        # root: None = all-gather (every rank ends up with the whole cloud, BASELINE config 4);
+        # an int = gather to that rank only (rplgpu_gather_clouds_dev, config 5's fused message)
+        self.root = root
         self.gpu, self.dist, self.dev, self.world, self.rank = gpu, dist_mod, dev, world, rank
         self.B, self.n, self.out_stride = B, n, out_stride
         self.chunks = max(1, min(chunks, max(B, 1)))
@@ -285,9 +323,18 @@ class CloudExchange:
             g.comm_fence(0)
 
     def _gather(self, c, mine, meta):
-        if self.native:
+        if self.native and self.root is not None:
+            self.gpu.gather_clouds_dev(self.root, mine.data_ptr(), self.slot, 3, meta.data_ptr(), self.mw,
+                                       self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
+        elif self.native:
             self.gpu.allgather_clouds_xyi_dev(mine.data_ptr(), self.slot, meta.data_ptr(), self.mw,
                                               self.recv_pts[c].data_ptr(), self.recv_meta[c].data_ptr())
+        elif self.root is not None:
+            self.gpu.synchronize()
+            slots, metas = gather_slots_to_root(mine.reshape(-1).clone(), meta.reshape(-1).clone(), self.root)
+            if slots is not None:
+                self.recv_pts[c].view(self.world, -1).copy_(slots)
+                self.recv_meta[c].view(self.world, -1).copy_(metas)
         else:  # fallback: torch.distributed on torch's current stream — the handle's stream (which
             # the kernels above were queued on) must be drained first; a send copy to be safe
             self.gpu.synchronize()
@@ -303,6 +350,8 @@ class CloudExchange:
 
     def last_bytes(self):
         """bytes this rank RECEIVES from its peers per step"""
+        if self.root is not None and self.rank != self.root:
+            return 0
         return int(self.chunks * (self.world - 1) * (self.slot or 0) * 12)
 
     def unpack(self, c, d_packed, d_total, d_start_all, d_np_all, d_status=0):

@@ -105,6 +105,21 @@ def main():
         import cdr_oracle as cdr
         ml = int(d_ml.item())
         assert d_msg.cpu().numpy()[:ml].tobytes() == cdr.cloud_msg(FID, 5, 6, ga[: int(d_total.item())])
+        # gather to ONE rank (rplgpu_gather_clouds_dev, grouped ncclSend / ncclRecv): the last rank is
+        # the root; what it receives must be what the all-gather gave it, the others pass no buffers
+        root = world - 1
+        g_pts = torch.full((world, slot, 4), -5.0, dtype=torch.float32, device=dev) if rank == root else None
+        g_meta = torch.zeros(world, mw, dtype=torch.int32, device=dev) if rank == root else None
+        gpu.gather_clouds_dev(root, mine["arena"].data_ptr(), slot, 4, d_meta.data_ptr(), mw,
+                              g_pts.data_ptr() if rank == root else 0,
+                              g_meta.data_ptr() if rank == root else 0)
+        gpu.comm_fence()
+        gpu.synchronize()
+        if rank == root:
+            assert torch.equal(g_meta, d_meta_all)
+            for r in range(world):
+                k = int(d_meta_all[r, 0].item())
+                assert torch.equal(g_pts[r, :k], d_pts_all[r, :k]), r
         gpu.comm_destroy()
     ok = torch.ones(1, dtype=torch.int32, device=dev)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)

@@ -283,3 +283,72 @@ def test_chunked_overlapped_exchange_equals_plain_launch():
             ex.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_gather_to_root_single_rank_equals_allgather():
+    """rplgpu_gather_clouds_dev (grouped ncclSend / ncclRecv, SURVEY.md §8(e)'s gather-to-root for the
+    fused message of BASELINE config 5) with ONE rank: the root's own slot is a device copy — or
+    nothing at all when the slot already is its place in the receive buffer — and the result is the
+    all-gather's, for 16-byte and for 12-byte points.  (Two ranks: tests/test_gpu2_rccl.py.)"""
+    import torch
+    dev = torch.device("cuda:0")
+    S, n = 4, 8000
+    batch = synth.make_batch(61, S, n)
+    p = Params.defaults(clip_enable=1, range_max=40.0, voxel_enable=1)
+    prev_stream = torch.cuda.current_stream(dev)
+    with RplGpu(device=0, max_samples_per_scan=32768, max_batch=S) as gpu, _restore_stream(torch, prev_stream):
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        gpu.set_stream(stream.cuda_stream)
+        slot = S * 4096
+        mw = abi.cloud_meta_words(S)
+        t = _arena(gpu, torch, dev, batch, p, slot)
+        d_meta = torch.zeros(mw, dtype=torch.int32, device=dev)
+        gpu.pack_cloud_meta_dev(t["cur"].data_ptr(), t["start"].data_ptr(), t["npts"].data_ptr(), S,
+                                slot, S, d_meta.data_ptr())
+        # without a communicator the call is refused
+        with pytest.raises(Exception):
+            gpu.gather_clouds_dev(0, t["arena"].data_ptr(), slot, 4, d_meta.data_ptr(), mw,
+                                  t["arena"].data_ptr(), d_meta.data_ptr())
+        gpu.comm_init(0, 1, RplGpu.comm_unique_id())
+        a_pts = torch.full((slot, 4), -9.0, dtype=torch.float32, device=dev)
+        a_meta = torch.zeros(mw, dtype=torch.int32, device=dev)
+        gpu.allgather_clouds_dev(t["arena"].data_ptr(), slot, d_meta.data_ptr(), mw, a_pts.data_ptr(),
+                                 a_meta.data_ptr())
+        g_pts = torch.full((slot, 4), -5.0, dtype=torch.float32, device=dev)
+        g_meta = torch.zeros(mw, dtype=torch.int32, device=dev)
+        gpu.gather_clouds_dev(0, t["arena"].data_ptr(), slot, 4, d_meta.data_ptr(), mw, g_pts.data_ptr(),
+                              g_meta.data_ptr())
+        gpu.comm_fence()
+        gpu.synchronize()
+        assert torch.equal(a_pts, g_pts) and torch.equal(a_meta, g_meta) and torch.equal(g_meta, d_meta)
+        # in place (the slot IS the root's place in the receive buffer): nothing moves, nothing breaks
+        before = t["arena"].clone()
+        gpu.gather_clouds_dev(0, t["arena"].data_ptr(), slot, 4, d_meta.data_ptr(), mw,
+                              t["arena"].data_ptr(), d_meta.data_ptr())
+        gpu.comm_fence()
+        gpu.synchronize()
+        assert torch.equal(before, t["arena"])
+        # 12-byte points
+        d_slot = torch.zeros(slot, 3, dtype=torch.float32, device=dev)
+        gpu.pack_cloud_xyi_dev(t["arena"].data_ptr(), t["cur"].data_ptr(), slot, d_slot.data_ptr())
+        g3 = torch.full((slot, 3), -5.0, dtype=torch.float32, device=dev)
+        gpu.gather_clouds_dev(0, d_slot.data_ptr(), slot, 3, d_meta.data_ptr(), mw, g3.data_ptr(),
+                              g_meta.data_ptr())
+        gpu.comm_fence()
+        d_packed = torch.zeros(slot, 4, dtype=torch.float32, device=dev)
+        d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_sa = torch.zeros(S, dtype=torch.int64, device=dev)
+        d_na = torch.zeros(S, dtype=torch.int32, device=dev)
+        gpu.unpack_gathered_xyi_dev(g3.data_ptr(), slot, g_meta.data_ptr(), mw, 1, S, d_packed.data_ptr(),
+                                    d_total.data_ptr(), d_sa.data_ptr(), d_na.data_ptr(), 0)
+        gpu.synchronize()
+        total = int(t["cur"].item())
+        assert int(d_total.item()) == total
+        assert d_packed[:total].cpu().numpy().tobytes() == t["arena"][:total].cpu().numpy().tobytes()
+        # a root outside the communicator, a point size that does not exist
+        for bad in ((1, 4), (-1, 4), (0, 5)):
+            with pytest.raises(Exception):
+                gpu.gather_clouds_dev(bad[0], t["arena"].data_ptr(), slot, bad[1], d_meta.data_ptr(), mw,
+                                      g_pts.data_ptr(), g_meta.data_ptr())
+        gpu.comm_destroy()

@@ -190,6 +190,16 @@ def _c5_worker(rank, world, port, per_rank, n, q):
             s12_all.view(world, slot, 3).numpy(), slot, meta_all.numpy().view(np.uint32), world, per_rank)
         ok = ok and packed12.tobytes() == packed_np.tobytes() and np.array_equal(st12, st_np) \
             and np.array_equal(np12, npn_np) and int(status12.sum()) == 0
+        # gather to ONE rank (rplgpu_gather_clouds_dev's layout: the all-gather's, on the root only)
+        root = world - 1
+        g_slots, g_metas = sh.gather_slots_to_root(slot12.reshape(-1), meta, root)
+        if rank == root:
+            gp, gs, gn, gst = abi.unpack_gathered_host(
+                g_slots.view(world, slot, 3).numpy(), slot, g_metas.numpy().view(np.uint32), world, per_rank)
+            ok = ok and gp.tobytes() == packed_np.tobytes() and np.array_equal(gs, st_np) \
+                and np.array_equal(gn, npn_np) and int(gst.sum()) == 0
+        else:
+            ok = ok and g_slots is None and g_metas is None
         # per-sensor transform into the common frame, then one serialised PointCloud2
         fused = packed.numpy().copy()
         for r in range(world):
