@@ -55,17 +55,23 @@ def static_traffic(kernel: str, B: int, n: int):
     # the record names the kernel source it was measured on: a kernel edited since then gets no
     # traffic figure (re-run tools/prof.sh) instead of the old one
     want = ent.get("source_sha256")
-    have = source_sha256(ent.get("source_file", "rplidar_ros2_driver_amd/csrc/rpl_voxel.hip"))
+    have = source_sha256(ent.get("source_files") or [ent.get("source_file",
+                                                              "rplidar_ros2_driver_amd/csrc/rpl_voxel.hip")])
     if not want or want != have:
         return None, "stale: profiles/traffic.json was measured on another state of the kernel source " \
                      f"(recorded {str(want)[:12]}, now {str(have)[:12]}); re-run tools/prof.sh"
     return int(ent["hbm_bytes_per_launch"]), "static: " + str(ent.get("source"))
 
 
-def source_sha256(rel: str):
+def source_sha256(rels):
+    """one digest over the kernel's source file and what sets its launch geometry and store sizing
+    (rpl_device.hpp, rpl_launch.hpp, rplgpu_api.hip: tools/prof_summary.py lists them per kernel)"""
     import hashlib
+    h = hashlib.sha256()
     try:
-        return hashlib.sha256((ROOT / rel).read_bytes()).hexdigest()
+        for rel in rels:
+            h.update((ROOT / rel).read_bytes())
+        return h.hexdigest()
     except Exception:
         return None
 

@@ -60,6 +60,9 @@ extern "C" {
 #define RPLGPU_SCAN_CELL_RANGE 0x2u    /* voxel: |cell index| >= 32767 (range/leaf too large) */
 #define RPLGPU_SCAN_TABLE_FULL 0x4u    /* voxel: more occupied cells than the on-chip table holds */
 #define RPLGPU_SCAN_OUT_TRUNCATED 0x8u /* output region (out_stride) too small; count is clamped */
+#define RPLGPU_SCAN_NOT_PRODUCED 0x80u /* voxel, pipelined two-kernel form only: the item's run records
+                                          never arrived (the producer kernel did not run next to the
+                                          consumer, e.g. serialised queues); the item is EMPTY (0 points) */
 /* per-stream status bits of the decode stage */
 #define RPLGPU_STREAM_UNFRAMED 0x10u         /* frames given back to back but a frame does not start
                                                  with its sync pattern: run rplgpu_frame_stream */
@@ -329,10 +332,13 @@ int32_t rplgpu_set_cell_key_output(rplgpu_handle_t h, uint32_t *d_cell_keys);
  * run of samples in one cell (clean rings: ~14 records per block).  TWO_CLASS lets a block that
  * would make more than 26 records be aggregated in the two colours of a checkerboard of cells
  * instead (range noise makes neighbouring samples alternate between two cells: 8 700 -> 6 200
- * records per 32 000-sample scan at 1 cm), at 1.5-2.7 % on clean data.  AUTO (the default) picks
- * per batch launch from the records per scan the handle's PREVIOUS batch launch made — i.e. the
- * choice, and with it the time of a launch, depends on the launch before it; a caller who wants
- * timing independent of history (or knows its sensor) pins PLAIN or TWO_CLASS. */
+ * records per 32 000-sample scan at 1 cm), at 1.5-2.7 % on clean data.  AUTO (the default) decides
+ * per batch launch from the records per scan THIS batch made the last time the handle launched it
+ * (same device buffer, stride, scan count and group size: the statistics follow every launch to
+ * pinned memory); a batch the handle has not launched before runs PLAIN.  So the first launch over
+ * a noisy batch is the slow one and repeated launches (a bench loop, a sensor's frames arriving in
+ * one staging buffer) converge after one; no other batch's history enters.  A caller who knows its
+ * sensor pins PLAIN or TWO_CLASS. */
 #define RPLGPU_VOXEL_AGG_AUTO 0
 #define RPLGPU_VOXEL_AGG_PLAIN 1
 #define RPLGPU_VOXEL_AGG_TWO_CLASS 2

@@ -28,6 +28,10 @@
 // host (dataunpacker.cpp:164-166), not with anything in the stream.
 #include <type_traits>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "rpl_device.hpp"
 #include "rpl_launch.hpp"
 
@@ -1725,6 +1729,9 @@ __global__ __launch_bounds__(kDecBlock) void k_assemble(
         else cout[e] = e < from_c ? cin[e] : in[from + (e - from_c)];
       }
       cy.len_out[b] = full;
+      // (the open scan did not fit the carry buffer — only possible when carry_stride is smaller than
+      // the scan cap: the next call's first scan will be shorter than ScanDataHolder's, and says so)
+      if (total > full && ccap < max_count && status) atomicOr(&status[b], (uint32_t)RPLGPU_SCAN_OUT_TRUNCATED);
     }
   }
   if (tid == 0) {
@@ -1817,9 +1824,26 @@ static hipError_t launch_decode_staged(hipStream_t s, int ans, const uint8_t *by
   auto go = [&](auto kfn, uint32_t nt, bool fits, uint32_t mf_cap) -> hipError_t {
     if (!fits) return hipSuccess;
     const DecStageLayout lay = dec_stage_layout(ans, max_frames < mf_cap ? max_frames : mf_cap);
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
-    if (e != hipSuccess) return e;
+    // The attribute is per kernel FUNCTION and process-wide: set with a call's own size, two handles
+    // decoding on two host threads could interleave set(large) set(small) launch(large), and the
+    // launch would fail.  It is set ONCE per instance and device, to the most any call of the
+    // instance can ask for (the staged frame count of the answer type); a launch passes its own size.
+    {
+      static std::mutex mu;
+      static std::set<std::pair<const void *, int>> done_for;
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      std::lock_guard<std::mutex> lk(mu);
+      const auto key = std::make_pair(reinterpret_cast<const void *>(kfn), dev);
+      if (!done_for.count(key)) {
+        const DecStageLayout most = dec_stage_layout(ans, decode_staged_frames(ans));
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)(most.total > lay.total ? most.total : lay.total));
+        if (e != hipSuccess) return e;
+        done_for.insert(key);
+      }
+    }
     hipLaunchKernelGGL(kfn, dim3(B), dim3(nt), lay.total, s, bytes, stream_stride,
                        frame_off, gap, n_frames, max_frames,
                        sample_duration_us, state_in, state_out, nodes, node_stride, n_nodes, reset_at,

@@ -1438,11 +1438,19 @@ __attribute__((amdgpu_waves_per_eu(RPL_CELLS_WAVES_PER_EU, RPL_CELLS_WAVES_PER_E
           __builtin_amdgcn_s_sleep(32);
           if (wall_clock64() - t_in > 200000000ull) { late = true; break; }  // 2 s
         }
-        if (late) atomicOr(&L.misc[1], (uint32_t)RPLGPU_SCAN_TABLE_FULL);
+        // (late: the regions may be unfinished, or hold an earlier stage's entries — nothing of them
+        // is used: the item comes out EMPTY and says why, instead of a plausible wrong cloud)
+        if (late) atomicOr(&L.misc[1], (uint32_t)RPLGPU_SCAN_NOT_PRODUCED);
+        L.tmp[30] = late ? 1u : 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (p.dbg) p.dbg[16 * (item0 + bl) + 1] = wall_clock64();  // ... saw the item ready
       }
       __syncthreads();
+      if (L.tmp[30]) {  // block-uniform
+        __syncthreads();
+        if (threadIdx.x == 0) L.misc[0] = 0u;  // an empty queue: no records, no cells
+        return;
+      }
     }
     const uint2 *rc = rcount + (size_t)bl * qn;
     const uint4 *RG = regions + (size_t)bl * qn * kRegionCap;

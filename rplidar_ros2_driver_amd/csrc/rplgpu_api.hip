@@ -24,6 +24,15 @@
 #include "rpl_msg.hpp"
 #include "rpl_comm_layout.hpp"
 
+// which batch the voxel queue statistics in pinned memory describe (voxel_split_for)
+struct VoxelBatchId {
+  const void *nodes = nullptr;
+  uint32_t n_stride = 0, B = 0, group = 0;
+  bool operator==(const VoxelBatchId &o) const {
+    return nodes == o.nodes && n_stride == o.n_stride && B == o.B && group == o.group;
+  }
+};
+
 struct rplgpu_ctx {
   int device = -1;
   hipStream_t own_stream = nullptr;
@@ -60,6 +69,8 @@ struct rplgpu_ctx {
   unsigned long long *h_vstats = nullptr;
   bool voxel_split = false;
   uint32_t stats_group = 1;           // scans per work item of the launch the statistics come from
+  bool stats_valid = false;           // ... and which batch that launch was over (voxel_split_for)
+  VoxelBatchId stats_id;
   uint32_t n_cu = 0;                  // compute units of `device`
   void *d_vstore = nullptr;           // k_cloud_voxel record stores (one per resident workgroup)
   // the two-kernel voxel path's region store (k_voxel_runs -> k_voxel_cells), allocated by the
@@ -188,23 +199,39 @@ rpl::KParams to_kparams(const rplgpu_params_t &p) {
   return k;
 }
 
-// Which instance of k_cloud_voxel the next launch uses: the one whose blocks may be aggregated in
+// Which instance of k_cloud_voxel a batch launch uses: the one whose blocks may be aggregated in
 // two classes pays off when scans make many short runs (range noise), and costs a clean batch
-// 1.5-2.7 %.  The decision follows the queue entries per work item of the handle's PREVIOUS launch
-// (copied to pinned memory behind it, read here without waiting: a stale or torn value only picks
-// the other instance once — the results are the same either way).
-void refresh_voxel_mode(rplgpu_ctx *c) {
-  if (!c->h_vstats) return;
-  const unsigned long long entries = __atomic_load_n(&c->h_vstats[0], __ATOMIC_RELAXED);
-  const unsigned long long items = __atomic_load_n(&c->h_vstats[1], __ATOMIC_RELAXED);
-  if (items == 0 || entries > items * 70000ull) return;
-  const unsigned long long avg = entries / (items * std::max(1u, c->stats_group));  // per scan, not per work item
-  if (!c->voxel_split && avg > 6500ull) c->voxel_split = true;       // (a clean C3 scan: ~3300)
-  else if (c->voxel_split && avg < 4000ull) c->voxel_split = false;  // (1 cm noise, split: ~6200)
+// 1.5-2.7 %.  RPLGPU_VOXEL_AGG_AUTO decides from THIS batch's own statistics: the queue entries per
+// scan that the previous launch over the SAME batch (same device buffer, stride, scan count and
+// group size) left in pinned memory behind it (read here without waiting: a stale or torn value
+// only picks the other instance once — the results are the same either way).  A batch the handle
+// has not launched before — another buffer or another shape — runs the plain instance; what an
+// unrelated earlier batch looked like decides nothing (round 4: it did).
+bool voxel_split_for(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride, uint32_t B, uint32_t group) {
+  group = std::max(1u, std::min(group, std::max(B, 1u)));
+  const VoxelBatchId id{d_nodes, n_stride, B, group};
+  const bool with_stats = c->h_vstats && (B + group - 1u) / group >= 64u;  // (launch_cloud_voxel's rule)
+  bool split = false;
+  if (c->h_vstats && c->stats_valid && c->stats_id == id) {
+    const unsigned long long entries = __atomic_load_n(&c->h_vstats[0], __ATOMIC_RELAXED);
+    const unsigned long long items = __atomic_load_n(&c->h_vstats[1], __ATOMIC_RELAXED);
+    split = c->voxel_split;
+    if (items != 0 && entries <= items * group * 70000ull) {  // (sanity: a torn or stale pair)
+      const unsigned long long avg = entries / (items * group);  // per scan, not per work item
+      if (!split && avg > 6500ull) split = true;        // (a clean C3 scan: ~3300)
+      else if (split && avg < 4000ull) split = false;   // (1 cm noise, two classes: ~6200)
+    }
+  }
+  if (with_stats) {  // this launch's statistics will describe `id`
+    c->stats_id = id;
+    c->stats_valid = true;
+    c->voxel_split = split;
+    c->stats_group = group;
+  }
+  return c->force_split >= 0 ? c->force_split != 0 : split;
 }
 
 rpl::Tables tables_of(rplgpu_ctx *c) {
-  refresh_voxel_mode(c);
   rpl::Tables t;
   t.angle = c->d_angle;
   t.angle_inv = c->d_angle_inv;
@@ -218,7 +245,7 @@ rpl::Tables tables_of(rplgpu_ctx *c) {
   t.voxel_store_recs = c->vstore_recs;
   t.voxel_stats = reinterpret_cast<unsigned long long *>(c->d_small + 24);  // [24..27]
   t.voxel_stats_host = c->h_vstats;
-  t.voxel_split = c->force_split >= 0 ? c->force_split : (c->voxel_split ? 1 : 0);
+  t.voxel_split = c->force_split > 0 ? 1 : 0;  // (batch launches: voxel_split_for)
   t.voxel_regions = c->d_regions;
   t.voxel_rcount = c->d_rcount;
   t.voxel_region_cap = c->region_cap;
@@ -836,8 +863,8 @@ static int32_t cloud_arena_impl(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
   if ((rc = ensure_regions(h, B, 1u, n_stride))) return rc;
   RPL_HIP(h, hipMemsetAsync(d_cursor, 0, 8, h->stream));
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "64-bit cursor");
-  const rpl::Tables T_arena = tables_of(h);
-  if (B >= 64u) h->stats_group = 1u;
+  rpl::Tables T_arena = tables_of(h);
+  T_arena.voxel_split = voxel_split_for(h, d_nodes, n_stride, B, 1u) ? 1 : 0;
   RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
                                      T_arena, mask, kMaskStride, nullptr, 0, d_n_points,
                                      d_status, d_arena, arena_capacity,
@@ -908,8 +935,8 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
   if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
   if ((rc = ensure_regions(h, B, group, n_stride))) return rc;
   RPL_HIP(h, hipMemsetAsync(d_cursor, 0, 8, h->stream));
-  const rpl::Tables T_fused = tables_of(h);  // (reads the previous launch's statistics: before stats_group changes)
-  if ((B + group - 1u) / group >= 64u) h->stats_group = group;
+  rpl::Tables T_fused = tables_of(h);
+  T_fused.voxel_split = voxel_split_for(h, d_nodes, n_stride, B, group) ? 1 : 0;
   RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
                                      T_fused, mask, kMaskStride, nullptr, 0, d_n_points,
                                      d_status, d_arena, arena_capacity,
@@ -930,7 +957,9 @@ int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
   const uint32_t *mask = nullptr;
   if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
   if (p->voxel_enable && (rc = ensure_regions(h, B, 1u, n_stride))) return rc;
-  RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, tables_of(h),
+  rpl::Tables T_batch = tables_of(h);
+  if (p->voxel_enable) T_batch.voxel_split = voxel_split_for(h, d_nodes, n_stride, B, 1u) ? 1 : 0;
+  RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, T_batch,
                                p->voxel_enable != 0, mask, kMaskStride, d_xyzi, out_stride,
                                d_n_points, d_status));
   return RPLGPU_OK;

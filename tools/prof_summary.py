@@ -41,19 +41,25 @@ import json
 import os
 import hashlib
 # the state of the kernel sources the counters were measured on (bench.py refuses a traffic figure
-# whose kernel source changed since): voxel kernels <-> rpl_voxel.hip, the others <-> their file
+# whose sources changed since): the kernel's own file AND what sets its launch geometry, its store
+# sizing and its device helpers — rpl_device.hpp, rpl_launch.hpp, rplgpu_api.hip (round 4 keyed on
+# the kernel file alone: a change of the launcher could change the traffic unnoticed)
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SRC = {"k_cloud_voxel": "rpl_voxel.hip", "k_voxel_runs": "rpl_voxel.hip", "k_voxel_cells": "rpl_voxel.hip",
         "k_ascend_stream": "rpl_kernels.hip", "k_ascend": "rpl_kernels.hip", "k_laserscan_a": "rpl_laserscan.hip",
         "k_ror_mask": "rpl_ror.hip", "k_decode": "rpl_decode.hip"}
+_COMMON = ["rpl_device.hpp", "rpl_launch.hpp", "rplgpu_api.hip"]
 
 
 def _sha(name):
-    rel = "rplidar_ros2_driver_amd/csrc/" + _SRC.get(name, "rpl_voxel.hip")
+    files = ["rplidar_ros2_driver_amd/csrc/" + f for f in [_SRC.get(name, "rpl_voxel.hip")] + _COMMON]
+    h = hashlib.sha256()
     try:
-        return rel, hashlib.sha256(open(os.path.join(_ROOT, rel), "rb").read()).hexdigest()
+        for rel in files:
+            h.update(open(os.path.join(_ROOT, rel), "rb").read())
+        return files, h.hexdigest()
     except OSError:
-        return rel, None
+        return files, None
 
 
 traffic = {}
@@ -69,7 +75,7 @@ for k, d in agg.items():
             "scans": int(os.environ.get("RPL_PROF_SCANS", "4096")),
             "samples_per_scan": int(os.environ.get("RPL_PROF_SAMPLES", "32000")),
             "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (tools/prof.sh), FETCH x2 gfx950 correction",
-            "source_file": _sha(name)[0], "source_sha256": _sha(name)[1],
+            "source_files": _sha(name)[0], "source_sha256": _sha(name)[1],
         }
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print("== traffic.json:", json.dumps({k: v["hbm_bytes_per_launch"] for k, v in traffic.items()}))
