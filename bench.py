@@ -844,6 +844,23 @@ def main():
         variants["ring_clean_q_min48"] = regime(gpu, dev, stream, "q", batch_np, pq, d_arena, d_cursor,
                                                 d_start, d_np, d_st, vreps)
         big_arena = torch.empty(B * n, 4, dtype=torch.float32, device=dev) if B * n * 16 < 8e9 else d_arena
+        if big_arena is not d_arena:
+            # the UNVOXELISED cloud of the same batch (E1 + E2 + E3: k_cloud, rplgpu_cloud_batch_dev):
+            # 8 B read + 16 B written per kept sample
+            pc = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0)
+
+            def plain_cloud():
+                gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, pc, big_arena.data_ptr(), n,
+                                    d_np.data_ptr(), d_st.data_ptr())
+            ms_pc = timed(plain_cloud, stream, vreps, lambda: torch.cuda.synchronize(dev))
+            pts_pc = int(d_np.to(torch.int64).sum().item())
+            variants["plain_cloud_no_voxel"] = {
+                "ms": round(ms_pc, 4), "gpts_s": round(B * n / ms_pc / 1e6, 1), "points": pts_pc,
+                "frac": round((8 * B * n + 16 * pts_pc) / (ms_pc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_read": round(8 * B * n / (ms_pc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "status_bits": int(d_st.max().item()),
+                "note": "k_cloud: the same batch without the voxel grid, one 16-byte point per kept sample "
+                        "in its scan's region (write bound: 1.9 GB out for 1.05 GB in)"}
         for name, kw in (("ring_noise_1cm", dict(noise_m=0.01)), ("uniform", dict(kind="uniform"))):
             vb = synth.make_batch(args.seed, B, n, **kw)
             variants[name] = regime(gpu, dev, stream, name, vb, params, big_arena, d_cursor, d_start,

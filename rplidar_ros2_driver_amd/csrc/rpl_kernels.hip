@@ -728,6 +728,13 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_raw(
 
 // ------------------------------------------------------------------------------
 // k_cloud — E1 keep mask + E2 polar->XYZ, stable compaction in input order
+// (Round 5 measured it on the C3 batch for the first time: 0.63-0.645 ms per 4096 x 32 000 samples,
+// 118.6 M points out = 8 B read + 14.5 B written per sample at 4.6 TB/s, 0.57-0.585 of the 8 TB/s
+// roofline, i.e. 73 % of the chip's copy rate: write bound.  A streaming form — 256-thread
+// workgroups, a running count, chunk counts through LDS, points staged through a wave-private LDS
+// tile so that every store instruction writes 64 consecutive points — was built, parity green, and
+// measured 0.652-0.668 ms: no gain over holding the scan in registers, removed.  Its first version
+// let lane l store its own two samples, i.e. every other 16-byte point per instruction: 1.36 ms.)
 // ------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_cloud(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,

@@ -948,3 +948,77 @@ def test_ascend_wrap_zone(gpu, oracle):
             assert asc[b, lens[b]:].tobytes() == batch[b, lens[b]:].tobytes()
             moved_front += int(got["dist_mm_q2"][0] == 0 and src["dist_mm_q2"][0] != 0)
         assert moved_front >= 5  # the cases really exercise the wrap
+
+
+# ------------------------------------------------------------- the plain cloud of a batch (E1 + E2)
+def test_plain_cloud_batch(gpu, oracle):
+    """The unvoxelised cloud of a batch (k_cloud) against the oracle, bit for bit: ragged lengths
+    (0, 1, odd, chunk-sized, 32 000), inversion, the quality / range clip, the E5 mask in front
+    (ror_enable), the E6 de-skew, a region too small for the cloud (truncated and flagged), and a
+    sub-batch giving the same bytes as the whole one."""
+    import sys
+    sys.path.insert(0, str(oracle_lib.ROOT / "oracle"))
+    import fusion_oracle as fo
+    torch = _torch()
+    B, n = 24, 32000
+    batch = synth.make_batch(515, B, n, jitter=2)
+    batch[7] = synth.make_scan(515, 7, n, kind="uniform")
+    lens = np.array([n, 0, 1, 2, 127, 128, 129, 2047, 2048, 2049, 4097, 31999] + [n - 311 * b for b in range(12)],
+                    np.uint32)
+    dev = torch.device("cuda:0")
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8).copy()).to(dev)
+    d_len = torch.from_numpy(lens.astype(np.int32)).to(dev)
+    d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    for kw in (dict(), dict(inverted=1, is_new_protocol=1), dict(clip_enable=1, q_min=40, range_min=0.5, range_max=20.0),
+               dict(clip_enable=1, range_max=40.0, ror_enable=1, ror_radius=0.05, ror_min_neighbors=2)):
+        if kw.get("ror_enable"):  # (the oracle's ROR is quadratic: short scans only)
+            sub = np.minimum(lens, 3000).astype(np.uint32)
+            sub[sub == 2049] = 2049
+        else:
+            sub = lens
+        d_sub = torch.from_numpy(sub.astype(np.int32)).to(dev)
+        p = Params.defaults(**kw)
+        d_xyzi = torch.full((B, n, 4), -1.0, dtype=torch.float32, device=dev)
+        gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_sub.data_ptr(), B, p, d_xyzi.data_ptr(), n,
+                            d_np.data_ptr(), d_st.data_ptr())
+        gpu.synchronize()
+        got, npts = d_xyzi.cpu().numpy(), d_np.cpu().numpy()
+        assert np.all(d_st.cpu().numpy() == 0)
+        for b in range(B):
+            want = oracle.scan_to_cloud(batch[b, : sub[b]], oracle_lib.copy_params(p))
+            assert npts[b] == len(want), (kw, b)
+            assert got[b, : npts[b]].tobytes() == want.tobytes(), (kw, b)
+            assert np.all(got[b, npts[b]:] == -1.0), (kw, b)  # nothing written past the cloud
+        # a sub-batch gives the same bytes
+        d_x8 = torch.full((8, n, 4), -1.0, dtype=torch.float32, device=dev)
+        gpu.cloud_batch_dev(d_nodes.data_ptr() + 8 * n * 8, n, d_sub.data_ptr() + 8 * 4, 8, p,
+                            d_x8.data_ptr(), n, d_np.data_ptr(), d_st.data_ptr())
+        gpu.synchronize()
+        assert d_x8.cpu().numpy().tobytes() == got[8:16].tobytes(), kw
+    # a region that is too small: cut at out_stride, flagged, nothing beyond it written
+    p = Params.defaults()
+    d_small = torch.full((B, 1000, 4), -1.0, dtype=torch.float32, device=dev)
+    gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_small.data_ptr(), 1000,
+                        d_np.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    sm, npts, st = d_small.cpu().numpy(), d_np.cpu().numpy(), d_st.cpu().numpy()
+    for b in range(B):
+        want = oracle.scan_to_cloud(batch[b, : lens[b]], oracle_lib.copy_params(p))
+        assert npts[b] == min(len(want), 1000)
+        assert (st[b] & abi.SCAN_OUT_TRUNCATED != 0) == (len(want) > 1000)
+        assert sm[b, : npts[b]].tobytes() == want[: npts[b]].tobytes()
+    # E6 de-skew in the streaming kernel
+    motion = np.tile(np.array([[1.5, -0.7, 0.9, 2.0e-5]], np.float32), (B, 1))
+    motion[0] = 0
+    d_motion = torch.from_numpy(motion).to(dev)
+    d_xyzi = torch.zeros(B, n, 4, dtype=torch.float32, device=dev)
+    gpu.cloud_deskew_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_motion.data_ptr(),
+                               d_xyzi.data_ptr(), n, d_np.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    got, npts = d_xyzi.cpu().numpy(), d_np.cpu().numpy()
+    for b in (0, 3, 7, 11, 23):
+        nodes = batch[b, : lens[b]]
+        plain = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(p))
+        want = fo.deskew_cloud(plain, np.flatnonzero(nodes["dist_mm_q2"] != 0), motion[b])
+        assert npts[b] == len(want) and got[b, : npts[b]].tobytes() == want.tobytes(), b
