@@ -750,7 +750,8 @@ def main():
         asc = {"uniform_angles": ascend_row(d_nodes, B, res["ascend"])}
         asc["uniform_angles"]["note"] = "the headline batch: exactly uniform angle words, the fill pass " \
             "recomputes the word already there and nothing needs the sort — the best case"
-        Bv = min(B, 1024)
+        Bv = B  # (round 5: the regimes at the full batch, like the headline row — rounds 3-4 used 1024 scans,
+        # where ramp-up and tail of the launch weigh four times as much)
         for name, jit, note in (
                 ("jitter1", 1, "valid samples' angle words jittered by +-1 (step 2.05): every filled word "
                                "differs from the stored one (8-byte stores), the order survives"),

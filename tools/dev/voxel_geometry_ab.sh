@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 5, call a: geometry variants of the fused voxel kernel on one box (tools/dev/vbench.py per library and data set)
-R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; O=$R/gpurun_out/r5a; mkdir -p $O; export RPL_SYNTH_CACHE=/tmp/rplc
+# geometry variants of the fused voxel kernel on one box (tools/dev/vbench.py per library and data set)
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; O=$R/gpurun_out/voxel_geometry_ab; mkdir -p $O; export RPL_SYNTH_CACHE=/tmp/rplc
 LIB=$R/rplidar_ros2_driver_amd/lib
 run() { # tag env...
   local v=$1; shift
