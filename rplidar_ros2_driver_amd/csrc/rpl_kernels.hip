@@ -512,11 +512,12 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
   constexpr int kDeep = 4;  // loads in flight per thread
   constexpr uint32_t kTrip = (uint32_t)kDeep * kAscT;  // pairs per trip of the workgroup
-  // The chunks are taken from the END of the scan to its front: with W > 0 a node is written W places
-  // above where it was read, i.e. into places that were read in this trip (after the barrier below)
-  // or in an earlier one.
-  for (uint32_t trip = (npairs + kTrip - 1u) / kTrip; trip-- > 0u;) {
-    const uint32_t base = trip * kTrip;
+  // With W > 0 the chunks are taken from the END of the scan to its front: a node is written W
+  // places above where it was read, i.e. into places that were read in this trip (after the barrier
+  // below) or in an earlier one.  (Front to end otherwise.)
+  const uint32_t ntrips = (npairs + kTrip - 1u) / kTrip;
+  for (uint32_t t = 0; t < ntrips; ++t) {
+    const uint32_t base = (W ? ntrips - 1u - t : t) * kTrip;
     uint4 w[kDeep];
 #pragma unroll
     for (int k = 0; k < kDeep; ++k) w[k] = load_pair(base + (uint32_t)k * kAscT + threadIdx.x);
