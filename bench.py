@@ -172,12 +172,23 @@ def dry_run(args, world, rank):
         all_pts.view(world, slot, 3).numpy(), slot, all_meta.numpy().view(np.uint32), world, per_rank)
     want = np.concatenate([cloud(r)[1] for r in range(world)])
     ok = packed.tobytes() == want.tobytes() and int(status.sum()) == 0 and int(npts.sum()) == len(want)
+    if args.exchange == "gather":  # the gather to root (rplgpu_gather_clouds_dev's layout): rank 0 only
+        from rplidar_ros2_driver_amd.sharding import gather_slots_to_root
+        g_slots, g_meta = gather_slots_to_root(torch.from_numpy(mine).view(-1),
+                                               torch.from_numpy(meta.view(np.int32).copy()), 0)
+        if rank == 0:
+            gp, _, gn, gs = abi.unpack_gathered_host(g_slots.view(world, slot, 3).numpy(), slot,
+                                                     g_meta.numpy().view(np.uint32), world, per_rank)
+            ok = ok and gp.tobytes() == want.tobytes() and int(gs.sum()) == 0 and int(gn.sum()) == len(want)
+        else:
+            ok = ok and g_slots is None
     t = torch.tensor([int(ok)])
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "ok": bool(int(t.item())),
-                          "points": int(len(packed)), "exchange_backend": "gloo (dry run, host layout entry points)"}))
+                          "points": int(len(packed)), "exchange": args.exchange,
+                          "exchange_backend": "gloo (dry run, host layout entry points)"}))
     return 0 if int(t.item()) else 1
 
 

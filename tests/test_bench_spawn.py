@@ -27,6 +27,11 @@ def test_gpus2_dry_run_spawns_two_ranks_and_checks_the_exchange():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["dry_run"] and d["ok"] and d["n_gpus"] == 2 and d["points"] > 0
+    # ... and the gather to root (bench.py --exchange gather: rplgpu_gather_clouds_dev's layout)
+    r = _run("--gpus", "2", "--dry-run", "--exchange", "gather")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["dry_run"] and d["ok"] and d["exchange"] == "gather"
 
 
 def test_rank_count_mismatch_is_an_error():
