@@ -388,17 +388,17 @@ typedef uint32_t asc_u32x4 __attribute__((ext_vector_type(4)));
 //            chunk) held two per lane — min / max inside the lane, then against the neighbour
 //            lanes by DPP — and the nodes follow their tokens through 1 KiB of wave-private LDS;
 //   phase B  after the scan's last chunk: a chunk boundary whose two sides are out of order
-//            (last word of chunk k - 1 > first word of chunk k) is repaired in the 16-sample window
-//            across it, one sample per lane, odd-even transposition inside a DPP row, the nodes
-//            following by ds_bpermute.
+//            (last word of chunk k - 1 > first word of chunk k) is repaired in the 32-sample window
+//            across it, one sample per lane, two windows per wave, odd-even transposition by DPP
+//            wave shifts, the nodes following by ds_bpermute.
 // Both are stable permutations (a swap only where the left token is strictly larger, tokens carry
 // the original place), nothing is ever dropped, and the result is CHECKED: every chunk must come out
 // ascending, every repaired window too, with its two end samples still in place (they anchor the
 // window to the sorted chunks around it).  A scan that fails a check — disorder reaching farther than
 // the rounds — is queued for k_ascend<true> as before, which then trusts the stored angle words
 // (`prefilled`).  Ties keep their input order, the library's tie rule (tests/canon.py).
-constexpr int kAscRounds = 6;    // phase A: pairs of (inside the lane, across lanes) rounds
-constexpr int kAscRoundsB = 8;   // phase B: pairs of (even, odd) rounds on 16 samples
+constexpr int kAscRounds = 16;   // phase A: at most this many (inside the lane, across lanes) rounds
+constexpr int kAscRoundsB = 16;  // phase B: at most this many pairs of (even, odd) rounds on 32 samples
 
 template <int CTRL>
 __device__ __forceinline__ uint32_t asc_dpp_mov(uint32_t old, uint32_t v) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
                                                          const uint32_t *__restrict__ n_per_scan,
                                                          uint32_t *__restrict__ status,
                                                          uint32_t *__restrict__ need_sort, uint32_t mark) {
-  __shared__ uint32_t s_misc[8];                  // 0 first valid, 1 front word, 2 not ascending, 3 wrap zone, 4 W
+  __shared__ uint32_t s_misc[8];                  // 0 first valid, 1 front word, 2 not ascending, 3 wrap zone, 4 W, 5-6 its invalid nodes
   __shared__ uint32_t s_edge[2 * (kMaxN / 128)];  // first / last angle word of every 128-sample chunk
   __shared__ uint4 s_xch[kAscW][64];              // phase A: the nodes of a chunk, by slot (wave-private)
   __shared__ uint2 s_wrap[64];                    // the wrapped fills at the scan's end (they go to its front)
@@ -476,24 +476,32 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
   __syncthreads();
   const uint32_t front_q = s_misc[1];
   const float front = q14_to_deg(front_q);  // :171
-  // W: the scan ends with W wrapped fills and the wrap zone holds no other invalid node — the one
-  // non-local move this kernel handles itself: those W nodes go to the front (in index order: their
-  // angles ascend), the others move up by W.  Anything else in the wrap zone is left to the checks
-  // below (the scan then comes out not ascending and goes to the sorting kernel).
+  // W: the wrap zone — the last tl indices — holds W invalid nodes, the wrapped fills.  This kernel moves
+  // them itself (to the front, in index order: their angles ascend; everything else up by W) when the
+  // zone lies inside the scan's LAST 128-sample chunk: there the fills count as "larger than any angle
+  // word", phase A lets them sink behind the chunk's other nodes, and what is stored is what is left.
+  // A longer zone, or one that reaches into the chunk before, is left to the checks below (the scan
+  // then comes out not ascending and goes to the sorting kernel).
   {
     const uint32_t tl = s_misc[3];
-    if (tl >= 1u && tl <= 64u && threadIdx.x < 64u) {  // wave 0
+    if (tl >= 1u && tl <= 64u && n - tl >= ((n - 1u) & ~127u) && threadIdx.x < 64u) {  // wave 0
       const bool inv = lane_id() < tl && nd_dist(scan[n - tl + lane_id()]) == 0u;
       const uint64_t m = __builtin_amdgcn_ballot_w64(inv);  // bit j: index n - tl + j
-      const uint64_t top = ~(m << (64u - tl));               // leading zeros = invalid nodes at the very end
-      uint32_t W = top ? (uint32_t)__builtin_clzll(top) : 64u;
-      W = min(W, tl);
-      if (lane_id() == 0u) s_misc[4] = ((uint32_t)__popcll(m) == W) ? W : 0u;
+      if (lane_id() == 0u) {
+        s_misc[4] = (uint32_t)__popcll(m);
+        s_misc[5] = (uint32_t)m;
+        s_misc[6] = (uint32_t)(m >> 32);
+      }
     }
   }
   __syncthreads();
   const uint32_t W = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_misc[4]);
-  const uint32_t nm = n - W;  // the nodes [0, nm) keep their order relative to each other (up to local repair)
+  const uint32_t zone0 = n - s_misc[3];  // first index of the wrap zone (only meaningful when W > 0)
+  const uint64_t zmask = ((uint64_t)s_misc[6] << 32) | s_misc[5];
+  const uint32_t nm = n - W;  // the other nodes keep their order relative to each other (up to local repair)
+  auto wrapped = [&](uint32_t i) -> bool {  // an invalid node of the wrap zone
+    return W && i >= zone0 && i < n && ((zmask >> (i - zone0)) & 1ull);
+  };
   // ---- the fill pass (:171-178) + the order of the result (:181 moves nothing when it ascends)
   auto new_angle = [&](uint2 v, uint32_t i) -> uint32_t {
     uint32_t nq = nd_q14(v);
@@ -533,25 +541,35 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
       const uint32_t fa = i < n ? new_angle(a, i) : 0u, fc = i + 1u < n ? new_angle(c, i + 1u) : 0u;
       uint2 na = make_uint2((a.x & 0xFFFF0000u) | fa, a.y);
       uint2 nc = make_uint2((c.x & 0xFFFF0000u) | fc, c.y);
-      if (W) {  // the wrapped fills wait in LDS until the front of the scan has been read
-        if (i >= nm && i < n) s_wrap[i - nm] = na;
-        if (i + 1u >= nm && i + 1u < n) s_wrap[i + 1u - nm] = nc;
+      const bool wa = wrapped(i), wc = wrapped(i + 1u);
+      if (W) {  // the wrapped fills wait in LDS (in index order) until the front of the scan has been read
+        if (wa) s_wrap[__popcll(zmask & ((1ull << (i - zone0)) - 1ull))] = na;
+        if (wc) s_wrap[__popcll(zmask & ((1ull << (i + 1u - zone0)) - 1ull))] = nc;
       }
       // (the wrapped fills and the samples beyond the scan compare as "larger than any angle word":
-      // they sit at the end of the last chunk and stay there)
-      uint32_t qa = i < nm ? fa : 0x10000u;
-      uint32_t qc = i + 1u < nm ? fc : 0x10000u;
+      // they end up behind the last chunk's other nodes and are not stored from there)
+      uint32_t qa = (i < n && !wa) ? fa : 0x10000u;
+      uint32_t qc = (i + 1u < n && !wc) ? fc : 0x10000u;
       // ---- phase A: is the chunk in order?  (lane l + 1's first word against this lane's second)
       const uint32_t nxt_q = asc_dpp_mov<0x130>(0xFFFFFFFFu, qa);  // wave_shl:1; lane 63: no successor here
       if (__builtin_amdgcn_ballot_w64((qa > qc) | (qc > nxt_q))) {  // wave-uniform: local repair
         uint32_t ta = (qa << 8) | (2u * lane_id()), tc = (qc << 8) | (2u * lane_id() + 1u);
+        // rounds in pairs until the chunk is in order (wave-uniform exit: +-3 words of jitter need
+        // two or three pairs) or kAscRounds are spent (then the checks below send the scan on)
+        // (The chunk that holds the wrapped fills is sorted to the end whatever it takes — 128 rounds
+        // sort any 128 tokens: a fill left in front of a node that stays would be stored in its place.)
+        const int max_rounds = (W && (pair >> 6) == ((n - 1u) >> 7)) ? 128 : kAscRounds;
+        for (int r = 0; r < max_rounds; r += 2) {
 #pragma unroll
-        for (int r = 0; r < kAscRounds; ++r) {
-          const uint32_t lo = min(ta, tc), hi = max(ta, tc);
-          const uint32_t nx = asc_dpp_mov<0x130>(0xFFFFFFFFu, lo);  // lane l + 1's smaller token
-          const uint32_t pv = asc_dpp_mov<0x138>(0u, hi);           // lane l - 1's larger token (wave_shr:1)
-          ta = max(lo, pv);
-          tc = min(hi, nx);
+          for (int rr = 0; rr < 2; ++rr) {
+            const uint32_t lo = min(ta, tc), hi = max(ta, tc);
+            const uint32_t nx = asc_dpp_mov<0x130>(0xFFFFFFFFu, lo);  // lane l + 1's smaller token
+            const uint32_t pv = asc_dpp_mov<0x138>(0u, hi);           // lane l - 1's larger token (wave_shr:1)
+            ta = max(lo, pv);
+            tc = min(hi, nx);
+          }
+          const uint32_t nxa = asc_dpp_mov<0x130>(0xFFFFFFFFu, ta);
+          if (!__builtin_amdgcn_ballot_w64((ta > tc) | (tc > nxa))) break;
         }
         {  // (the last exchange across lanes may leave a lane's two tokens swapped)
           const uint32_t lo = min(ta, tc), hi = max(ta, tc);
@@ -585,38 +603,40 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
   __syncthreads();  // (also: the nodes every wave wrote are visible to the whole workgroup)
   // ---- phase B: chunk boundaries whose two sides are out of order
   const uint32_t nchunks = (npairs + 63u) >> 6;
-  const uint32_t row = lane_id() >> 4, col = lane_id() & 15u;
-  for (uint32_t base = 1u; base < nchunks; base += (uint32_t)kAscT / 16u) {
-    const uint32_t kb = base + wv * 4u + row;  // the boundary between chunk kb - 1 and chunk kb
+  const uint32_t half = lane_id() >> 5, col = lane_id() & 31u;  // two 32-sample windows per wave
+  for (uint32_t base = 1u; base < nchunks; base += (uint32_t)kAscT / 32u) {
+    const uint32_t kb = base + wv * 2u + half;  // the boundary between chunk kb - 1 and chunk kb
     const bool need = kb < nchunks && s_edge[2u * kb - 1u] > s_edge[2u * kb];
     if (!__builtin_amdgcn_ballot_w64(need)) continue;  // wave-uniform
-    const uint32_t pos = 128u * kb - 8u + col;  // (place among the nm nodes; W above that in the buffer)
+    const uint32_t pos = 128u * kb - 16u + col;  // (place among the nm nodes; W above that in the buffer)
     uint2 v = make_uint2(0u, 0u);
     if (need && pos < nm) v = scan[pos + W];
     const uint32_t q = (need && pos < nm) ? nd_q14(v) : 0x10000u;
     uint32_t t = (q << 8) | col;
     const bool odd = (col & 1u) != 0u;
-#pragma unroll
     for (int r = 0; r < kAscRoundsB; ++r) {
       {  // pairs (0,1) (2,3) ...: the even lane keeps the smaller token
-        const uint32_t nx = asc_dpp_mov<0x101>(t, t);  // row_shl:1 (lane 15 of a row: its own)
-        const uint32_t pv = asc_dpp_mov<0x111>(t, t);  // row_shr:1 (lane 0 of a row: its own)
+        const uint32_t nx = asc_dpp_mov<0x130>(t, t);  // wave_shl:1 (an odd lane never uses it)
+        const uint32_t pv = asc_dpp_mov<0x138>(t, t);  // wave_shr:1 (an even lane never uses it)
         t = odd ? max(t, pv) : min(t, nx);
       }
-      {  // pairs (1,2) (3,4) ...: the odd lane keeps the smaller token; lanes 0 and 15 stay
-        const uint32_t nx = asc_dpp_mov<0x101>(t, t);
-        const uint32_t pv = asc_dpp_mov<0x111>(t, t);
-        t = odd ? min(t, nx) : max(t, pv);
+      {  // pairs (1,2) (3,4) ...: the odd lane keeps the smaller token; a window's end lanes stay
+        const uint32_t nx = asc_dpp_mov<0x130>(t, t);
+        const uint32_t pv = asc_dpp_mov<0x138>(t, t);
+        const uint32_t t2 = odd ? min(t, nx) : max(t, pv);
+        t = (col == 0u || col == 31u) ? t : t2;
       }
+      const uint32_t pv = asc_dpp_mov<0x138>(0u, t);
+      if (!__builtin_amdgcn_ballot_w64(col != 0u && pv > t)) break;  // wave-uniform: both windows ascend
     }
     // checks: the window ascends, its end samples did not move
-    const uint32_t pv = asc_dpp_mov<0x111>(0u, t);
-    bad |= need & ((pv > t) | ((col == 0u || col == 15u) && (t & 15u) != col));
-    // the nodes follow: source lane = same row, column = the token's low bits
-    const uint32_t src = ((lane_id() & 48u) | (t & 15u)) * 4u;
+    const uint32_t pv = asc_dpp_mov<0x138>(0u, t);
+    bad |= need & ((col != 0u && pv > t) | ((col == 0u || col == 31u) && (t & 31u) != col));
+    // the nodes follow: source lane = same window, column = the token's low bits
+    const uint32_t src = ((lane_id() & 32u) | (t & 31u)) * 4u;
     const uint32_t mx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.x);
     const uint32_t my = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.y);
-    if (need && pos < nm && (t & 15u) != col) scan[pos + W] = make_uint2(mx, my);
+    if (need && pos < nm && (t & 31u) != col) scan[pos + W] = make_uint2(mx, my);
   }
   // ---- the wrapped fills: to the front, in index order
   if (W >= 16u) {
@@ -637,7 +657,7 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
     uint32_t t = ((inwin ? nd_q14(v) : 0x10000u) << 10) | ((tie & 31u) << 5) | (c16 & 15u);
     const bool odd = (c16 & 1u) != 0u;
 #pragma unroll
-    for (int r = 0; r < kAscRoundsB; ++r) {
+    for (int r = 0; r < 8; ++r) {  // 16 samples: eight pairs of (even, odd) rounds sort anything
       {
         const uint32_t nx = asc_dpp_mov<0x101>(t, t);
         const uint32_t pv = asc_dpp_mov<0x111>(t, t);

@@ -893,9 +893,10 @@ def test_ascend_then_laserscan_equals_laserscan(gpu, oracle):
 def test_ascend_wrap_zone(gpu, oracle):
     """Invalid nodes at the end of a scan whose interpolated angle passes 360 degrees are given an
     angle near zero (src/sdk/src/sl_lidar_driver.cpp:174-176) and belong at the FRONT of the sorted
-    scan: every other node moves up.  The streaming kernel does that move itself when the wrapped
-    fills are the scan's last W nodes (W <= 64); other shapes of the wrap zone go to the sorting
-    kernel.  Both must give ascendScanData's result."""
+    scan: every other node moves up.  The streaming kernel does that move itself when the wrap
+    zone (at most 64 indices) lies inside the scan's last 128-sample chunk, whatever the pattern of
+    valid and invalid nodes in it; other shapes go to the sorting kernel.  Both must give
+    ascendScanData's result."""
     torch = _torch()
     n = 32000
     # (angle offset of the whole scan / of sample 0 alone, indices made invalid, indices forced valid, length)
@@ -905,6 +906,8 @@ def test_ascend_wrap_zone(gpu, oracle):
     for q0, k in ((5, 1), (40, 5), (200, 64)):
         shapes.append((0, q0, list(range(n - k, n)), [], n))       # ... or in between the first samples
     shapes.append((40, 0, [n - 1, n - 2, n - 4], [n - 3], n))      # a valid node inside the zone
+    shapes.append((60, 0, [n - 30, n - 17, n - 16, n - 3], [n - 1, n - 2, n - 4, n - 5], n))  # scattered fills
+    shapes.append((120, 0, list(range(n - 58, n, 2)), list(range(n - 57, n, 2)), n))          # every other node
     shapes.append((3000, 0, list(range(n - 30, n)), [], n))        # a zone of ~1500 samples
     shapes.append((40, 0, list(range(20000 - 3, 20000)), [], 20000))  # shorter scans
     shapes.append((40, 0, [298, 299], [], 300))
