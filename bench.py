@@ -767,10 +767,12 @@ def main():
                 ("jitter1", 1, "valid samples' angle words jittered by +-1 (step 2.05): every filled word "
                                "differs from the stored one (8-byte stores), the order survives"),
                 ("jitter3", 3, "jitter +-3: neighbouring samples swap in every scan; repaired inside the "
-                               "streaming kernel (odd-even transposition per 128-sample chunk, 16-sample "
+                               "streaming kernel (odd-even transposition per 128-sample chunk, 32-sample "
                                "windows across chunk boundaries, wrapped fills moved to the front); only a "
                                "scan that fails the final order check goes to the sorting kernel"),
-                ("jitter10", 10, "jitter +-10: disorder reaches past the repair windows in part of the scans, "
+                ("jitter10", 10, "jitter +-10: samples up to ~10 places from their sorted position, 89 % of "
+                                 "the nodes rewritten; still repaired in the streaming pass"),
+                ("jitter20", 20, "jitter +-20: disorder reaches past the repair windows in part of the scans, "
                                  "which take the sorting kernel (k_ascend<true>) on top")):
             vb = synth.make_batch(args.seed + 11, Bv, n, jitter=jit)
             d_v = torch.from_numpy(vb.view(np.uint8).reshape(Bv, n * 8)).to(dev)
