@@ -588,8 +588,18 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
         qa = ta >> 8;
         qc = tc >> 8;
       }
-      if (i < nm && (W || na.x != a.x || na.y != a.y)) scan[i + W] = na;
-      if (i + 1u < nm && (W || nc.x != c.x || nc.y != c.y)) scan[i + 1u + W] = nc;
+      {
+        const bool sa = i < nm && (W || na.x != a.x || na.y != a.y);
+        const bool sc = i + 1u < nm && (W || nc.x != c.x || nc.y != c.y);
+        // (a run of invalid nodes changes both nodes of most of its pairs: one 16-byte store then — the
+        // pair is 16-byte aligned when W is even)
+        if (sa && sc && !(W & 1u)) {
+          *reinterpret_cast<uint4 *>(&scan[i + W]) = make_uint4(na.x, na.y, nc.x, nc.y);
+        } else {
+          if (sa) scan[i + W] = na;
+          if (sc) scan[i + 1u + W] = nc;
+        }
+      }
       // what is left out of order inside the chunk after the repair (nothing, normally)
       const uint32_t prev = asc_dpp_mov<0x138>(0u, qc);  // the lane to the left (lane 0: nothing before it here)
       bad |= (qa > qc) | (prev > qa);
