@@ -12,11 +12,14 @@ n = int(os.environ.get('RPL_VOXDBG_N', '32000')) if True else 32000
 NOISE = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 import os
 R0MAX = float(os.environ.get('RPL_VOXDBG_R0MAX', '30'))
-batch = synth.make_batch(2026, B, n, noise_m=NOISE, r0_range=(1.0, R0MAX))
+KIND = os.environ.get('RPL_VOXDBG_KIND', 'ring')
+batch = synth.make_batch(2026, B, n, kind='uniform') if KIND == 'uniform' else \
+    synth.make_batch(2026, B, n, noise_m=NOISE, r0_range=(1.0, R0MAX))
+STRIDE = n if KIND == 'uniform' or NOISE >= 0.02 else 8192
 dev = torch.device("cuda:0")
 d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
 d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
-d_xyzi = torch.empty(B, 8192, 4, dtype=torch.float32, device=dev)
+d_xyzi = torch.empty(B, STRIDE, 4, dtype=torch.float32, device=dev)
 d_np = torch.zeros(B, dtype=torch.int32, device=dev)
 d_st = torch.zeros(B, dtype=torch.int32, device=dev)
 d_dbg = torch.zeros(B, 16, dtype=torch.int64, device=dev)
@@ -29,7 +32,7 @@ for it in range(3):
     d_dbg.zero_()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(st)
-    gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_xyzi.data_ptr(), 8192,
+    gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_xyzi.data_ptr(), STRIDE,
                         d_np.data_ptr(), d_st.data_ptr())
     b.record(st); torch.cuda.synchronize()
     print("kernel ms", a.elapsed_time(b))
