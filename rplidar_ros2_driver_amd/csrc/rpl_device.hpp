@@ -70,6 +70,8 @@ struct KParams {
   int32_t vox_L;      // leaf * 2^K: the leaf's 24-bit significand, exact
   int32_t vox_bias;   // 0 since round 3 (offsets are summed as wrapping two's complement)
   float inv_leaf;     // RN(1 / voxel_leaf)
+  float leaf_s;       // voxel_leaf * 2^K (= vox_L) and RN(1 / voxel_leaf) * 2^-K: the cell divide on
+  float inv_leaf_s;   // coordinates in units of 2^-K m (both exact scalings)
   // E1 keep mask as an integer interval on dist_mm_q2 (host-derived, see make_keep_interval in
   // rplgpu_api.hip): keep <=> (dist_q2 - d_lo) <= d_span (unsigned) && quality >= q_min.
   // dist_m = RN(u32->f32(d)) / 4000 is monotone in d, so the float compares against range_min /

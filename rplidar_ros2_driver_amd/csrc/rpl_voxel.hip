@@ -74,6 +74,10 @@ static_assert(kRecCap * 2u <= 2u * kRowCap * 4u, "the cell-head list (u16) lives
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef RPL_VX_IDXEN
+typedef int i4v __attribute__((ext_vector_type(4)));
+__device__ f2 llvm_struct_load_f2(i4v rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v2f32");
+#endif
 #ifndef RPL_VOXEL_AHEAD
 #define RPL_VOXEL_AHEAD 2
 #endif
@@ -247,6 +251,69 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
   ci = kept ? ((1u << 16) | ((hi >> ibfe_off) & ibfe_w)) : 0u;  // count | intensity (:591-592)
   return kept;
 }
+
+#ifdef RPL_VX_V2
+// (developer experiment, round 5: instruction-mix variants of the per-sample arithmetic for the two
+// samples of a lane; bit 0 the divide by 4000 of both samples as packed operations, bit 1 the
+// fixed-point scale folded into dist_m — power of two, exact — so that the offsets come out of the
+// remainder FMA directly)
+template <bool FAST_DIV, bool SAFE, bool HASQ>
+__device__ __forceinline__ void voxel_pair(const uint32_t (&lo)[2], const uint32_t (&hi)[2], const float2 (&c)[2],
+                                           const KParams &p, uint32_t q_min16, uint32_t ibfe_off, uint32_t ibfe_w,
+                                           bool (&ok)[2], uint32_t (&key)[2], uint32_t (&qx)[2], uint32_t (&qy)[2],
+                                           uint32_t (&ci)[2], uint32_t &flags) {
+  f2 df;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const uint32_t d = __builtin_amdgcn_alignbit(hi[j], lo[j], 16);
+    bool kept = (d - p.d_lo) <= p.d_span;
+    if (HASQ) kept = kept & ((hi[j] & 0x00FF0000u) >= q_min16);
+    ok[j] = kept;
+    df[j] = __uint2float_rn(kept ? d : 0u);
+  }
+  f2 dm;
+  if ((RPL_VX_V2 & 1) && FAST_DIV) {
+    dm = div_by2(df, 4000.0f, 0.00025f);
+  } else {
+    dm.x = FAST_DIV ? div_by(df.x, 4000.0f, 0.00025f) : df.x / 4000.0f;
+    dm.y = FAST_DIV ? div_by(df.y, 4000.0f, 0.00025f) : df.y / 4000.0f;
+  }
+  const bool scaled = (RPL_VX_V2 & 2) != 0;
+  const float leaf = scaled ? p.leaf_s : p.voxel_leaf, inv_leaf = scaled ? p.inv_leaf_s : p.inv_leaf;
+  if (scaled) dm = dm * p.vox_scale_f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const f2 cv = {c[j].x, c[j].y};
+    const f2 xy = cv * dm[j];
+    f2 t;
+    if (FAST_DIV) {
+      t = div_by2(xy, leaf, inv_leaf);
+    } else {
+      t.x = xy.x / leaf;
+      t.y = xy.y / leaf;
+    }
+    const f2 f = {__builtin_floorf(t.x), __builtin_floorf(t.y)};
+    if (!SAFE) {
+      const bool inr = (fabsf(f.x) < 32767.0f) && (fabsf(f.y) < 32767.0f);
+      if (ok[j] && !inr) flags |= RPLGPU_SCAN_CELL_RANGE;
+      ok[j] = ok[j] & inr;
+    }
+    const uint32_t kx = __float_as_uint(f.x + kKeyMagic);
+    const uint32_t ky = __float_as_uint(f.y + kKeyMagic);
+    key[j] = __builtin_amdgcn_perm(ky, kx, 0x05040100u);
+    const f2 lf = {leaf, leaf};
+    const f2 r = __builtin_elementwise_fma(-f, lf, xy);
+    const f2 o = scaled ? r : r * p.vox_scale_f;
+    qx[j] = (uint32_t)(int)o.x;
+    qy[j] = (uint32_t)(int)o.y;
+    if (!SAFE) {
+      qx[j] = ok[j] ? qx[j] : 0u;
+      qy[j] = ok[j] ? qy[j] : 0u;
+    }
+    ci[j] = ok[j] ? ((1u << 16) | ((hi[j] >> ibfe_off) & ibfe_w)) : 0u;
+  }
+}
+#endif
 
 // Cross-lane part of one block of 64 * NS samples: lane l holds the NS consecutive samples
 // NS l .. NS l + NS - 1 (ok[j]: the sample survived the keep mask).  A record is written where a
@@ -793,8 +860,18 @@ __device__ __forceinline__ void voxel_stream(Sink &sink, const KParams &p,
   w[0] = load_pair(blk0 * 1024u + lane_off);
   w[1] = load_pair((blk0 + (uint32_t)STEP) * 1024u + lane_off);
   if (AHEAD == 3) w[2] = load_pair((blk0 + 2u * STEP) * 1024u + lane_off);
-  cA[0] = cs[w[0].x & 0xFFFFu];
-  cB[0] = cs[w[0].z & 0xFFFFu];
+#ifdef RPL_VX_IDXEN  // (developer experiment: the table entry by buffer index — v_and instead of an SDWA shift per gather)
+  const unsigned long long cs_addr = (unsigned long long)(uintptr_t)cs;
+  const i4v cs_rsrc = {(int)(uint32_t)cs_addr, (int)((uint32_t)(cs_addr >> 32) | (8u << 16)), 65536, 0x00020000};
+  auto gat = [&](uint32_t word) -> float2 {
+    const f2 v = llvm_struct_load_f2(cs_rsrc, (int)(word & 0xFFFFu), 0, 0, 0);
+    return make_float2(v.x, v.y);
+  };
+#else
+  auto gat = [&](uint32_t word) -> float2 { return cs[word & 0xFFFFu]; };
+#endif
+  cA[0] = gat(w[0].x);
+  cB[0] = gat(w[0].z);
   unsigned long long sub[5] = {0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0ull;
   for (uint32_t blk4 = blk0; blk4 < blk_end; blk4 += 4u * STEP) {
 #pragma unroll
@@ -806,8 +883,8 @@ __device__ __forceinline__ void voxel_stream(Sink &sink, const KParams &p,
       unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
       if (DBG) t0 = clock64();
 #ifndef RPL_ABL_NOGATHER
-      cA[(k + 1) & 1] = cs[w[(k + 1) & 3].x & 0xFFFFu];
-      cB[(k + 1) & 1] = cs[w[(k + 1) & 3].z & 0xFFFFu];
+      cA[(k + 1) & 1] = gat(w[(k + 1) & 3].x);
+      cB[(k + 1) & 1] = gat(w[(k + 1) & 3].z);
 #else  // (developer ablation: no table gathers)
       cA[(k + 1) & 1] = make_float2(__uint_as_float(0x3F000000u | (w[(k + 1) & 3].x & 0xFFFFu)), 0.5f);
       cB[(k + 1) & 1] = make_float2(__uint_as_float(0x3F000000u | (w[(k + 1) & 3].z & 0xFFFFu)), 0.5f);
@@ -837,6 +914,11 @@ __device__ __forceinline__ void voxel_stream(Sink &sink, const KParams &p,
         const uint32_t i0 = blk * 128u + lane_id() * 2u;  // sample index inside the scan
         bool ok[2];
         uint32_t key[2], qx[2], qy[2], ci[2];
+#ifdef RPL_VX_V2
+        if (!XF) {
+          voxel_pair<FAST_DIV, SAFE, HASQ>(lo, hi, c0, p, q_min16, ibfe_off, ibfe_w, ok, key, qx, qy, ci, flags);
+        } else
+#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           ok[j] = voxel_sample<FAST_DIV, SAFE, HASQ, XF>(lo[j], hi[j], c0[j], p, q_min16, ibfe_off,

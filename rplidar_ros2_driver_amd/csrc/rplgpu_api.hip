@@ -171,6 +171,8 @@ rpl::KParams to_kparams(const rplgpu_params_t &p) {
   k.vox_L = 1;
   k.vox_bias = 0;  // (round 3: offsets are summed as wrapping two's complement, no bias)
   k.inv_leaf = 1.0f;
+  k.leaf_s = 1.0f;
+  k.inv_leaf_s = 1.0f;
   k.fast_div = 0;
   k.fast_d4000 = 0;
   k.dbg = nullptr;
@@ -195,6 +197,8 @@ rpl::KParams to_kparams(const rplgpu_params_t &p) {
     k.vox_scale_f = (float)k.vox_scale;
     k.vox_L = (int32_t)std::llround((double)p.voxel_leaf * k.vox_scale);
     k.inv_leaf = 1.0f / p.voxel_leaf;
+    k.leaf_s = p.voxel_leaf * k.vox_scale_f;
+    k.inv_leaf_s = k.inv_leaf / k.vox_scale_f;
   }
   return k;
 }
