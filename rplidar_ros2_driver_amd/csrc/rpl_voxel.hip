@@ -81,6 +81,9 @@ __device__ f2 llvm_struct_load_f2(i4v rsrc, int vindex, int voffset, int soffset
 #ifndef RPL_VOXEL_AHEAD
 #define RPL_VOXEL_AHEAD 2
 #endif
+#ifndef RPL_VOXEL_GAHEAD
+#define RPL_VOXEL_GAHEAD 1  // (cos, sin) gathers: blocks in front of the block being aggregated
+#endif
 #ifndef RPL_RAW_AUX
 #define RPL_RAW_AUX 2  // cache policy of the raw-pair loads (bit 0 glc, bit 1 slc): streamed once
 #endif
@@ -848,18 +851,21 @@ __device__ __forceinline__ void voxel_stream(Sink &sink, const KParams &p,
                                              uint32_t mask_stride, const ScanXf &xf, uint32_t q_min16,
                                              uint32_t ibfe_off, uint32_t ibfe_w, uint32_t &flags,
                                              unsigned long long *dbg_slot) {
-  static_assert(AHEAD == 2 || AHEAD == 3, "raw pairs run two or three blocks ahead");
+  // raw pairs run AHEAD blocks in front of the block being aggregated, the table entries GA blocks (their
+  // addresses come out of the raw pair: GA < AHEAD); both live in register rings of N slots, the loop is
+  // unrolled N times so that the rings cost no moves
+  constexpr int GA = RPL_VOXEL_GAHEAD < AHEAD ? RPL_VOXEL_GAHEAD : AHEAD - 1, N = AHEAD <= 3 ? 4 : AHEAD + 1;
+  static_assert(AHEAD >= 2 && AHEAD <= 7 && GA >= 1 && GA < AHEAD, "ring depths");
   if (blk0 >= blk_end) return;  // wave-uniform (no barrier inside the stream)
   auto load_pair = [&](uint32_t byte_off) -> uint4 {
     const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)byte_off, 0, RPL_RAW_AUX);
     return make_uint4(t.x, t.y, t.z, t.w);
   };
   const uint32_t lane_off = lane_id() * 16u;
-  uint4 w[4];
-  float2 cA[2], cB[2];
-  w[0] = load_pair(blk0 * 1024u + lane_off);
-  w[1] = load_pair((blk0 + (uint32_t)STEP) * 1024u + lane_off);
-  if (AHEAD == 3) w[2] = load_pair((blk0 + 2u * STEP) * 1024u + lane_off);
+  uint4 w[N];
+  float2 cA[N], cB[N];
+#pragma unroll
+  for (int j = 0; j < AHEAD; ++j) w[j] = load_pair((blk0 + (uint32_t)(j * STEP)) * 1024u + lane_off);
 #ifdef RPL_VX_IDXEN  // (developer experiment: the table entry by buffer index — v_and instead of an SDWA shift per gather)
   const unsigned long long cs_addr = (unsigned long long)(uintptr_t)cs;
   const i4v cs_rsrc = {(int)(uint32_t)cs_addr, (int)((uint32_t)(cs_addr >> 32) | (8u << 16)), 65536, 0x00020000};
@@ -870,12 +876,15 @@ __device__ __forceinline__ void voxel_stream(Sink &sink, const KParams &p,
 #else
   auto gat = [&](uint32_t word) -> float2 { return cs[word & 0xFFFFu]; };
 #endif
-  cA[0] = gat(w[0].x);
-  cB[0] = gat(w[0].z);
-  unsigned long long sub[5] = {0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0ull;
-  for (uint32_t blk4 = blk0; blk4 < blk_end; blk4 += 4u * STEP) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+  for (int j = 0; j < GA; ++j) {
+    cA[j] = gat(w[j].x);
+    cB[j] = gat(w[j].z);
+  }
+  unsigned long long sub[5] = {0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0ull;
+  for (uint32_t blk4 = blk0; blk4 < blk_end; blk4 += (uint32_t)(N * STEP)) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
       const uint32_t blk = blk4 + (uint32_t)k * STEP;
       // (the loads are issued whether or not the block exists — beyond the resource they return
       // zeros — so that every path through the loop has the same loads in flight and the
@@ -883,25 +892,25 @@ __device__ __forceinline__ void voxel_stream(Sink &sink, const KParams &p,
       unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
       if (DBG) t0 = clock64();
 #ifndef RPL_ABL_NOGATHER
-      cA[(k + 1) & 1] = gat(w[(k + 1) & 3].x);
-      cB[(k + 1) & 1] = gat(w[(k + 1) & 3].z);
+      cA[(k + GA) % N] = gat(w[(k + GA) % N].x);
+      cB[(k + GA) % N] = gat(w[(k + GA) % N].z);
 #else  // (developer ablation: no table gathers)
-      cA[(k + 1) & 1] = make_float2(__uint_as_float(0x3F000000u | (w[(k + 1) & 3].x & 0xFFFFu)), 0.5f);
-      cB[(k + 1) & 1] = make_float2(__uint_as_float(0x3F000000u | (w[(k + 1) & 3].z & 0xFFFFu)), 0.5f);
+      cA[(k + GA) % N] = make_float2(__uint_as_float(0x3F000000u | (w[(k + GA) % N].x & 0xFFFFu)), 0.5f);
+      cB[(k + GA) % N] = make_float2(__uint_as_float(0x3F000000u | (w[(k + GA) % N].z & 0xFFFFu)), 0.5f);
 #endif
 #ifndef RPL_ABL_NORAW
-      w[(k + AHEAD) & 3] = load_pair((blk + (uint32_t)AHEAD * STEP) * 1024u + lane_off);
+      w[(k + AHEAD) % N] = load_pair((blk + (uint32_t)AHEAD * STEP) * 1024u + lane_off);
 #else  // (developer ablation: no raw loads inside the loop)
-      w[(k + AHEAD) & 3] = w[k];
-      asm volatile("" : "+v"(w[(k + AHEAD) & 3].x), "+v"(w[(k + AHEAD) & 3].y), "+v"(w[(k + AHEAD) & 3].z), "+v"(w[(k + AHEAD) & 3].w));
+      w[(k + AHEAD) % N] = w[k];
+      asm volatile("" : "+v"(w[(k + AHEAD) % N].x), "+v"(w[(k + AHEAD) % N].y), "+v"(w[(k + AHEAD) % N].z), "+v"(w[(k + AHEAD) % N].w));
 #endif
       if (DBG) {  // [8] issue of the loads (incl. the wait for the raw pair the gathers need)
-        asm volatile("" : "+v"(cA[(k + 1) & 1].x), "+v"(cB[(k + 1) & 1].x)::"memory");
+        asm volatile("" : "+v"(cA[(k + GA) % N].x), "+v"(cB[(k + GA) % N].x)::"memory");
         t1 = clock64();
       }
       if (blk < blk_end) {  // wave-uniform
         const uint4 w0 = w[k];
-        const float2 c0[2] = {cA[k & 1], cB[k & 1]};
+        const float2 c0[2] = {cA[k], cB[k]};
         uint32_t lo[2] = {w0.x, w0.z}, hi[2] = {w0.y, w0.w};
         if (HASMASK) {  // E5 mask (one bit per sample): a dropped sample gets dist 0
           const uint32_t word = blk * 4u + (lane_id() >> 4);  // sample 128 blk + 2 l -> bit 2 (l & 15)
