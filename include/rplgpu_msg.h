@@ -201,6 +201,18 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
                                      uint64_t arena_capacity, uint64_t *d_cursor,
                                      uint64_t *d_group_start, uint32_t *d_n_points,
                                      uint32_t *d_status);
+/* Time alignment inside a group (row 4, the temporal side): the scans fused into one grid do not
+ * start at the same instant — every sensor free-runs, and a node stamps its LaserScan with its own
+ * start time (src/rplidar_node.cpp:620) and publishes time_increment / scan_time (:627,637-638).  d_t0 holds
+ * per scan of the batch the time [s] of its FIRST sample relative to the instant the group is fused
+ * at (scan stamp - fused stamp; negative: the scan started earlier).  While set, E6 — in
+ * rplgpu_cloud_deskew_batch_dev and rplgpu_cloud_fused_voxel_dev, which then require d_motion —
+ * moves every point to the sensor pose at the FUSED instant instead of the scan's first sample:
+ *   tau = t0 + float(i) * time_increment      (product rounded to float32, then the sum)
+ * and the formulas of rplgpu_cloud_deskew_batch_dev apply unchanged.  NULL (the default) switches it
+ * off: tau = float(i) * time_increment, bit for bit as before.  The buffer is the caller's and must
+ * stay valid until the launches that use it have completed. */
+int32_t rplgpu_set_scan_time_offsets_dev(rplgpu_handle_t h, const float *d_t0);
 /* The whole arena as ONE serialised PointCloud2 (the fused cloud of BASELINE config 5):
  * width = min(*d_total_points, arena_capacity) with d_total_points the arena cursor of
  * rplgpu_cloud_arena_dev — no host round trip.  *d_msg_len (device) = serialised size, or 0 +

@@ -42,14 +42,18 @@ def planar_pose(yaw_rad: float, tx: float, ty: float, tz: float = 0.0) -> np.nda
     return np.array([[c, -s, 0, tx], [s, c, 0, ty], [0, 0, 1, tz]], np.float32)
 
 
-def deskew_cloud(xyzi: np.ndarray, sample_index: np.ndarray, motion) -> np.ndarray:
+def deskew_cloud(xyzi: np.ndarray, sample_index: np.ndarray, motion, t0=None) -> np.ndarray:
     """E6 motion de-skew (include/rplgpu_msg.h): xyzi (n, 4) float32 = the plain cloud,
     sample_index (n,) = input index of every kept sample, motion = (vx, vy, wz, time_increment).
+    t0 (rplgpu_set_scan_time_offsets_dev): time of the scan's first sample relative to the instant
+    the points are wanted at, tau = t0 + float(i) * time_increment; None: tau = float(i) * time_increment.
     Every operation rounded to float32, in the documented order."""
     f = np.float32
     p = np.asarray(xyzi, np.float32).reshape(-1, 4)
     vx, vy, wz, dt = (f(v) for v in motion)
     tau = (np.asarray(sample_index).astype(np.float32) * dt).astype(np.float32)
+    if t0 is not None:
+        tau = (f(t0) + tau).astype(np.float32)
     a = (wz * tau).astype(np.float32)
     a2 = (a * a).astype(np.float32)
     ts = (a2 * (f(1.0) / f(120.0))).astype(np.float32)

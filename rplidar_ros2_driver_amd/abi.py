@@ -85,6 +85,7 @@ ABI_SYMBOLS = [
     "rplgpu_laserscan_to_cloud",
     "rplgpu_cloud_fused_voxel_dev",
     "rplgpu_set_cell_key_output",
+    "rplgpu_set_scan_time_offsets_dev",
     "rplgpu_set_voxel_aggregation",
     # include/rplgpu_comm.h
     "rplgpu_comm_unique_id",
@@ -278,6 +279,7 @@ def load_library() -> C.CDLL:
     lib.rplgpu_cloud_fused_voxel_dev.argtypes = [vp, vp, u32, vp, u32, u32, C.POINTER(Params), vp, vp, vp,
                                                  u64, vp, vp, vp, vp]
     lib.rplgpu_set_cell_key_output.argtypes = [vp, vp]
+    lib.rplgpu_set_scan_time_offsets_dev.argtypes = [vp, vp]
     lib.rplgpu_comm_unique_id.argtypes = [vp]
     lib.rplgpu_comm_init.argtypes = [vp, i32, i32, vp]
     lib.rplgpu_comm_destroy.argtypes = [vp]
@@ -536,6 +538,11 @@ class RplGpu:
         """0 = auto (from the previous batch launch's statistics), 1 = plain, 2 = two-class
         (include/rplgpu.h RPLGPU_VOXEL_AGG_*).  Results are identical in every mode."""
         self._check(self._lib.rplgpu_set_voxel_aggregation(self._h, int(mode)))
+
+    def set_scan_time_offsets_dev(self, d_t0: int = 0):
+        """Per scan of the following de-skew / fused launches: the time [s] of its first sample relative
+        to the fused instant (include/rplgpu_msg.h); 0 switches the offsets off."""
+        self._check(self._lib.rplgpu_set_scan_time_offsets_dev(self._h, d_t0 or None))
 
     def set_cell_key_output(self, d_cell_keys: int = 0):
         """Optional voxel output: one u32 per output point, (iy + 32768) << 16 | (ix + 32768)."""

@@ -50,6 +50,7 @@ struct Tables {
   uint32_t voxel_pipe_items;  // items the ready counts hold (a pipelined stage has no more)
   void *voxel_pipe_stream;    // hipStream_t of the consumer
   void *voxel_pipe_ev[2];     // hipEvent_t: fork, join
+  const float *scan_t0;       // per scan: time of its first sample relative to the fused instant (E6), or null
 };
 
 struct KParams {

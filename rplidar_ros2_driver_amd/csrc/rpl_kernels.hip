@@ -781,9 +781,13 @@ __global__ __launch_bounds__(kBlock) void k_cloud(
   const uint2 *scan = nodes + (size_t)b * n_stride;
   float4 *out = xyzi + (size_t)b * out_stride;
   // E6 (include/rplgpu_msg.h): motion of the sensor during the scan, (vx, vy, wz, time_increment)
-  float mvx = 0.0f, mvy = 0.0f, mwz = 0.0f, mdt = 0.0f;
+  // and, optionally, the time of the scan's first sample relative to the instant its points are wanted
+  // at (rplgpu_set_scan_time_offsets_dev)
+  float mvx = 0.0f, mvy = 0.0f, mwz = 0.0f, mdt = 0.0f, mt0 = 0.0f;
+  const bool has_t0 = motion && T.scan_t0;  // block-uniform
   if (motion) {
     mvx = motion[4 * b], mvy = motion[4 * b + 1], mwz = motion[4 * b + 2], mdt = motion[4 * b + 3];
+    if (has_t0) mt0 = T.scan_t0[b];
   }
 
   uint2 v[kIters];
@@ -818,7 +822,8 @@ __global__ __launch_bounds__(kBlock) void k_cloud(
         float2 c = cs[nd_q14(v[j])];
         float x = dm * c.x, y = dm * c.y;
         if (motion) {  // the point as seen from the sensor pose at the first sample
-          const float tau = (float)sample_index(j) * mdt;
+          float tau = (float)sample_index(j) * mdt;
+          if (has_t0) tau = mt0 + tau;
           const float a = mwz * tau, a2 = a * a;
           // sin / cos as fixed polynomials (|a| <= 0.5 rad: error < 2e-8), every operation
           // rounded once, in this order -- the oracle does the same, bit for bit

@@ -178,10 +178,13 @@ __device__ __forceinline__ void glb_store128_off(const void *base, uint32_t byte
 // reproduce x, y bit for bit.
 struct ScanXf {
   float vx, vy, wz, dt;             // planar twist of the sensor and time between samples
+  float t0;                         // time of the first sample relative to the fused instant
+  uint32_t has_t0;                  // (0: no offsets set — tau = i * dt, bit for bit as without them)
   float r00, r01, tx, r10, r11, ty;  // [R | t] of the sensor in the common frame (2-D)
 };
 __device__ __forceinline__ f2 apply_xf(f2 xy, uint32_t sample_index, const ScanXf &m) {
-  const float tau = (float)sample_index * m.dt;
+  float tau = (float)sample_index * m.dt;
+  if (m.has_t0) tau = m.t0 + tau;  // (scan-uniform)
   const float a = m.wz * tau, a2 = a * a;
   float ts = a2 * (1.0f / 120.0f);
   ts = ts + (-1.0f / 6.0f);
@@ -961,11 +964,15 @@ struct ScanSide {
 };
 __device__ __forceinline__ ScanSide scan_side(uint32_t sc, const uint32_t *__restrict__ keepmask,
                                               uint32_t mask_stride, const float *__restrict__ motion,
-                                              const float *__restrict__ pose2d) {
+                                              const float *__restrict__ pose2d,
+                                              const float *__restrict__ scan_t0) {
   ScanSide s;
   s.ror_bits = keepmask ? keepmask + (size_t)sc * mask_stride : nullptr;
-  s.xf = ScanXf{0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
-  if (motion) { s.xf.vx = motion[4 * sc]; s.xf.vy = motion[4 * sc + 1]; s.xf.wz = motion[4 * sc + 2]; s.xf.dt = motion[4 * sc + 3]; }
+  s.xf = ScanXf{0.f, 0.f, 0.f, 0.f, 0.f, 0u, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+  if (motion) {
+    s.xf.vx = motion[4 * sc]; s.xf.vy = motion[4 * sc + 1]; s.xf.wz = motion[4 * sc + 2]; s.xf.dt = motion[4 * sc + 3];
+    if (scan_t0) { s.xf.t0 = scan_t0[sc]; s.xf.has_t0 = 1u; }
+  }
   if (pose2d) {
     s.xf.r00 = pose2d[6 * sc]; s.xf.r01 = pose2d[6 * sc + 1]; s.xf.tx = pose2d[6 * sc + 2];
     s.xf.r10 = pose2d[6 * sc + 3]; s.xf.r11 = pose2d[6 * sc + 4]; s.xf.ty = pose2d[6 * sc + 5];
@@ -1439,7 +1446,7 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(kVB * kVWG 
       // the compiler's vmcnt bookkeeping is exact.
       const __amdgpu_buffer_rsrc_t scan_rsrc =
           __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
-      const ScanSide sd = scan_side(sc, keepmask, mask_stride, motion, pose2d);
+      const ScanSide sd = scan_side(sc, keepmask, mask_stride, motion, pose2d, T.scan_t0);
       const uint32_t blk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
 #ifdef RPL_VOXEL_PRIO_STAGGER  // (developer experiment: the waves of a SIMD at different priorities)
       {
@@ -1528,7 +1535,7 @@ __attribute__((amdgpu_waves_per_eu(RPL_RUNS_WAVES_PER_EU, RPL_RUNS_WAVES_PER_EU)
     uint32_t mask_stride, uint4 *__restrict__ regions, uint2 *__restrict__ rcount, uint32_t item0,
     uint32_t B, uint32_t group, uint32_t n_scans, uint32_t cps, uint32_t scan_major,
     const float *__restrict__ motion, const float *__restrict__ pose2d, VoxelPipe pipe,
-    uint32_t pipe_want) {
+    uint32_t pipe_want, const float *__restrict__ scan_t0) {
   const uint32_t qn = group * cps;  // regions per item
   const uint32_t total = B * qn;
   const uint32_t ishift = p.is_new_protocol ? 0u : 2u;  // :591-592
@@ -1580,7 +1587,7 @@ __attribute__((amdgpu_waves_per_eu(RPL_RUNS_WAVES_PER_EU, RPL_RUNS_WAVES_PER_EU)
         const uint32_t lim = min(n, blk_end * 128u) * 8u;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(nodes + (size_t)sc * n_stride), 0, (int)lim, 0x00020000);
-        const ScanSide sd = scan_side(sc, keepmask, mask_stride, motion, pose2d);
+        const ScanSide sd = scan_side(sc, keepmask, mask_stride, motion, pose2d, scan_t0);
         voxel_stream_dispatch<FAST_DIV, SAFE, SPLIT, false, 1, RPL_RUNS_AHEAD>(
             sink, p, cs, rsrc, blk0, blk_end, sd, mask_stride, use_xf, q_min16, ibfe_off, ibfe_w,
             flags, nullptr);
@@ -1774,7 +1781,7 @@ static hipError_t launch_runs(hipStream_t s, const void *nodes, uint32_t n_strid
                      (const uint2 *)nodes, n_stride, n_per_scan, p, p.inverted ? T.cs_inv : T.cs,
                      keepmask, mask_stride, (uint4 *)T.voxel_regions, (uint2 *)T.voxel_rcount, item0,
                      Bs, group, n_scans, cps, (uint32_t)(T.voxel_scan_major ? 1u : 0u), motion, pose2d,
-                     pipe, pipe_want);
+                     pipe, pipe_want, T.scan_t0);
   return hipGetLastError();
 }
 

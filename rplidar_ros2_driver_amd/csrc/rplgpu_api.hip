@@ -64,6 +64,7 @@ struct rplgpu_ctx {
   bool idx_checked = false, idx_ok = false;  // Mode A bin-index divide, see k_validate_idx
   unsigned long long *dbg = nullptr;  // developer aid: per-block phase cycle counters
   uint32_t *cell_keys = nullptr;      // optional cell-key output of the voxel kernel (rplgpu_set_cell_key_output)
+  const float *scan_t0 = nullptr;     // optional per-scan time offsets of E6 (rplgpu_set_scan_time_offsets_dev)
   // k_cloud_voxel's queue statistics of the previous launch, copied to pinned memory behind every
   // launch (no synchronisation): they choose the kernel instance of the NEXT launch (voxel_split)
   unsigned long long *h_vstats = nullptr;
@@ -260,6 +261,7 @@ rpl::Tables tables_of(rplgpu_ctx *c) {
   t.voxel_pipe_ctr = c->d_pipe_ctr;
   t.voxel_pipe_items = c->pipe_items;
   t.voxel_pipe_stream = c->vstream;
+  t.scan_t0 = c->scan_t0;
   t.voxel_pipe_ev[0] = c->ev_v[0];
   t.voxel_pipe_ev[1] = c->ev_v[1];
   return t;
@@ -690,6 +692,13 @@ int32_t rplgpu_set_cell_key_output(rplgpu_handle_t h, uint32_t *d_cell_keys) {
   return RPLGPU_OK;
 }
 
+int32_t rplgpu_set_scan_time_offsets_dev(rplgpu_handle_t h, const float *d_t0) {
+  if (!h) return RPLGPU_ERR_INVALID_ARG;
+  if (d_t0 && !device_readable(h, d_t0, "d_t0")) return RPLGPU_ERR_INVALID_ARG;
+  h->scan_t0 = d_t0;
+  return RPLGPU_OK;
+}
+
 int32_t rplgpu_set_voxel_aggregation(rplgpu_handle_t h, int32_t mode) {
   if (!h || mode < RPLGPU_VOXEL_AGG_AUTO || mode > RPLGPU_VOXEL_AGG_TWO_CLASS) return RPLGPU_ERR_INVALID_ARG;
   h->force_split = mode == RPLGPU_VOXEL_AGG_AUTO ? -1 : (mode == RPLGPU_VOXEL_AGG_TWO_CLASS ? 1 : 0);
@@ -913,6 +922,10 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
   if ((d_motion && !device_readable(h, d_motion, "d_motion")) ||
       (d_pose2d && !device_readable(h, d_pose2d, "d_pose2d")))
     return RPLGPU_ERR_INVALID_ARG;
+  if (h->scan_t0 && !d_motion) {
+    h->err = "rplgpu_cloud_fused_voxel_dev: scan time offsets are set (rplgpu_set_scan_time_offsets_dev) but d_motion is NULL";
+    return RPLGPU_ERR_INVALID_ARG;
+  }
   // Every sample of a group can end a run record: the record stores grow (only ever grow, and
   // only here — the first call with a larger group pays one reallocation) to group x stride.
   group = std::min(group, B);  // "all sensors in one grid" may be asked for with any group >= B

@@ -392,6 +392,44 @@ def test_deskewed_cloud_matches_oracle(gpu, oracle):
             assert got[b, : npts[b]].tobytes() == want.tobytes(), (clip, b)
             if b == 0:  # no motion: the plain cloud, untouched
                 assert want.tobytes() == plain.tobytes()
+    # time alignment (rplgpu_set_scan_time_offsets_dev): the scans did not start at the fused instant
+    t0 = np.array([0.0, -0.031, 0.012, 0.05, -2.5e-4, 0.0], np.float32)
+    d_t0 = torch.from_numpy(t0).to(dev)
+    p = Params.defaults(clip_enable=1, q_min=10, range_min=0.5, range_max=25.0)
+
+    def kept_index(nodes):
+        dm = nodes["dist_mm_q2"].astype(np.float32) / np.float32(4000.0)
+        return np.flatnonzero((nodes["dist_mm_q2"] != 0) & (nodes["quality"] >= 10) & (dm >= np.float32(0.5))
+                              & (dm <= np.float32(25.0)))
+
+    gpu.set_scan_time_offsets_dev(d_t0.data_ptr())
+    try:
+        gpu.cloud_deskew_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_motion.data_ptr(),
+                                   d_xyzi.data_ptr(), n, d_np.data_ptr(), d_st.data_ptr())
+        gpu.synchronize()
+    finally:
+        gpu.set_scan_time_offsets_dev(0)
+    got, npts = d_xyzi.cpu().numpy(), d_np.cpu().numpy()
+    moved = 0
+    for b in range(B):
+        nodes = batch[b, : lens[b]]
+        plain = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(p))
+        idx = kept_index(nodes)
+        assert len(idx) == npts[b]
+        want = fo.deskew_cloud(plain, idx, motion[b], t0[b])
+        assert got[b, : npts[b]].tobytes() == want.tobytes(), b
+        moved += want.tobytes() != fo.deskew_cloud(plain, idx, motion[b]).tobytes()
+    assert moved >= 3  # (scans 0 and 5 have a zero offset, scan 0 no motion either)
+    # offsets off again: the launch is the one without them, bit for bit
+    gpu.cloud_deskew_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_motion.data_ptr(),
+                               d_xyzi.data_ptr(), n, d_np.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    got = d_xyzi.cpu().numpy()
+    for b in range(B):
+        nodes = batch[b, : lens[b]]
+        plain = oracle.scan_to_cloud(nodes, oracle_lib.copy_params(p))
+        idx = kept_index(nodes)
+        assert got[b, : len(idx)].tobytes() == fo.deskew_cloud(plain, idx, motion[b]).tobytes()
     # voxel_enable is refused: de-skew belongs in front of the cell computation
     with pytest.raises(abi.RplGpuError):
         gpu.cloud_deskew_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B,
@@ -463,7 +501,7 @@ def test_laserscan_to_cloud_matches_oracle(gpu, oracle):
 
 
 # ------------------------------------------------ E8: one voxel grid per group of scans (row 4)
-def _e8_oracle(oracle, scans, p, motion, pose2d, leaf):
+def _e8_oracle(oracle, scans, p, motion, pose2d, leaf, t0=None):
     """Spec of rplgpu_cloud_fused_voxel_dev from its parts: E1 + E2 per scan (C oracle), E6
     de-skew and the planar pose (numpy restatements in oracle/fusion_oracle.py), then E4 over all
     points of the group (C oracle's voxel grid)."""
@@ -479,7 +517,7 @@ def _e8_oracle(oracle, scans, p, motion, pose2d, leaf):
         idx = np.flatnonzero(keep)
         assert not p.ror_enable and len(idx) == len(cloud)
         if motion is not None:
-            cloud = fo.deskew_cloud(cloud, idx, motion[s])
+            cloud = fo.deskew_cloud(cloud, idx, motion[s], None if t0 is None else t0[s])
         if pose2d is not None:
             r00, r01, tx, r10, r11, ty = pose2d[s]
             pose = np.array([[r00, r01, 0, tx], [r10, r11, 0, ty], [0, 0, 1, 0]], np.float32)
@@ -549,3 +587,69 @@ def test_fused_voxel_groups_match_oracle(gpu, oracle):
                 for b in range(B):
                     assert npts[b] == n2[b]
                     assert arena[start[b]: start[b] + npts[b]].tobytes() == a2[s2[b]: s2[b] + n2[b]].tobytes()
+
+
+def test_fused_voxel_time_alignment(gpu_mode, oracle):
+    """The temporal side of row 4: the sensors of a time step start their scans at different instants;
+    with rplgpu_set_scan_time_offsets_dev every point is de-skewed to the FUSED instant
+    (tau = t0 + i * time_increment) before the shared grid.  Against the composition of the oracles, in
+    every form of the voxel path; without motion the call is refused."""
+    import torch
+    import fusion_oracle as fo
+    gpu = gpu_mode
+    dev = torch.device("cuda:0")
+    n, group, G = 9000, 4, 3
+    B = group * G
+    scans = [synth.make_scan(4100, b, n, noise_m=0.005, r0_range=(2.0, 10.0)) for b in range(B)]
+    batch = np.stack(scans)
+    rng = np.random.default_rng(41)
+    motion = np.stack([[rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-0.8, 0.8), 0.1 / n]
+                       for _ in range(B)]).astype(np.float32)
+    t0 = rng.uniform(-0.08, 0.08, B).astype(np.float32)
+    t0[1] = 0.0
+    poses = np.stack([fo.planar_pose(rng.uniform(-3, 3), rng.uniform(-4, 4), rng.uniform(-4, 4)) for _ in range(B)])
+    pose2d = np.ascontiguousarray(poses[:, :2][:, :, [0, 1, 3]].reshape(B, 6))
+    p = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1, voxel_leaf=0.05)
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+    d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
+    d_motion = torch.from_numpy(motion).to(dev)
+    d_pose = torch.from_numpy(pose2d).to(dev)
+    d_t0 = torch.from_numpy(t0).to(dev)
+    cap = B * n
+
+    def run(with_motion=True):
+        d_arena = torch.zeros(cap, 4, dtype=torch.float32, device=dev)
+        d_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+        d_start = torch.zeros(G, dtype=torch.int64, device=dev)
+        d_np = torch.zeros(G, dtype=torch.int32, device=dev)
+        d_st = torch.zeros(G, dtype=torch.int32, device=dev)
+        gpu.cloud_fused_voxel_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, group, p,
+                                  d_motion.data_ptr() if with_motion else 0, d_pose.data_ptr(), d_arena.data_ptr(),
+                                  cap, d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+        gpu.synchronize()
+        assert int(d_st.max()) == 0
+        return d_arena.cpu().numpy(), d_start.cpu().numpy(), d_np.cpu().numpy()
+
+    base = run()
+    gpu.set_scan_time_offsets_dev(d_t0.data_ptr())
+    try:
+        arena, start, npts = run()
+        with pytest.raises(abi.RplGpuError):
+            run(with_motion=False)
+    finally:
+        gpu.set_scan_time_offsets_dev(0)
+    differs = 0
+    for g in range(G):
+        sl = slice(g * group, (g + 1) * group)
+        want, _, _ = _e8_oracle(oracle, scans[sl], p, motion[sl], pose2d[sl], 0.05, t0[sl])
+        got = arena[start[g]: start[g] + npts[g]]
+        assert len(got) == len(want), g
+        assert np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2])) <= 1e-6
+        assert got[:, 3].tobytes() == want[:, 3].tobytes()
+        b0 = base[0][base[1][g]: base[1][g] + base[2][g]]
+        differs += len(b0) != len(got) or b0.tobytes() != got.tobytes()
+    assert differs == G  # the offsets move the points: every group's grid changes
+    after = run()  # offsets off again: the launch without them
+    for g in range(G):
+        assert after[0][after[1][g]: after[1][g] + after[2][g]].tobytes() == \
+            base[0][base[1][g]: base[1][g] + base[2][g]].tobytes()

@@ -255,3 +255,31 @@ def test_laserscan_to_cloud_oracle_vs_numpy(oracle, name):
     pts = oracle.laserscan_to_cloud(r, i, p)
     rr = r[np.isfinite(r)]
     assert np.max(np.abs(np.hypot(pts[:, 0].astype(np.float64), pts[:, 1]) - rr)) < 1e-5
+
+
+def test_fusion_oracle_time_offsets():
+    """oracle/fusion_oracle.py, E6 with a start offset (rplgpu_set_scan_time_offsets_dev): properties of the
+    spec itself — no offset = the old formula bit for bit; a pure translation moves every point by v * tau
+    with tau = t0 + i * dt rounded in that order; at the fused instant itself (tau = 0) a point stays."""
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "oracle"))
+    import fusion_oracle as fo
+    rng = np.random.default_rng(7)
+    n = 4000
+    cloud = np.zeros((n, 4), np.float32)
+    cloud[:, :2] = rng.uniform(-20, 20, (n, 2)).astype(np.float32)
+    cloud[:, 3] = rng.integers(0, 64, n).astype(np.float32)
+    idx = np.sort(rng.choice(32000, n, replace=False))
+    dt = np.float32(3.125e-6)
+    a = fo.deskew_cloud(cloud, idx, (1.2, -0.4, 0.7, dt))
+    assert a.tobytes() == fo.deskew_cloud(cloud, idx, (1.2, -0.4, 0.7, dt), None).tobytes()
+    t0 = np.float32(-0.0375)
+    tr = fo.deskew_cloud(cloud, idx, (2.0, -3.0, 0.0, dt), t0)   # no rotation: x' = x + vx * tau
+    tau = (t0 + (idx.astype(np.float32) * dt).astype(np.float32)).astype(np.float32)
+    assert tr[:, 0].tobytes() == (cloud[:, 0] + (np.float32(2.0) * tau).astype(np.float32)).astype(np.float32).tobytes()
+    assert tr[:, 1].tobytes() == (cloud[:, 1] + (np.float32(-3.0) * tau).astype(np.float32)).astype(np.float32).tobytes()
+    assert tr[:, 2:].tobytes() == cloud[:, 2:].tobytes()
+    i0 = np.array([12800])                                   # 12800 * 3.125e-6 = 0.04 s, exactly -t0
+    pt = cloud[:1]
+    at = fo.deskew_cloud(pt, i0, (5.0, 5.0, 1.0, dt), np.float32(-0.04))
+    assert np.max(np.abs(at[:, :2] - pt[:, :2])) <= 1e-6     # (0.04f is not 12800 * dt exactly: tau ~ 1e-9 s)
