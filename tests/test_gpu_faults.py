@@ -234,6 +234,18 @@ def test_round2_entry_points_reject_bad_arguments_and_recover(oracle):
         assert fused(arena=0) == abi.ERR_INVALID_ARG
         host_motion = np.zeros((Bs, 4), np.float32)
         assert fused(motion=host_motion.ctypes.data) == abi.ERR_INVALID_ARG
+        # per-scan time offsets: a host pointer is refused; set, they require d_motion; cleared, all is as before
+        host_t0 = np.zeros(Bs, np.float32)
+        assert lib.rplgpu_set_scan_time_offsets_dev(h, host_t0.ctypes.data) == abi.ERR_INVALID_ARG
+        assert lib.rplgpu_set_scan_time_offsets_dev(None, None) == abi.ERR_INVALID_ARG
+        d_t0 = torch.zeros(Bs, dtype=torch.float32, device=dev)
+        d_mo = torch.zeros(Bs, 4, dtype=torch.float32, device=dev)
+        assert lib.rplgpu_set_scan_time_offsets_dev(h, d_t0.data_ptr()) == abi.OK
+        assert fused() == abi.ERR_INVALID_ARG
+        assert b"d_motion" in lib.rplgpu_last_error(h)
+        assert fused(motion=d_mo.data_ptr()) == abi.OK
+        assert lib.rplgpu_set_scan_time_offsets_dev(h, None) == abi.OK
+        assert fused() == abi.OK
         _still_works(gpu, oracle)
 
         # LaserScan -> cloud, and the exchange before rplgpu_comm_init
