@@ -534,7 +534,7 @@ def main():
     import torch.distributed as dist
 
     from rplidar_ros2_driver_amd import Params, RplGpu, synth
-    from rplidar_ros2_driver_amd.sharding import CloudExchange, predicted_step_ms, shard_range
+    from rplidar_ros2_driver_amd.sharding import CloudExchange, best_chunks, launch_rel, predicted_step_ms, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -602,9 +602,15 @@ def main():
         # chunks; chunk k is voxelised into arena half (k & 1) while chunk k - 1 is gathered
         # (auto: with one rank there is no transfer to hide, so one chunk = one launch; with peers
         # two chunks, so that the first half's clouds travel while the second half is voxelised)
-        # (round 5: four chunks with peers — by DESIGN.md §7's model the exchange of all but the LAST
-        # chunk can hide under compute, so 3/4 instead of 1/2 of it; sharding.predicted_step_ms)
-        n_chunks = args.chunks if args.chunks > 0 else (1 if world == 1 else 4)
+        # (round 5: with peers the chunk count comes from DESIGN.md section 7's model — sharding.best_chunks: more
+        # chunks hide more of the exchange under compute, but every chunk is a launch with its own fixed cost and,
+        # below one scan per compute unit, idle units; a priori figures: the one-GPU launch time of this workload
+        # and 12 bytes x ~2670 cells per scan of cloud)
+        if args.chunks > 0:
+            n_chunks = args.chunks
+        else:
+            n_chunks = best_chunks(world, 0.449 * launch_rel(B_total) / launch_rel(4096), 12.0 * 2670.0 * B_total,
+                                   B_total, gather_root=args.exchange == "gather")
         exch = CloudExchange(gpu, dist, dev, world, rank, B, n, out_stride, n_chunks,
                              root=0 if args.exchange == "gather" else None)
         if exch.native and exch.comm_ranks != world:
@@ -663,9 +669,10 @@ def main():
                         "comm_ranks": exch.comm_ranks, "exchange": args.exchange,
                         "model_ms_per_step": round(predicted_step_ms(
                             world, ms_c * world, 12.0 * world * exch.chunks * (exch.slot or 0), exch.chunks,
-                            gather_root=args.exchange == "gather"), 4),
-                        "model_note": "DESIGN.md section 7: per rank compute/chunks per piece, a piece's slot "
-                                      "on one 76.8 GB/s link, pieces pipelined; measured = overlapped_ms",
+                            gather_root=args.exchange == "gather", scans_total=B_total), 4),
+                        "model_note": "DESIGN.md section 7: a piece = one launch over the rank's scans / chunks (measured "
+                                      "launch-time curve) + its slot on one 76.8 GB/s link + 0.015 ms, pieces "
+                                      "pipelined; measured = overlapped_ms; chunks chosen by the same model",
                         "note": "compute = the rank's whole block in one launch, no exchange; "
                                 "exchange_only = RCCL all-gather of the last step's clouds; "
                                 "overlapped = the timed step (chunked, two streams)"}

@@ -188,22 +188,60 @@ def gather_slots_to_root(slot: torch.Tensor, meta: torch.Tensor, root: int, grou
     return None, None
 
 
+# Launch time of the voxel kernel against the scans of ONE launch on one MI355X (256 compute units, 32 000-sample
+# ring scans; profiles/r05/voxel_instruction_mix_r05.txt section 5), relative to the 4096-scan launch: a launch of
+# few scans pays its fixed cost (launch, prologue, the tail of a dynamically drawn queue) and, below one scan per
+# compute unit, leaves units idle.  What a CHUNK of a step costs — the reason more chunks are not always better.
+_LAUNCH_REL = ((0, 0.06), (128, 0.12), (256, 0.1376), (512, 0.2180), (1024, 0.3131), (2048, 0.5365), (4096, 1.0),
+               (8192, 1.9333), (16384, 3.8173))
+_EXCHANGE_FIXED_MS = 0.015  # per chunk: the collective's launch + the unpack kernel (one-rank runs, 1 / 4 / 8 chunks)
+
+
+def launch_rel(scans: float) -> float:
+    """Interpolated `_LAUNCH_REL` (linear between the measured points, the last slope beyond them)."""
+    pts = _LAUNCH_REL
+    if scans >= pts[-1][0]:
+        (x0, y0), (x1, y1) = pts[-2], pts[-1]
+        return y1 + (scans - x1) * (y1 - y0) / (x1 - x0)
+    for (x0, y0), (x1, y1) in zip(pts, pts[1:]):
+        if scans <= x1:
+            return y0 + (max(scans, x0) - x0) * (y1 - y0) / (x1 - x0)
+    return pts[-1][1]
+
+
 def predicted_step_ms(world: int, compute_ms_one_gpu: float, cloud_bytes_total: float, chunks: int,
-                      gather_root: bool = False, link_gbs: float = 76.8) -> float:
-    """DESIGN.md §7's model of a step on `world` GPUs (strong scaling of one batch): every rank
-    computes 1/world of the batch in `chunks` pieces; a piece's exchange starts when the piece is
-    computed and pieces follow one another on the links.  All-gather: a link carries one rank's
-    share of a piece (the links of a rank work in parallel); gather to root: the root's links carry
-    the same (one slot each) but nothing else moves.  Returns milliseconds."""
+                      gather_root: bool = False, link_gbs: float = 76.8, scans_total: int = 4096) -> float:
+    """DESIGN.md section 7's model of a step on `world` GPUs (strong scaling of one batch of `scans_total`
+    scans): every rank computes 1/world of the batch in `chunks` launches — a launch priced with the measured
+    launch-time curve, scaled to `compute_ms_one_gpu` (the whole batch in one launch on one GPU) — a piece's
+    exchange starts when the piece is computed and pieces follow one another on the links.  All-gather: a link
+    carries one rank's share of a piece (the links of a rank work in parallel); gather to root: the root's links
+    carry the same (one slot each) but nothing else moves.  Every piece also pays the exchange's fixed cost.
+    Returns milliseconds."""
     if world <= 1:
         return compute_ms_one_gpu
-    comp = compute_ms_one_gpu / world / chunks            # one piece on one rank
-    exch = cloud_bytes_total / world / chunks / (link_gbs * 1e6)  # one piece on one link, ms
+    comp = compute_ms_one_gpu * launch_rel(scans_total / world / chunks) / launch_rel(scans_total)
+    exch = cloud_bytes_total / world / chunks / (link_gbs * 1e6) + _EXCHANGE_FIXED_MS  # one piece on one link, ms
     t_c = t_x = 0.0
     for _ in range(chunks):
         t_c += comp
         t_x = max(t_x, t_c) + exch
     return t_x
+
+
+def best_chunks(world: int, compute_ms_one_gpu: float, cloud_bytes_total: float, scans_total: int,
+                gather_root: bool = False, candidates=(1, 2, 4, 8)) -> int:
+    """The chunk count the model prefers (ties: fewer chunks).  One rank: one chunk — there is nothing to hide."""
+    if world <= 1:
+        return 1
+    best, best_ms = 1, float("inf")
+    for c in candidates:
+        if c > max(scans_total // world, 1):
+            break
+        ms = predicted_step_ms(world, compute_ms_one_gpu, cloud_bytes_total, c, gather_root, scans_total=scans_total)
+        if ms < best_ms * 0.995:
+            best, best_ms = c, ms
+    return best
 
 
 class CloudExchange:

@@ -108,6 +108,29 @@ def _worker(rank, world, port, total, n, q):
         dist.destroy_process_group()
 
 
+def test_step_model_and_chunk_choice():
+    """sharding.predicted_step_ms / best_chunks: the measured launch-time curve makes a
+    chunk a launch with a fixed cost, so more chunks are not always better; one rank never chunks."""
+    from rplidar_ros2_driver_amd.sharding import best_chunks, launch_rel, predicted_step_ms
+    assert launch_rel(4096) == 1.0 and launch_rel(8192) > 1.9 and launch_rel(16384) > 3.8
+    xs = [0, 64, 128, 256, 300, 512, 1000, 2048, 4096, 9000, 20000, 40000]
+    ys = [launch_rel(x) for x in xs]
+    assert all(b > a for a, b in zip(ys, ys[1:]))               # monotone
+    assert launch_rel(256) / launch_rel(4096) > 256 / 4096 * 2  # a small launch is far from proportional
+    one = 0.449
+    assert predicted_step_ms(1, one, 131e6, 4) == one and best_chunks(1, one, 131e6, 4096) == 1
+    for world in (2, 4, 8):
+        ms = {c: predicted_step_ms(world, one, 131e6, c, scans_total=4096) for c in (1, 2, 4, 8)}
+        best = best_chunks(world, one, 131e6, 4096)
+        assert ms[best] <= min(ms.values()) * 1.006
+        assert ms[2] < ms[1]                       # hiding half the compute under the exchange pays ...
+        assert ms[8] > min(ms.values())            # ... eight launches per step do not
+        # the exchange is the step from two GPUs on: never faster than the slot on one link
+        assert min(ms.values()) > 131e6 / world / 76.8e6
+    assert best_chunks(8, one, 131e6, 4096) == 2   # 512 scans per rank: a quarter of them is half a GPU
+    assert best_chunks(4, one, 131e6, 8) <= 2      # never more chunks than scans per rank
+
+
 def test_allgather_clouds_world2_gloo():
     world, total, n = 2, 5, 1500  # uneven shard: 3 + 2 scans
     ctx = mp.get_context("spawn")
