@@ -340,6 +340,10 @@ __device__ __forceinline__ void voxel_pair(const uint32_t (&lo)[2], const uint32
 #define RPL_VOXEL_SPLIT_ABOVE 26  // clean rings: <= ~21 runs per 128 samples at r = 30 m
 #endif
 constexpr uint32_t kSplitAbove = RPL_VOXEL_SPLIT_ABOVE;
+#ifndef RPL_VOXEL_BRIDGE
+#define RPL_VOXEL_BRIDGE 2  // FILL passes: wholly dropped lanes a run may cross (see voxel_block_pass)
+#endif
+constexpr int kBridge = RPL_VOXEL_BRIDGE;
 // Only the kernel instance the launcher picks for batches known to be noisy compiles kPassSplit:
 // inlined next to the plain path it costs a clean batch 1.5-2.7 % (profiles/r03/voxel_split_r03.txt).
 enum : int { kPassPlain = 0, kPassSplit = 2 };
@@ -382,8 +386,29 @@ __device__ __forceinline__ bool voxel_block_pass(Sink &S, const bool (&ok)[NS], 
     for (int j = 0; j < NS; ++j) okm[j] = __builtin_amdgcn_ballot_w64(ok[j]);
   }
   // lane l+1's first key (lane 63: any value, its successor counts as dropped below)
-  const uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)key[0], 0x130,
-                                                              0xF, 0xF, false);  // wave_shl:1
+  uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)key[0], 0x130,
+                                                        0xF, 0xF, false);  // wave_shl:1
+  // FILL: a lane BOTH of whose samples were dropped (the other class's, a low-quality pair, a masked
+  // pair) is transparent as well — the run of the lane in front of it goes on in the lane behind it
+  // when the keys agree — for gaps of up to kBridge lanes.  Dropped samples contribute zeros, so the
+  // prefix sums do not see them.  (1 cm noise: 5800 -> 4900 -> 4650 records per scan with 1 / 2
+  // lanes bridged; every record less is one less in every step of phase R.)
+  uint64_t ok_after = okm[0] >> 1;  // the lane behind has a kept sample
+  if (FILL && kBridge > 0) {
+    uint32_t far = next;
+    uint64_t reach = ok_after;      // some lane within the bridge has a kept sample
+#pragma unroll
+    for (int g = 1; g <= kBridge; ++g) {
+      far = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFEu, (int)far, 0x130, 0xF, 0xF, false);
+      const uint64_t here = okm[0] >> (g + 1);  // lane l + g + 1 has a kept sample
+      // the nearest lane with a kept sample decides: lanes nearer than g + 1 have none iff !reach
+      uint32_t pick;
+      asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(pick) : "v"(far), "v"(next), "s"(reach));
+      next = pick;
+      reach |= here;
+    }
+    ok_after = reach;
+  }
   // run-end masks built in scalar registers: (sample kept) & (key differs from the next one, or
   // the next one is dropped).  Written with explicit compares because `ballot(a && b)` is
   // materialised by the compiler as v_cndmask + v_cmp per mask; the per-lane predicates for the
@@ -397,7 +422,7 @@ __device__ __forceinline__ bool voxel_block_pass(Sink &S, const bool (&ok)[NS], 
   for (int j = 0; j < NS; ++j) {
     const uint32_t nk = j + 1 < NS ? key[j + 1 < NS ? j + 1 : 0] : next;
     asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m[j]) : "v"(key[j]), "v"(nk));
-    const uint64_t ok_next = j + 1 < NS ? okm[j + 1 < NS ? j + 1 : 0] : (okm[0] >> 1);
+    const uint64_t ok_next = j + 1 < NS ? okm[j + 1 < NS ? j + 1 : 0] : ok_after;
     m[j] = okm[j] & (m[j] | ~ok_next);
     total += (uint32_t)__popcll(m[j]);
   }
