@@ -31,6 +31,8 @@ d_np = torch.zeros(B, dtype=torch.int32, device=dev)
 d_st = torch.zeros(B, dtype=torch.int32, device=dev)
 p = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1, voxel_leaf=0.05)
 gpu = RplGpu(device=0, max_samples_per_scan=32768, max_batch=B)
+if os.environ.get("VB_AGG"):  # 0 auto, 1 plain, 2 two-class (rplgpu_set_voxel_aggregation)
+    gpu.set_voxel_aggregation(int(os.environ["VB_AGG"]))
 stream = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(stream)
 gpu.set_stream(stream.cuda_stream)
