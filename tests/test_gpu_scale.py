@@ -211,3 +211,40 @@ def test_exchange_slot_written_by_the_kernel_equals_the_packed_arena(gpu_mode, r
             if n2[b] == npts[b] and npts[b]:
                 want = arena[start[b]: start[b] + npts[b]][:, [0, 1, 3]]
                 assert pts[s2[b]: s2[b] + n2[b]].tobytes() == np.ascontiguousarray(want).tobytes(), (slot, b)
+
+
+def test_runs_across_dropped_lanes_patterns(gpu_mode, oracle):
+    """The FILL passes (a class of a two-class block, the quality filter, the E5 mask) let a run cross dropped
+    samples and up to two wholly dropped lanes (a lane = two consecutive samples).  Scans built to sit on every
+    branch of that: points alternating between two or three cells in groups of 1 ... 7 samples (so that the other
+    class's — or the low-quality — samples fill 0, 1, 2, 3 whole lanes between two samples of one cell), at every
+    lane phase and across the 128-sample block ends and the lane 63 | lane 0 seam, with random invalid samples on
+    top; with and without the quality filter and the ROR mask.  Every scan against the oracle, in every form."""
+    gpu = gpu_mode
+    rng = np.random.default_rng(515)
+    B, n = 96, 4096
+    batch = np.zeros((B, n), synth.NODE_DTYPE)
+    for b in range(B):
+        group = 1 + b % 7                      # samples per stretch in one cell
+        ncell = 2 + (b // 7) % 2               # cells the stretches rotate through
+        phase = int(rng.integers(0, 2 * group + 1))
+        i = np.arange(n)
+        which = ((i + phase) // group) % ncell
+        ang = (i.astype(np.float64) / n) * 2.0 * np.pi
+        r0 = 3.0 + 0.37 * (b % 11)
+        # radial offsets that put neighbouring stretches into different 5 cm cells (and, for odd b, into cells
+        # of the SAME checkerboard colour two cells apart as well)
+        step = 0.05 if b % 2 == 0 else 0.10
+        r = r0 + which * step + rng.normal(0.0, 0.002, n)
+        d = np.clip(np.round(r * 4000.0), 1, 2 ** 31).astype(np.uint32)
+        q = rng.integers(0, 256, n).astype(np.uint8) if b % 3 == 0 else np.where(which == 0, 200, 20 + (b % 5) * 10).astype(np.uint8)
+        inv = rng.random(n) < (0.0 if b % 4 else 0.06)
+        d[inv] = 0
+        batch[b]["angle_z_q14"] = np.round(ang * (32768.0 / np.pi)).astype(np.int64) % 65536
+        batch[b]["dist_mm_q2"] = d
+        batch[b]["quality"] = q
+        batch[b]["flag"] = 0
+    for qmin, ror in ((0, 0), (48, 0), (120, 0), (0, 1), (48, 1)):
+        p = Params.defaults(clip_enable=1, q_min=qmin, range_min=0.15, range_max=40.0, voxel_enable=1,
+                            voxel_leaf=0.05, ror_enable=ror, ror_radius=0.08, ror_min_neighbors=2)
+        _check_batch(gpu, oracle, batch, p, cap_per_scan=n)
