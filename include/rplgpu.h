@@ -60,9 +60,7 @@ extern "C" {
 #define RPLGPU_SCAN_CELL_RANGE 0x2u    /* voxel: |cell index| >= 32767 (range/leaf too large) */
 #define RPLGPU_SCAN_TABLE_FULL 0x4u    /* voxel: more occupied cells than the on-chip table holds */
 #define RPLGPU_SCAN_OUT_TRUNCATED 0x8u /* output region (out_stride) too small; count is clamped */
-#define RPLGPU_SCAN_NOT_PRODUCED 0x80u /* voxel, pipelined two-kernel form only: the item's run records
-                                          never arrived (the producer kernel did not run next to the
-                                          consumer, e.g. serialised queues); the item is EMPTY (0 points) */
+/* 0x80u: reserved (rounds 4-5: RPLGPU_SCAN_NOT_PRODUCED of the pipelined two-kernel voxel form, removed) */
 /* per-stream status bits of the decode stage */
 #define RPLGPU_STREAM_UNFRAMED 0x10u         /* frames given back to back but a frame does not start
                                                  with its sync pattern: run rplgpu_frame_stream */

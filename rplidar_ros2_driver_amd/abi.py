@@ -32,7 +32,6 @@ SCAN_ALL_INVALID = 0x1
 SCAN_CELL_RANGE = 0x2
 SCAN_TABLE_FULL = 0x4
 SCAN_OUT_TRUNCATED = 0x8
-SCAN_NOT_PRODUCED = 0x80
 
 SL_RESULT_OK = 0
 SL_RESULT_OPERATION_FAIL = 0x80008001

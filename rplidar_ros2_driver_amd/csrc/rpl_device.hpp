@@ -37,19 +37,6 @@ struct Tables {
   unsigned long long *voxel_stats;  // [0] queue entries, [1] work items of the launch (device; may be null)
   unsigned long long *voxel_stats_host;  // pinned copy of voxel_stats, refreshed behind every launch (or null)
   int32_t voxel_split;     // host decision from the previous launch's statistics: the noisy-batch instance
-  // two-kernel path (k_voxel_runs + k_voxel_cells, rpl_voxel.hip): the region store
-  void *voxel_regions;        // voxel_region_cap regions of voxel_region_bytes() each (or null)
-  void *voxel_rcount;         // one (entry count, status flags) pair per region
-  uint32_t voxel_region_cap;  // regions the store holds
-  int32_t voxel_two_kernel;   // 0: fused kernel only; 1: two kernels for stages that fill the device; 2: always
-  uint32_t voxel_stage_items; // items per stage at most (0: as many as the store holds)
-  int32_t voxel_scan_major;   // task order of k_voxel_runs (developer aid; 0 = chunk-major)
-  // pipelining of the two kernels (k_voxel_cells next to k_voxel_runs on the same CUs)
-  int32_t voxel_pipe;         // 0: one after the other on the caller's stream; n > 0: pipelined, n x 4 producer waves per SIMD
-  uint32_t *voxel_pipe_ctr;   // [0] task counter, [1] item counter, [2 ...] ready count per item of a stage
-  uint32_t voxel_pipe_items;  // items the ready counts hold (a pipelined stage has no more)
-  void *voxel_pipe_stream;    // hipStream_t of the consumer
-  void *voxel_pipe_ev[2];     // hipEvent_t: fork, join
   const float *scan_t0;       // per scan: time of its first sample relative to the fused instant (E6), or null
 };
 

@@ -78,9 +78,6 @@ inline uint64_t voxel_store_need(uint32_t group, uint32_t n_stride) {
   const uint64_t s = n_stride < kMaxN ? n_stride : kMaxN;
   return (uint64_t)(group ? group : 1u) * (s + 2u * ((s + 127u) / 128u) + 1u);
 }
-// the two-kernel path's region store: regions a work item of `group` scans needs, bytes per region
-uint32_t voxel_regions_per_item(uint32_t group, uint32_t n_stride);
-uint64_t voxel_region_bytes();
 hipError_t launch_ror_mask(hipStream_t s, const void *nodes, uint32_t n_stride,
                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                            const Tables &T, uint32_t *mask, uint32_t mask_stride);

@@ -74,10 +74,6 @@ static_assert(kRecCap * 2u <= 2u * kRowCap * 4u, "the cell-head list (u16) lives
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#ifdef RPL_VX_IDXEN
-typedef int i4v __attribute__((ext_vector_type(4)));
-__device__ f2 llvm_struct_load_f2(i4v rsrc, int vindex, int voffset, int soffset, int aux) __asm("llvm.amdgcn.struct.buffer.load.v2f32");
-#endif
 #ifndef RPL_VOXEL_AHEAD
 #define RPL_VOXEL_AHEAD 2
 #endif
@@ -164,12 +160,6 @@ __device__ __forceinline__ void lds_store128(uint32_t lds_byte_addr, u32x4 v) {
 }
 __device__ __forceinline__ void glb_store128(void *p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
-}
-// (sc1: agent scope — the entry is written through to where the other XCDs' compute units see it;
-// the consumer of a region may run behind another L2, and a release fence per region, i.e. a
-// buffer_wbl2 per wave task, made the producer ten times slower)
-__device__ __forceinline__ void glb_store128_off(const void *base, uint32_t byte_off, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
 }
 
 // E8 (include/rplgpu_msg.h): what happens to a point between polar->XY and the grid when a GROUP
@@ -258,68 +248,6 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
   return kept;
 }
 
-#ifdef RPL_VX_V2
-// (developer experiment, round 5: instruction-mix variants of the per-sample arithmetic for the two
-// samples of a lane; bit 0 the divide by 4000 of both samples as packed operations, bit 1 the
-// fixed-point scale folded into dist_m — power of two, exact — so that the offsets come out of the
-// remainder FMA directly)
-template <bool FAST_DIV, bool SAFE, bool HASQ>
-__device__ __forceinline__ void voxel_pair(const uint32_t (&lo)[2], const uint32_t (&hi)[2], const float2 (&c)[2],
-                                           const KParams &p, uint32_t q_min16, uint32_t ibfe_off, uint32_t ibfe_w,
-                                           bool (&ok)[2], uint32_t (&key)[2], uint32_t (&qx)[2], uint32_t (&qy)[2],
-                                           uint32_t (&ci)[2], uint32_t &flags) {
-  f2 df;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const uint32_t d = __builtin_amdgcn_alignbit(hi[j], lo[j], 16);
-    bool kept = (d - p.d_lo) <= p.d_span;
-    if (HASQ) kept = kept & ((hi[j] & 0x00FF0000u) >= q_min16);
-    ok[j] = kept;
-    df[j] = __uint2float_rn(kept ? d : 0u);
-  }
-  f2 dm;
-  if ((RPL_VX_V2 & 1) && FAST_DIV) {
-    dm = div_by2(df, 4000.0f, 0.00025f);
-  } else {
-    dm.x = FAST_DIV ? div_by(df.x, 4000.0f, 0.00025f) : df.x / 4000.0f;
-    dm.y = FAST_DIV ? div_by(df.y, 4000.0f, 0.00025f) : df.y / 4000.0f;
-  }
-  const bool scaled = (RPL_VX_V2 & 2) != 0;
-  const float leaf = scaled ? p.leaf_s : p.voxel_leaf, inv_leaf = scaled ? p.inv_leaf_s : p.inv_leaf;
-  if (scaled) dm = dm * p.vox_scale_f;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const f2 cv = {c[j].x, c[j].y};
-    const f2 xy = cv * dm[j];
-    f2 t;
-    if (FAST_DIV) {
-      t = div_by2(xy, leaf, inv_leaf);
-    } else {
-      t.x = xy.x / leaf;
-      t.y = xy.y / leaf;
-    }
-    const f2 f = {__builtin_floorf(t.x), __builtin_floorf(t.y)};
-    if (!SAFE) {
-      const bool inr = (fabsf(f.x) < 32767.0f) && (fabsf(f.y) < 32767.0f);
-      if (ok[j] && !inr) flags |= RPLGPU_SCAN_CELL_RANGE;
-      ok[j] = ok[j] & inr;
-    }
-    const uint32_t kx = __float_as_uint(f.x + kKeyMagic);
-    const uint32_t ky = __float_as_uint(f.y + kKeyMagic);
-    key[j] = __builtin_amdgcn_perm(ky, kx, 0x05040100u);
-    const f2 lf = {leaf, leaf};
-    const f2 r = __builtin_elementwise_fma(-f, lf, xy);
-    const f2 o = scaled ? r : r * p.vox_scale_f;
-    qx[j] = (uint32_t)(int)o.x;
-    qy[j] = (uint32_t)(int)o.y;
-    if (!SAFE) {
-      qx[j] = ok[j] ? qx[j] : 0u;
-      qy[j] = ok[j] ? qy[j] : 0u;
-    }
-    ci[j] = ok[j] ? ((1u << 16) | ((hi[j] >> ibfe_off) & ibfe_w)) : 0u;
-  }
-}
-#endif
 
 // Cross-lane part of one block of 64 * NS samples: lane l holds the NS consecutive samples
 // NS l .. NS l + NS - 1 (ok[j]: the sample survived the keep mask).  A record is written where a
@@ -347,23 +275,14 @@ constexpr int kBridge = RPL_VOXEL_BRIDGE;
 // Only the kernel instance the launcher picks for batches known to be noisy compiles kPassSplit:
 // inlined next to the plain path it costs a clean batch 1.5-2.7 % (profiles/r03/voxel_split_r03.txt).
 enum : int { kPassPlain = 0, kPassSplit = 2 };
-// Where a block's queue entries go.  QueueSink: the fused kernel's per-scan queue (LDS while it has
-// room, the workgroup's record store after that; the position comes from an LDS atomic).
-// RegionSink: the streaming kernel of the two-kernel path (k_voxel_runs) — a wave owns a chunk of
-// consecutive blocks and appends to its own region of the record store at a cursor it keeps in a
-// scalar register: no atomic, no LDS, no other wave involved.
+// Where a block's queue entries go: the per-scan queue (LDS while it has room, the workgroup's
+// record store after that; the position comes from an LDS atomic).
 struct QueueSink {
-  static constexpr bool kRegion = false;
   VoxelLds &L;
   uint4 *G;
 };
-struct RegionSink {
-  static constexpr bool kRegion = true;
-  uint4 *R;      // first entry of this wave's region (wave-uniform)
-  uint32_t cur;  // entries written so far (wave-uniform)
-};
-template <bool FILL, int NS, int MODE = kPassPlain, class Sink>
-__device__ __forceinline__ bool voxel_block_pass(Sink &S, const bool (&ok)[NS], uint32_t (&key)[NS],
+template <bool FILL, int NS, int MODE = kPassPlain>
+__device__ __forceinline__ bool voxel_block_pass(QueueSink &S, const bool (&ok)[NS], uint32_t (&key)[NS],
                                                  const uint32_t (&qx)[NS], const uint32_t (&qy)[NS],
                                                  const uint32_t (&ci)[NS]) {
   uint64_t okm[NS];
@@ -432,13 +351,11 @@ __device__ __forceinline__ bool voxel_block_pass(Sink &S, const bool (&ok)[NS], 
   // overlaps the scans below (hand-placed so that the compiler's atomic optimiser does not wait
   // for it right away)
   uint32_t base = 0u;
-  if constexpr (!Sink::kRegion) {
-    if (lane_id() == 0) {
-      asm volatile("ds_add_rtn_u32 %0, %1, %2"
-                   : "=v"(base)
-                   : "v"((uint32_t)(uintptr_t)&S.L.misc[0]), "v"(total + 1u)
-                   : "memory");
-    }
+  if (lane_id() == 0) {
+    asm volatile("ds_add_rtn_u32 %0, %1, %2"
+                 : "=v"(base)
+                 : "v"((uint32_t)(uintptr_t)&S.L.misc[0]), "v"(total + 1u)
+                 : "memory");
   }
   // lane totals -> inclusive block prefix of the lane's LAST sample; the others by subtraction
   uint32_t Px = qx[0], Py = qy[0], Pc = ci[0];
@@ -455,13 +372,8 @@ __device__ __forceinline__ bool voxel_block_pass(Sink &S, const bool (&ok)[NS], 
   for (int j = 0; j < NS; ++j)
     before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[j] >> 32),
                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m[j], before));
-  if constexpr (Sink::kRegion) {
-    base = S.cur;
-    S.cur = base + total + 1u;
-  } else {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(base)::"memory");
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(base)::"memory");
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
   uint32_t pos[NS];
   pos[0] = base + 1u + before;  // entries are queued in sample order behind the marker
 #pragma unroll
@@ -480,18 +392,6 @@ __device__ __forceinline__ bool voxel_block_pass(Sink &S, const bool (&ok)[NS], 
   // selected pointer, and a flat instruction anywhere in the loop makes every wait for the
   // prefetched loads a vmcnt(0) (flat accesses return out of order).  The compiler does not see
   // these stores: the stream loop ends with an explicit wait for them before its barrier.
-  if constexpr (Sink::kRegion) {
-    // (saddr form: 32-bit byte offset per lane + the region's base in scalar registers)
-#ifndef RPL_ABL_NOSTORE  // (developer ablation: the streaming kernel without its record stores)
-    if (lane_id() == 0) glb_store128_off(S.R, base * 16u, marker);
-#pragma unroll
-    for (int j = 0; j < NS; ++j)
-      if (__builtin_amdgcn_inverse_ballot_w64(m[j])) glb_store128_off(S.R, pos[j] * 16u, rec[j]);
-#else
-    asm volatile("" ::"v"(rec[0]), "v"(rec[NS - 1]), "v"(pos[0]), "v"(pos[NS - 1]));
-#endif
-    return false;
-  } else {
   VoxelLds &L = S.L;
   uint4 *const G = S.G;
   const uint32_t lds_rec = (uint32_t)(uintptr_t)&L.rec[0];
@@ -512,13 +412,12 @@ __device__ __forceinline__ bool voxel_block_pass(Sink &S, const bool (&ok)[NS], 
     }
   }
   return false;
-  }
 }
 
 // A noisy block in two classes (see kPassSplit): class c keeps the samples whose cell has
 // (ix + iy) & 1 == c, the others count as dropped (zero contribution, neighbour's key).
-template <int NS, class Sink>
-__device__ __forceinline__ void voxel_block_split(Sink &S,
+template <int NS>
+__device__ __forceinline__ void voxel_block_split(QueueSink &S,
                                                   const bool (&ok)[NS], const uint32_t (&key)[NS],
                                                   const uint32_t (&qx)[NS], const uint32_t (&qy)[NS],
                                                   const uint32_t (&ci)[NS]) {
@@ -858,10 +757,9 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
 }
 
 // ------------------------------------------------------------------------------
-// Phase S over the blocks blk0, blk0 + STEP, ... < blk_end of ONE scan (`scan_rsrc`: a bounds-checked
+// Phase S over the blocks blk0, blk0 + kVW, ... < blk_end of ONE scan (`scan_rsrc`: a bounds-checked
 // buffer resource over the bytes this caller may read; beyond it a load returns zeros = dropped
-// samples and costs no memory traffic).  STEP = kVW: the fused kernel, whose waves interleave the
-// blocks of their scan; STEP = 1: k_voxel_runs, where a wave owns a chunk of consecutive blocks.
+// samples and costs no memory traffic): the waves of the workgroup interleave the blocks of their scan.
 // block k = the samples [128 k, 128 k + 128), i.e. one contiguous KiB; lane l owns the sample pair
 // 128 k + 2 l, + 1 (one buffer_load_dwordx4).  The raw pairs run kAhead blocks ahead in a ring of
 // four register buffers, unrolled four times so that the ring costs no register moves; the table
@@ -870,9 +768,8 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
 // at a stride of 8 entries — the texture addresser became the bottleneck; transposed through LDS
 // each block waits for two LDS round trips on top of the loads: profiles/r03/voxel_phaseS_r03.txt.)
 // ------------------------------------------------------------------------------
-template <bool FAST_DIV, bool SAFE, bool SPLIT, bool DBG, bool HASQ, bool HASMASK, bool XF, int STEP,
-          int AHEAD, class Sink>
-__device__ __forceinline__ void voxel_stream(Sink &sink, const KParams &p,
+template <bool FAST_DIV, bool SAFE, bool SPLIT, bool DBG, bool HASQ, bool HASMASK, bool XF, int AHEAD>
+__device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
                                              const float2 *__restrict__ cs,
                                              const __amdgpu_buffer_rsrc_t scan_rsrc, uint32_t blk0,
                                              uint32_t blk_end, const uint32_t *__restrict__ ror_bits,
@@ -893,45 +790,26 @@ __device__ __forceinline__ void voxel_stream(Sink &sink, const KParams &p,
   uint4 w[N];
   float2 cA[N], cB[N];
 #pragma unroll
-  for (int j = 0; j < AHEAD; ++j) w[j] = load_pair((blk0 + (uint32_t)(j * STEP)) * 1024u + lane_off);
-#ifdef RPL_VX_IDXEN  // (developer experiment: the table entry by buffer index — v_and instead of an SDWA shift per gather)
-  const unsigned long long cs_addr = (unsigned long long)(uintptr_t)cs;
-  const i4v cs_rsrc = {(int)(uint32_t)cs_addr, (int)((uint32_t)(cs_addr >> 32) | (8u << 16)), 65536, 0x00020000};
-  auto gat = [&](uint32_t word) -> float2 {
-    const f2 v = llvm_struct_load_f2(cs_rsrc, (int)(word & 0xFFFFu), 0, 0, 0);
-    return make_float2(v.x, v.y);
-  };
-#else
+  for (int j = 0; j < AHEAD; ++j) w[j] = load_pair((blk0 + (uint32_t)(j * kVW)) * 1024u + lane_off);
   auto gat = [&](uint32_t word) -> float2 { return cs[word & 0xFFFFu]; };
-#endif
 #pragma unroll
   for (int j = 0; j < GA; ++j) {
     cA[j] = gat(w[j].x);
     cB[j] = gat(w[j].z);
   }
   unsigned long long sub[5] = {0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0ull;
-  for (uint32_t blk4 = blk0; blk4 < blk_end; blk4 += (uint32_t)(N * STEP)) {
+  for (uint32_t blk4 = blk0; blk4 < blk_end; blk4 += (uint32_t)(N * kVW)) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-      const uint32_t blk = blk4 + (uint32_t)k * STEP;
+      const uint32_t blk = blk4 + (uint32_t)k * kVW;
       // (the loads are issued whether or not the block exists — beyond the resource they return
       // zeros — so that every path through the loop has the same loads in flight and the
       // compiler's waits stay exact)
       unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
       if (DBG) t0 = clock64();
-#ifndef RPL_ABL_NOGATHER
       cA[(k + GA) % N] = gat(w[(k + GA) % N].x);
       cB[(k + GA) % N] = gat(w[(k + GA) % N].z);
-#else  // (developer ablation: no table gathers)
-      cA[(k + GA) % N] = make_float2(__uint_as_float(0x3F000000u | (w[(k + GA) % N].x & 0xFFFFu)), 0.5f);
-      cB[(k + GA) % N] = make_float2(__uint_as_float(0x3F000000u | (w[(k + GA) % N].z & 0xFFFFu)), 0.5f);
-#endif
-#ifndef RPL_ABL_NORAW
-      w[(k + AHEAD) % N] = load_pair((blk + (uint32_t)AHEAD * STEP) * 1024u + lane_off);
-#else  // (developer ablation: no raw loads inside the loop)
-      w[(k + AHEAD) % N] = w[k];
-      asm volatile("" : "+v"(w[(k + AHEAD) % N].x), "+v"(w[(k + AHEAD) % N].y), "+v"(w[(k + AHEAD) % N].z), "+v"(w[(k + AHEAD) % N].w));
-#endif
+      w[(k + AHEAD) % N] = load_pair((blk + (uint32_t)AHEAD * kVW) * 1024u + lane_off);
       if (DBG) {  // [8] issue of the loads (incl. the wait for the raw pair the gathers need)
         asm volatile("" : "+v"(cA[(k + GA) % N].x), "+v"(cB[(k + GA) % N].x)::"memory");
         t1 = clock64();
@@ -951,11 +829,6 @@ __device__ __forceinline__ void voxel_stream(Sink &sink, const KParams &p,
         const uint32_t i0 = blk * 128u + lane_id() * 2u;  // sample index inside the scan
         bool ok[2];
         uint32_t key[2], qx[2], qy[2], ci[2];
-#ifdef RPL_VX_V2
-        if (!XF) {
-          voxel_pair<FAST_DIV, SAFE, HASQ>(lo, hi, c0, p, q_min16, ibfe_off, ibfe_w, ok, key, qx, qy, ci, flags);
-        } else
-#endif
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           ok[j] = voxel_sample<FAST_DIV, SAFE, HASQ, XF>(lo[j], hi[j], c0[j], p, q_min16, ibfe_off,
@@ -1005,8 +878,8 @@ __device__ __forceinline__ ScanSide scan_side(uint32_t sc, const uint32_t *__res
   return s;
 }
 // (one loop instance per uniform condition, so that none of them is tested per block)
-template <bool FAST_DIV, bool SAFE, bool SPLIT, bool DBG, int STEP, int AHEAD, class Sink>
-__device__ __forceinline__ void voxel_stream_dispatch(Sink &sink, const KParams &p,
+template <bool FAST_DIV, bool SAFE, bool SPLIT, bool DBG, int AHEAD>
+__device__ __forceinline__ void voxel_stream_dispatch(QueueSink &sink, const KParams &p,
                                                       const float2 *__restrict__ cs,
                                                       const __amdgpu_buffer_rsrc_t rsrc, uint32_t blk0,
                                                       uint32_t blk_end, const ScanSide &sd,
@@ -1015,7 +888,7 @@ __device__ __forceinline__ void voxel_stream_dispatch(Sink &sink, const KParams 
                                                       uint32_t ibfe_w, uint32_t &flags,
                                                       unsigned long long *dbg_slot) {
 #define RPL_VS(HQ, HM, XFB)                                                                         \
-  voxel_stream<FAST_DIV, SAFE, SPLIT, DBG, HQ, HM, XFB, STEP, AHEAD>(sink, p, cs, rsrc, blk0, blk_end, \
+  voxel_stream<FAST_DIV, SAFE, SPLIT, DBG, HQ, HM, XFB, AHEAD>(sink, p, cs, rsrc, blk0, blk_end, \
                                                                      sd.ror_bits, mask_stride, sd.xf, \
                                                                      q_min16, ibfe_off, ibfe_w, flags, \
                                                                      dbg_slot)
@@ -1112,7 +985,6 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
           L.misc[11] = 0u;
         }
         __syncthreads();
-#ifndef RPL_VOXEL_NO_HIST_BANDS
         // Round 5: the bands come from a HISTOGRAM of the records' rows instead of from bisecting the
         // key range (every bisection step that still held too many records cost a selection pass
         // over the whole store, and left bands half full: uniform random samples — one record per
@@ -1217,7 +1089,6 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
             }
           }
         }
-#endif
       }
     } else {
       // ---- a band of a scan that lives in the record store: select its records ----------
@@ -1473,275 +1344,12 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(kVB * kVWG 
           __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
       const ScanSide sd = scan_side(sc, keepmask, mask_stride, motion, pose2d, T.scan_t0);
       const uint32_t blk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
-#ifdef RPL_VOXEL_PRIO_STAGGER  // (developer experiment: the waves of a SIMD at different priorities)
-      {
-        const uint32_t pr = (blk0 >> 2) & 3u;
-        if (pr == 1u) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2u) __builtin_amdgcn_s_setprio(2);
-        else if (pr == 3u) __builtin_amdgcn_s_setprio(3);
-      }
-#endif
-#ifdef RPL_VOXEL_SLEEP_STAGGER  // (developer experiment: the waves of a SIMD start a fraction of a trip apart)
-      {
-        const uint32_t pr = (blk0 >> 2) & 3u;
-        if (pr == 1u) __builtin_amdgcn_s_sleep(RPL_VOXEL_SLEEP_STAGGER);
-        else if (pr == 2u) __builtin_amdgcn_s_sleep(2 * RPL_VOXEL_SLEEP_STAGGER);
-        else if (pr == 3u) __builtin_amdgcn_s_sleep(3 * RPL_VOXEL_SLEEP_STAGGER);
-      }
-#endif
-      voxel_stream_dispatch<FAST_DIV, SAFE, SPLIT, DBG, kVW, RPL_VOXEL_AHEAD>(
+      voxel_stream_dispatch<FAST_DIV, SAFE, SPLIT, DBG, RPL_VOXEL_AHEAD>(
           sink, p, cs, scan_rsrc, blk0, (n + 127u) >> 7, sd, mask_stride, use_xf, q_min16, ibfe_off,
           ibfe_w, flags, (DBG && p.dbg) ? p.dbg + 16 * b : nullptr);
-#ifdef RPL_VOXEL_PRIO_STAGGER
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
   };
   voxel_work_loop<DBG>(L, p, T, G, xyzi, out_stride, n_points, status, B, 0u, arena, phase_s);
-}
-
-// ------------------------------------------------------------------------------
-// The TWO-KERNEL path (batches, round 4).  The fused kernel needs a compute unit's whole LDS for
-// one scan, so a CU holds 16 waves, every wave has ONE KiB of raw samples in flight, and phase R
-// (LDS latency) runs with nothing streaming: 58 k cycles per scan, a third of the HBM roofline for
-// three rounds.  Here the two phases are two kernels:
-//   k_voxel_runs  — phase S alone.  No LDS, no barrier, no atomic: a WAVE owns a chunk of
-//     kChunkBlocks consecutive blocks (2048 samples) of one scan and appends its queue entries to
-//     its own REGION of the record store at a cursor in a scalar register; the entry count of the
-//     region (and the wave's status flags) go to rcount[].  256-thread workgroups, as many waves
-//     per SIMD as the registers allow: the loads of a wave hide behind the arithmetic of the others.
-//     Tasks are numbered chunk-major (chunk q of items 0 .. B-1, then chunk q + 1, ...): the waves in
-//     flight work on the same angular window of their scans, so the (cos, sin) entries they gather
-//     are shared through the vector L1 instead of being read from L2 once per scan.
-//   k_voxel_cells — phase R alone: a persistent workgroup gathers the regions of an item into its
-//     LDS queue (in region order, i.e. in sample order: every region starts with a block's marker
-//     entry, so "the entry before" stays the right subtrahend) and runs the same per-item loop as
-//     the fused kernel from there (bands, record store, arena modes: all unchanged).
-// Cost: the queue entries travel through L2 once (a clean scan: 52 KB written, 52 KB read, next to
-// 256 KB of samples).
-// ------------------------------------------------------------------------------
-constexpr uint32_t kChunkBlocks = 16u;
-constexpr uint32_t kChunkSamples = kChunkBlocks * 128u;
-// entries a chunk can make: one per sample + one marker per block (two when a block is split)
-constexpr uint32_t kRegionCap = kChunkSamples + 2u * kChunkBlocks;
-#ifndef RPL_RUNS_THREADS
-#define RPL_RUNS_THREADS 256
-#endif
-#ifndef RPL_RUNS_AHEAD
-#define RPL_RUNS_AHEAD 3
-#endif
-#ifndef RPL_RUNS_WAVES_PER_EU
-#define RPL_RUNS_WAVES_PER_EU 8
-#endif
-constexpr int kRunsThreads = RPL_RUNS_THREADS;
-constexpr int kRunsWaves = kRunsThreads / 64;
-
-// Pipelining of the two kernels (`pipe` != null): k_voxel_cells runs NEXT to k_voxel_runs on the
-// same compute units (it is launched on a second stream, takes a CU's LDS and half its wave
-// slots; this kernel takes the other half) and picks an item up as soon as all its regions are
-// written.  Then this kernel is a grid of persistent workgroups (4 per CU) whose waves stride
-// through the tasks — numbered so that the items complete in order, kPipeBurst at a time — and
-// every wave, when its region is complete (agent-scope stores: the consumer may sit behind
-// another L2), bumps pipe->ready[item].  The consumer never blocks this kernel, so
-// the pair cannot deadlock; if the device runs the kernels one after the other (a profiler that
-// serialises dispatches) the consumer simply finds every item ready.
-struct VoxelPipe {
-  uint32_t *task_ctr;   // next task of k_voxel_runs
-  uint32_t *item_ctr;   // next item of k_voxel_cells
-  uint32_t *ready;      // per item of the stage: regions written so far
-};
-constexpr uint32_t kPipeBurst = 256u;  // items whose chunks are streamed together (they complete together)
-
-template <bool FAST_DIV, bool SAFE, bool SPLIT>
-__global__ __launch_bounds__(kRunsThreads)
-__attribute__((amdgpu_waves_per_eu(RPL_RUNS_WAVES_PER_EU, RPL_RUNS_WAVES_PER_EU))) void k_voxel_runs(
-    const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
-    KParams p, const float2 *__restrict__ cs, const uint32_t *__restrict__ keepmask,
-    uint32_t mask_stride, uint4 *__restrict__ regions, uint2 *__restrict__ rcount, uint32_t item0,
-    uint32_t B, uint32_t group, uint32_t n_scans, uint32_t cps, uint32_t scan_major,
-    const float *__restrict__ motion, const float *__restrict__ pose2d, VoxelPipe pipe,
-    uint32_t pipe_want, const float *__restrict__ scan_t0) {
-  const uint32_t qn = group * cps;  // regions per item
-  const uint32_t total = B * qn;
-  const uint32_t ishift = p.is_new_protocol ? 0u : 2u;  // :591-592
-  const uint32_t ibfe_off = 16u + ishift, ibfe_w = 0xFFu >> ishift;
-  const uint32_t q_min16 = p.clip_enable ? (min(p.q_min, 256u) << 16) : 0u;
-  const bool use_xf = (group > 1u) || motion || pose2d;
-  // task t of this launch -> (item bl of the stage, scan g of its group, chunk c of that scan)
-  // (persistent waves take the tasks w, w + W, w + 2 W, ...: the tasks are of one size, and a shared
-  // task counter — 65 536 returning atomics on one address — alone took 0.8 ms)
-  uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * kRunsWaves + wave_id()));
-  const uint32_t t_step = gridDim.x * kRunsWaves;
-  if (pipe.task_ctr && pipe_want) {
-    // The consumer's workgroups need a CU's LDS and half its wave slots at once; if this kernel's
-    // small workgroups got there first they would take slot after slot as they come free and the
-    // consumer would only start when this kernel ends.  So it is launched first and this kernel
-    // gives its workgroups a moment (at most 30 us) to settle: pipe.task_ctr counts them.
-    const unsigned long long t_in = wall_clock64();
-    while (__hip_atomic_load(pipe.task_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pipe_want &&
-           wall_clock64() - t_in < 3000ull)
-      __builtin_amdgcn_s_sleep(16);
-  }
-  for (;; t += t_step) {
-    if (t >= total) return;
-    uint32_t q, bl;
-    if (pipe.task_ctr) {  // bursts of kPipeBurst items, chunk-major inside a burst
-      const uint32_t per = kPipeBurst * qn, u = t / per, v = t - u * per;
-      const uint32_t nb = min(kPipeBurst, B - u * kPipeBurst);  // items of this burst
-      q = v / nb;
-      bl = u * kPipeBurst + (v - q * nb);
-    } else if (scan_major) {
-      bl = t / qn;
-      q = t - bl * qn;
-    } else {
-      q = t / B;
-      bl = t - q * B;
-    }
-    const uint32_t g = q / cps, c = q - g * cps;
-    const uint32_t sc = (item0 + bl) * group + g;
-    const uint32_t r = bl * qn + q;  // this wave's region (stage-relative)
-    RegionSink sink{regions + (size_t)r * kRegionCap, 0u};
-    uint32_t flags = 0;
-    if (sc < n_scans) {
-      const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(
-          (int)min(n_per_scan[sc], min(n_stride, kMaxN)));  // never past the slot
-      const uint32_t blk0 = c * kChunkBlocks, blk_end = min((n + 127u) >> 7, blk0 + kChunkBlocks);
-      if (blk0 < blk_end) {
-        // the resource ends with the chunk (or the scan): the ring's loads beyond it return zeros
-        // and move no data
-        const uint32_t lim = min(n, blk_end * 128u) * 8u;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(nodes + (size_t)sc * n_stride), 0, (int)lim, 0x00020000);
-        const ScanSide sd = scan_side(sc, keepmask, mask_stride, motion, pose2d, scan_t0);
-        voxel_stream_dispatch<FAST_DIV, SAFE, SPLIT, false, 1, RPL_RUNS_AHEAD>(
-            sink, p, cs, rsrc, blk0, blk_end, sd, mask_stride, use_xf, q_min16, ibfe_off, ibfe_w,
-            flags, nullptr);
-      }
-    }
-    // status flags of the wave's samples (any lane), then the region's entry count
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) flags |= (uint32_t)__shfl_xor((int)flags, d, 64);
-    if (lane_id() == 0) {
-      const uint64_t cf = (uint64_t)sink.cur | ((uint64_t)flags << 32);
-      __hip_atomic_store(reinterpret_cast<uint64_t *>(rcount + r), cf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (p.dbg && lane_id() == 0) {  // developer aid: when the item's last region was complete
-      atomicMax(&p.dbg[16 * (item0 + bl) + 3], wall_clock64());
-    }
-    if (!pipe.task_ctr) return;
-    // every store of this wave (agent scope, see glb_store128_off; the entries by hand-written
-    // instructions the compiler does not track) has completed before the item's count is bumped
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane_id() == 0) __hip_atomic_fetch_add(&pipe.ready[bl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// (LDS is passed as dynamic shared memory: with the 133 KB visible at compile time the compiler
-// concludes that one workgroup per CU is all there can be and spends 128 registers per lane — which
-// leaves none for the waves of k_voxel_runs that are to run next to this kernel.)
-#ifndef RPL_CELLS_WAVES_PER_EU
-#define RPL_CELLS_WAVES_PER_EU 7  // 72 registers per lane: 4 waves of this + 4 of k_voxel_runs per SIMD
-#endif
-template <bool DBG>
-__global__ __launch_bounds__(kVB)
-__attribute__((amdgpu_waves_per_eu(RPL_CELLS_WAVES_PER_EU, RPL_CELLS_WAVES_PER_EU))) void k_voxel_cells(
-    KParams p, Tables T, const uint4 *__restrict__ regions, const uint2 *__restrict__ rcount,
-    float4 *__restrict__ xyzi, uint32_t out_stride, uint32_t *__restrict__ n_points,
-    uint32_t *__restrict__ status, uint32_t item0, uint32_t B, uint32_t qn, VoxelArena arena,
-    uint4 *__restrict__ store, VoxelPipe pipe) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char voxel_dyn_lds[];
-  VoxelLds &L = *reinterpret_cast<VoxelLds *>(voxel_dyn_lds);
-  if (pipe.item_ctr) T.work_ctr = pipe.item_ctr;
-#ifndef RPL_CELLS_PRIO
-#define RPL_CELLS_PRIO 3
-#endif
-  // This kernel is a chain of dependent LDS round trips and barriers; next to the producer's waves,
-  // which always have a vector instruction ready, its waves would wait their turn at every step
-  // (measured: 3 x slower).  They issue little, so they go first.
-  if (pipe.item_ctr) __builtin_amdgcn_s_setprio(RPL_CELLS_PRIO);
-  if (pipe.task_ctr && threadIdx.x == 0)  // (the producer waits a moment for this, see k_voxel_runs)
-    __hip_atomic_fetch_add(pipe.task_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint4 *G = store + (size_t)blockIdx.x * 2u * T.voxel_store_recs;  // records, then the cell area
-  // the item's regions -> the queue, in region order.  Wave w takes the regions
-  // [w * per, (w + 1) * per): it needs the entries in front of its first region (a block scan over
-  // the waves' totals) and then walks its regions with a running position.
-  auto gather = [&](uint32_t, uint32_t bl, uint32_t &flags) {
-    if (pipe.ready) {  // pipelined: the producer may still be writing this item's regions
-      if (threadIdx.x == 0) {
-        if (p.dbg) p.dbg[16 * (item0 + bl) + 0] = wall_clock64();  // developer aid: began to wait
-        // (bounded: the producer never waits for this kernel, so the item does come — unless the
-        // producer's launch failed; then the item is flagged instead of spinning for ever)
-        const unsigned long long t_in = wall_clock64();
-        bool late = false;
-        while (__hip_atomic_load(&pipe.ready[bl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < qn) {
-          __builtin_amdgcn_s_sleep(32);
-          if (wall_clock64() - t_in > 200000000ull) { late = true; break; }  // 2 s
-        }
-        // (late: the regions may be unfinished, or hold an earlier stage's entries — nothing of them
-        // is used: the item comes out EMPTY and says why, instead of a plausible wrong cloud)
-        if (late) atomicOr(&L.misc[1], (uint32_t)RPLGPU_SCAN_NOT_PRODUCED);
-        L.tmp[30] = late ? 1u : 0u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (p.dbg) p.dbg[16 * (item0 + bl) + 1] = wall_clock64();  // ... saw the item ready
-      }
-      __syncthreads();
-      if (L.tmp[30]) {  // block-uniform
-        __syncthreads();
-        if (threadIdx.x == 0) L.misc[0] = 0u;  // an empty queue: no records, no cells
-        return;
-      }
-    }
-    const uint2 *rc = rcount + (size_t)bl * qn;
-    const uint4 *RG = regions + (size_t)bl * qn * kRegionCap;
-    const uint32_t per = (qn + kVW - 1u) / kVW;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
-    const uint32_t r0 = min(qn, w * per), r1 = min(qn, r0 + per);
-    uint32_t mine = 0u;
-    for (uint32_t r = r0 + lane_id(); r < r1; r += 64u) {
-      const uint2 v = rc[r];
-      mine += min(v.x, kRegionCap);
-      flags |= v.y;
-    }
-    const uint32_t inc = wave_incl_scan_fast(mine);
-    if (lane_id() == 63) L.tmp[wave_id()] = inc;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const uint32_t v = (threadIdx.x < kVW) ? L.tmp[threadIdx.x] : 0u;
-      const uint32_t ws = wave_incl_scan_fast(v);
-      if (threadIdx.x < kVW) L.tmp[threadIdx.x] = ws - v;  // entries in front of the wave's regions
-      if (threadIdx.x == kVW - 1) L.misc[0] = ws;          // the item's queue length
-    }
-    __syncthreads();
-    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tmp[w]);
-    for (uint32_t rb = r0; rb < r1; rb += 64u) {
-      const uint32_t cnt_l = (rb + lane_id() < r1) ? rc[rb + lane_id()].x : 0u;
-      const uint32_t nj = min(64u, r1 - rb);
-      for (uint32_t j = 0; j < nj; ++j) {
-        // (never more than a region holds, whatever the count word says: a producer that did not
-        // run leaves the words of an earlier call, or of no call at all)
-        const uint32_t cnt = min((uint32_t)__builtin_amdgcn_readlane((int)cnt_l, (int)j), kRegionCap);
-        const uint4 *src = RG + (size_t)(rb + j) * kRegionCap;
-        for (uint32_t i0 = 0; i0 < cnt; i0 += 256u) {  // four loads in flight per lane
-          uint4 e[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t i = i0 + 64u * k + lane_id();
-            if (i < cnt) e[k] = src[i];
-          }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint32_t i = i0 + 64u * k + lane_id();
-            if (i < cnt) {
-              const uint32_t d = pos + i;
-              if (d < kRecCap) L.rec[d] = e[k]; else G[d] = e[k];
-            }
-          }
-        }
-        pos += cnt;
-      }
-    }
-  };
-  voxel_work_loop<DBG>(L, p, T, G, xyzi, out_stride, n_points, status, B, item0, arena, gather);
 }
 
 // ------------------------------------------------------------------------------
@@ -1780,35 +1388,6 @@ hipError_t launch_validate_div(hipStream_t s, float d, float rd, uint32_t e_lo, 
 
 uint32_t voxel_max_workgroups(uint32_t n_cu) { return (uint32_t)kVWG * (n_cu ? n_cu : 256u); }
 
-uint32_t voxel_regions_per_item(uint32_t group, uint32_t n_stride) {
-  const uint32_t s = n_stride < kMaxN ? n_stride : kMaxN;
-  return (group ? group : 1u) * ((s + kChunkSamples - 1u) / kChunkSamples);
-}
-uint64_t voxel_region_bytes() { return (uint64_t)kRegionCap * 16u; }
-
-// The two-kernel path for the items [0, B) (work items of `group` scans): stages of as many items
-// as the region store holds; k_voxel_runs then k_voxel_cells per stage, on the same stream.
-template <bool FD, bool SF, bool SP>
-static hipError_t launch_runs(hipStream_t s, const void *nodes, uint32_t n_stride,
-                              const uint32_t *n_per_scan, const KParams &p, const Tables &T,
-                              const uint32_t *keepmask, uint32_t mask_stride, uint32_t item0,
-                              uint32_t Bs, uint32_t group, uint32_t n_scans, uint32_t cps,
-                              const float *motion, const float *pose2d, uint32_t pipe_want) {
-  const uint32_t tasks = Bs * group * cps;
-  const uint32_t grid = (tasks + (uint32_t)kRunsWaves - 1u) / (uint32_t)kRunsWaves;
-  VoxelPipe pipe{nullptr, nullptr, nullptr};
-  uint32_t g = grid;
-  if (T.voxel_pipe) {  // persistent waves, voxel_pipe workgroups of 4 waves per CU
-    pipe = VoxelPipe{T.voxel_pipe_ctr, T.voxel_pipe_ctr + 1, T.voxel_pipe_ctr + 2};
-    g = std::min<uint32_t>(grid, (T.n_cu ? T.n_cu : 256u) * (uint32_t)T.voxel_pipe);  // voxel_pipe workgroups per CU
-  }
-  hipLaunchKernelGGL((k_voxel_runs<FD, SF, SP>), dim3(g), dim3(kRunsThreads), 0, s,
-                     (const uint2 *)nodes, n_stride, n_per_scan, p, p.inverted ? T.cs_inv : T.cs,
-                     keepmask, mask_stride, (uint4 *)T.voxel_regions, (uint2 *)T.voxel_rcount, item0,
-                     Bs, group, n_scans, cps, (uint32_t)(T.voxel_scan_major ? 1u : 0u), motion, pose2d,
-                     pipe, pipe_want, T.scan_t0);
-  return hipGetLastError();
-}
 
 hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_stride,
                               const uint32_t *n_per_scan, uint32_t B, const KParams &p,
@@ -1832,24 +1411,11 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   ar.capacity = arena_capacity;
   ar.scan_start = scan_start;
   ar.xyi = (arena && arena_xyi) ? 1 : 0;
-  // Which path: the two-kernel path when the handle owns a region store that holds a stage worth
-  // the name (enough waves to fill the device), the fused kernel otherwise (single scans, small
-  // batches, the instrumented build).
-  const uint32_t qn = voxel_regions_per_item(group, n_stride);
-  const uint32_t cps = qn / group;
-  uint32_t stage = 0;
-  if (T.voxel_regions && T.voxel_rcount && T.voxel_two_kernel && (!p.dbg || T.voxel_two_kernel == 2) && qn) {
-    stage = std::min<uint32_t>(B, T.voxel_region_cap / qn);
-    if (T.voxel_stage_items) stage = std::min<uint32_t>(stage, T.voxel_stage_items);
-    if (T.voxel_pipe) stage = std::min<uint32_t>(stage, T.voxel_pipe_items);
-    if (T.voxel_two_kernel < 2 && (uint64_t)stage * qn < 4096u) stage = 0;  // too few waves per stage
-  }
-  if (kVWG == 2 && group > 1 && !stage) return hipErrorInvalidValue;  // (fused groups: 16-wave geometry only)
+  if (kVWG == 2 && group > 1) return hipErrorInvalidValue;  // (fused groups: 16-wave geometry only)
   // persistent workgroups of the handle's device (no more than the handle owns record stores
   // for); the item queue is cleared by a memset ahead of every launch (an aborted launch can
   // therefore not poison the next one)
-  const uint32_t B_launch = stage ? stage : B;
-  uint32_t grid = std::min<uint32_t>(std::min<uint32_t>(B_launch, voxel_max_workgroups(T.n_cu)),
+  uint32_t grid = std::min<uint32_t>(std::min<uint32_t>(B, voxel_max_workgroups(T.n_cu)),
                                      T.voxel_store_wgs);
   if (const char *e = std::getenv("RPLGPU_VOXEL_GRID")) {  // developer aid
     const long g = std::atol(e);
@@ -1861,61 +1427,6 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   if (!with_stats) Tk.voxel_stats = nullptr;
   if (with_stats)
     if (hipError_t e = hipMemsetAsync(T.voxel_stats, 0, 16, s); e != hipSuccess) return e;
-  if (stage) {
-    for (uint32_t i0 = 0; i0 < B; i0 += stage) {
-      const uint32_t Bs = std::min<uint32_t>(stage, B - i0);
-      hipError_t e;
-      if (T.voxel_pipe) {  // task counter, item counter, per-item ready counts; then fork
-        if ((e = hipMemsetAsync(T.voxel_pipe_ctr, 0, (2u + (size_t)Bs) * 4u, s)) != hipSuccess) return e;
-        if ((e = hipEventRecord((hipEvent_t)T.voxel_pipe_ev[0], s)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent((hipStream_t)T.voxel_pipe_stream, (hipEvent_t)T.voxel_pipe_ev[0], 0)) != hipSuccess) return e;
-      }
-#define RPL_RUNS(FD, SF, SP) \
-  e = launch_runs<FD, SF, SP>(s, nodes, n_stride, n_per_scan, p, T, keepmask, mask_stride, i0, Bs, group, n_scans, cps, motion, pose2d, pipe_want)
-      auto launch_cells = [&]() -> hipError_t {
-        const uint32_t g = std::min<uint32_t>(grid, Bs);
-        // (> 64 KB of dynamic LDS needs the attribute; it is per device, the call is cheap)
-        if (hipError_t e2 = hipFuncSetAttribute((const void *)&k_voxel_cells<false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)sizeof(VoxelLds));
-            e2 != hipSuccess)
-          return e2;
-        VoxelPipe pipe{nullptr, nullptr, nullptr};
-        hipStream_t sr = s;
-        if (T.voxel_pipe) {  // the consumer runs next to the producer, on the handle's second stream
-          pipe = VoxelPipe{T.voxel_pipe_ctr, T.voxel_pipe_ctr + 1, T.voxel_pipe_ctr + 2};
-          sr = (hipStream_t)T.voxel_pipe_stream;
-        } else if (g < Bs) {
-          if (hipError_t e2 = hipMemsetAsync(T.work_ctr, 0, 4, s); e2 != hipSuccess) return e2;
-        }
-        hipLaunchKernelGGL((k_voxel_cells<false>), dim3(g), dim3(kVB), sizeof(VoxelLds), sr, p, Tk,
-                           (const uint4 *)T.voxel_regions, (const uint2 *)T.voxel_rcount, (float4 *)xyzi,
-                           out_stride, n_points, status, i0, Bs, qn, ar, (uint4 *)T.voxel_store, pipe);
-        if (hipError_t e2 = hipGetLastError(); e2 != hipSuccess) return e2;
-        if (T.voxel_pipe)  // the caller's stream goes on when the consumer is done
-          if (hipError_t e2 = hipEventRecord((hipEvent_t)T.voxel_pipe_ev[1], sr); e2 != hipSuccess) return e2;
-        return hipSuccess;
-      };
-      if (T.voxel_pipe)  // (first: see k_voxel_runs)
-        if ((e = launch_cells()) != hipSuccess) return e;
-      const uint32_t pipe_want = T.voxel_pipe ? std::min<uint32_t>(std::min<uint32_t>(grid, Bs), T.n_cu ? T.n_cu : 256u) : 0u;
-      const bool sf = p.cell_range_safe != 0, sp = T.voxel_split != 0;
-      if (p.fast_div) {
-        if (sf) { if (sp) RPL_RUNS(true, true, true); else RPL_RUNS(true, true, false); }
-        else { if (sp) RPL_RUNS(true, false, true); else RPL_RUNS(true, false, false); }
-      } else {
-        if (sf) { if (sp) RPL_RUNS(false, true, true); else RPL_RUNS(false, true, false); }
-        else { if (sp) RPL_RUNS(false, false, true); else RPL_RUNS(false, false, false); }
-      }
-#undef RPL_RUNS
-      if (e != hipSuccess) return e;
-      if (!T.voxel_pipe) {
-        if ((e = launch_cells()) != hipSuccess) return e;
-      } else if ((e = hipStreamWaitEvent(s, (hipEvent_t)T.voxel_pipe_ev[1], 0)) != hipSuccess) {
-        return e;
-      }
-    }
-  } else {
   // (a launch with a workgroup per item does not touch the queue: one command less in front of a
   // single-scan call)
   if (grid < B)
@@ -1929,11 +1440,6 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
     if (p.cell_range_safe) RPL_LAUNCH_VOXEL(FD, true, DB, SP); else RPL_LAUNCH_VOXEL(FD, false, DB, SP); \
   } while (0)
   if (p.dbg) {  // developer aid: the instrumented build of the kernel (plain instance only)
-#ifdef RPL_VOXEL_DBG_SPLIT  // (developer build: the instrumented two-class instance as well)
-    if (T.voxel_split) {
-      RPL_LAUNCH_VOXEL_SF(true, true, true);
-    } else
-#endif
     if (p.fast_div) RPL_LAUNCH_VOXEL_SF(true, true, false); else RPL_LAUNCH_VOXEL_SF(false, true, false);
   } else if (T.voxel_split) {  // the handle's previous launch saw a noisy batch
     if (p.fast_div) RPL_LAUNCH_VOXEL_SF(true, false, true); else RPL_LAUNCH_VOXEL_SF(false, false, true);
@@ -1942,7 +1448,6 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   }
 #undef RPL_LAUNCH_VOXEL_SF
 #undef RPL_LAUNCH_VOXEL
-  }
   if (with_stats) {  // the statistics follow the launch to pinned memory (no wait)
     if (hipError_t e = hipMemcpyAsync(T.voxel_stats_host, T.voxel_stats, 16, hipMemcpyDeviceToHost, s);
         e != hipSuccess)

@@ -74,22 +74,8 @@ struct rplgpu_ctx {
   VoxelBatchId stats_id;
   uint32_t n_cu = 0;                  // compute units of `device`
   void *d_vstore = nullptr;           // k_cloud_voxel record stores (one per resident workgroup)
-  // the two-kernel voxel path's region store (k_voxel_runs -> k_voxel_cells), allocated by the
-  // first batch call large enough to use it, kept
-  void *d_regions = nullptr;
-  void *d_rcount = nullptr;
-  uint32_t region_cap = 0;            // regions it holds
-  int32_t two_kernel = 0;             // RPLGPU_VOXEL_PATH: fused = 0 (default: it is the faster path, profiles/r04/), auto = 1, two = 2
-  uint32_t stage_items = 0;           // RPLGPU_VOXEL_STAGE: items per stage at most (0 = default)
-  uint64_t region_budget = 2560ull << 20;  // RPLGPU_REGION_MB: bytes the region store may take
-  int32_t scan_major = 0;             // RPLGPU_RUNS_SCAN_MAJOR (developer aid)
   int32_t force_split = -1;           // RPLGPU_VOXEL_SPLIT: -1 follow the statistics, 0 / 1 forced
   bool dec_stage = true;              // RPLGPU_DEC_STAGE=0: the plain decoder only (tests / A-B runs)
-  int32_t pipe = 0;                   // RPLGPU_VOXEL_PIPE: n > 0: k_voxel_cells next to k_voxel_runs (n producer workgroups per CU); 0: one after the other
-  uint32_t *d_pipe_ctr = nullptr;     // task / item counters + per-item ready counts (2 + stage items words)
-  uint32_t pipe_items = 0;
-  hipStream_t vstream = nullptr;      // the consumer's stream
-  hipEvent_t ev_v[2] = {nullptr, nullptr};
   uint32_t vstore_wgs = 0;
   uint32_t vstore_recs = 0;           // records per workgroup (grows with the largest E8 group seen)
   unsigned char *d_dec = nullptr;     // rplgpu_decode_stream staging (grown on demand, kept)
@@ -251,19 +237,7 @@ rpl::Tables tables_of(rplgpu_ctx *c) {
   t.voxel_stats = reinterpret_cast<unsigned long long *>(c->d_small + 24);  // [24..27]
   t.voxel_stats_host = c->h_vstats;
   t.voxel_split = c->force_split > 0 ? 1 : 0;  // (batch launches: voxel_split_for)
-  t.voxel_regions = c->d_regions;
-  t.voxel_rcount = c->d_rcount;
-  t.voxel_region_cap = c->region_cap;
-  t.voxel_two_kernel = c->two_kernel;
-  t.voxel_stage_items = c->stage_items;
-  t.voxel_scan_major = c->scan_major;
-  t.voxel_pipe = (c->pipe && c->d_pipe_ctr && c->vstream) ? c->pipe : 0;
-  t.voxel_pipe_ctr = c->d_pipe_ctr;
-  t.voxel_pipe_items = c->pipe_items;
-  t.voxel_pipe_stream = c->vstream;
   t.scan_t0 = c->scan_t0;
-  t.voxel_pipe_ev[0] = c->ev_v[0];
-  t.voxel_pipe_ev[1] = c->ev_v[1];
   return t;
 }
 
@@ -330,11 +304,6 @@ void free_ctx(rplgpu_ctx *c) {
   if (c->d_scans) (void)hipFree(c->d_scans);
   if (c->d_dec_todo) (void)hipFree(c->d_dec_todo);
   if (c->d_vstore) (void)hipFree(c->d_vstore);
-  if (c->d_regions) (void)hipFree(c->d_regions);
-  if (c->d_rcount) (void)hipFree(c->d_rcount);
-  if (c->d_pipe_ctr) (void)hipFree(c->d_pipe_ctr);
-  if (c->vstream) { (void)hipStreamSynchronize(c->vstream); (void)hipStreamDestroy(c->vstream); }
-  for (auto &e : c->ev_v) if (e) (void)hipEventDestroy(e);
   if (c->h_vstats) (void)hipHostFree(c->h_vstats);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -633,15 +602,6 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   if (const char *e = std::getenv("RPLGPU_ZERO_COPY")) c->zero_copy = std::atoi(e) != 0;
   if (!c->d_pin) c->zero_copy = false;
   if (const char *e = std::getenv("RPLGPU_SPIN_SYNC")) c->spin_sync = std::atoi(e) != 0;
-  // voxel path selection (read once, here): which kernels a batch uses, see ensure_regions
-  if (const char *e = std::getenv("RPLGPU_VOXEL_PATH")) {
-    const std::string v(e);
-    c->two_kernel = v == "two" ? 2 : v == "auto" ? 1 : 0;
-  }
-  if (const char *e = std::getenv("RPLGPU_VOXEL_STAGE")) c->stage_items = (uint32_t)std::max(0, std::atoi(e));
-  if (const char *e = std::getenv("RPLGPU_REGION_MB")) c->region_budget = (uint64_t)std::max(1, std::atoi(e)) << 20;
-  if (const char *e = std::getenv("RPLGPU_RUNS_SCAN_MAJOR")) c->scan_major = std::atoi(e) != 0;
-  if (const char *e = std::getenv("RPLGPU_VOXEL_PIPE")) c->pipe = std::max(0, std::atoi(e));
   if (const char *e = std::getenv("RPLGPU_DEC_STAGE")) c->dec_stage = std::atoi(e) != 0;
   if (const char *e = std::getenv("RPLGPU_VOXEL_SPLIT")) c->force_split = std::atoi(e) != 0;  // developer aid
   std::memset(c->h_pin + c->flag_off, 0, kTail);
@@ -770,58 +730,6 @@ int32_t rplgpu_ascend_laserscan_batch_dev(rplgpu_handle_t h, rplgpu_node_t *d_no
   return RPLGPU_OK;
 }
 
-// The two-kernel voxel path (rpl_voxel.hip) needs a region store: one region per 2048-sample chunk
-// of every scan of a STAGE of work items.  It is allocated (grown) here, by the first batch call
-// whose stages would fill the device, within the handle's byte budget; smaller batches and
-// single scans keep the fused kernel and never allocate it.
-static int32_t ensure_regions(rplgpu_handle_t h, uint32_t B, uint32_t group, uint32_t n_stride) {
-  if (h->two_kernel == 0 || B == 0) return RPLGPU_OK;
-  group = std::max(1u, std::min(group, B));
-  const uint32_t items = (B + group - 1u) / group;
-  const uint64_t qn = rpl::voxel_regions_per_item(group, n_stride);
-  if (qn == 0) return RPLGPU_OK;
-  uint64_t stage = std::min<uint64_t>(items, h->stage_items ? h->stage_items : 4096u);
-  stage = std::min<uint64_t>(stage, h->region_budget / (qn * rpl::voxel_region_bytes()));
-  if (h->two_kernel == 2) stage = std::max<uint64_t>(stage, 1u);
-  else if (stage * qn < 4096u) return RPLGPU_OK;  // (the launcher takes the fused kernel)
-  if (h->pipe) {  // the second stream and the counters of the pipelined form
-    if (!h->vstream) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      if (hipStreamCreateWithPriority(&h->vstream, hipStreamNonBlocking, hi) != hipSuccess ||
-          hipEventCreateWithFlags(&h->ev_v[0], hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&h->ev_v[1], hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        h->pipe = 0;  // (no second stream: the kernels run one after the other)
-      }
-    }
-    if (h->pipe && stage > h->pipe_items) {
-      RPL_HIP(h, hipStreamSynchronize(h->stream));
-      if (h->d_pipe_ctr) (void)hipFree(h->d_pipe_ctr);
-      h->d_pipe_ctr = nullptr;
-      h->pipe_items = 0;
-      if (hipMalloc((void **)&h->d_pipe_ctr, (2u + stage) * 4u) == hipSuccess) h->pipe_items = (uint32_t)stage;
-      else (void)hipGetLastError();
-    }
-  }
-  const uint64_t need = stage * qn;
-  if (need <= h->region_cap) return RPLGPU_OK;
-  RPL_HIP(h, hipStreamSynchronize(h->stream));
-  if (h->d_regions) (void)hipFree(h->d_regions);
-  if (h->d_rcount) (void)hipFree(h->d_rcount);
-  h->d_regions = h->d_rcount = nullptr;
-  h->region_cap = 0;
-  if (hipMalloc(&h->d_regions, need * rpl::voxel_region_bytes()) != hipSuccess ||
-      hipMalloc(&h->d_rcount, need * 8u) != hipSuccess) {
-    (void)hipGetLastError();
-    if (h->d_regions) (void)hipFree(h->d_regions);
-    h->d_regions = nullptr;  // (no region store: the fused kernel serves the call)
-    return RPLGPU_OK;
-  }
-  h->region_cap = (uint32_t)need;
-  return RPLGPU_OK;
-}
-
 // parameter checks, divisor validation and the E5 mask shared by the cloud entry points
 static int32_t prepare_cloud(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
                              const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
@@ -873,7 +781,6 @@ static int32_t cloud_arena_impl(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
   rpl::KParams kp;
   const uint32_t *mask = nullptr;
   if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
-  if ((rc = ensure_regions(h, B, 1u, n_stride))) return rc;
   RPL_HIP(h, hipMemsetAsync(d_cursor, 0, 8, h->stream));
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "64-bit cursor");
   rpl::Tables T_arena = tables_of(h);
@@ -950,7 +857,6 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
   rpl::KParams kp;
   const uint32_t *mask = nullptr;
   if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
-  if ((rc = ensure_regions(h, B, group, n_stride))) return rc;
   RPL_HIP(h, hipMemsetAsync(d_cursor, 0, 8, h->stream));
   rpl::Tables T_fused = tables_of(h);
   T_fused.voxel_split = voxel_split_for(h, d_nodes, n_stride, B, group) ? 1 : 0;
@@ -973,7 +879,6 @@ int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, 
   rpl::KParams kp;
   const uint32_t *mask = nullptr;
   if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
-  if (p->voxel_enable && (rc = ensure_regions(h, B, 1u, n_stride))) return rc;
   rpl::Tables T_batch = tables_of(h);
   if (p->voxel_enable) T_batch.voxel_split = voxel_split_for(h, d_nodes, n_stride, B, 1u) ? 1 : 0;
   RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, T_batch,

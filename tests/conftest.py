@@ -78,16 +78,14 @@ def gpu():
     h.close()
 
 
-# The voxel path has alternative forms that must give the same clouds: the two-class block
-# aggregation (RPLGPU_VOXEL_AGG_TWO_CLASS, normally picked from the previous launch's statistics)
-# and the two-kernel path (k_voxel_runs + k_voxel_cells, sequential or pipelined; a developer
-# option since round 4, selected by environment variables the library reads in rplgpu_create).
-# `gpu_mode` runs a test once per form, each on its own handle.
+# The voxel path has two block-aggregation forms that must give the same clouds: plain and
+# two-class (RPLGPU_VOXEL_AGG_TWO_CLASS, normally picked from the batch's own statistics).
+# `gpu_mode` runs a test once per form, each on its own handle.  (Rounds 4-5 also ran the two-kernel
+# and pipelined forms here; they measured 1.36 x slower and left the library in round 6 —
+# tools/dev/patches/voxel_lab_r05.diff has them.)
 _MODES = {
     "default": ({}, 0),
     "two_class": ({}, 2),
-    "two_kernel": ({"RPLGPU_VOXEL_PATH": "two"}, 0),
-    "two_kernel_pipe": ({"RPLGPU_VOXEL_PATH": "two", "RPLGPU_VOXEL_PIPE": "3"}, 0),
 }
 
 

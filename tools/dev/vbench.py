@@ -1,5 +1,5 @@
 """Developer aid: time rplgpu_cloud_arena_dev on a C3-shaped batch under the current environment
-(RPLGPU_VOXEL_PATH / RPLGPU_VOXEL_STAGE / RPLGPU_LIBRARY ...).  One line per call:
+(RPLGPU_LIBRARY, VB_* ...).  One line per call:
   python tools/dev/vbench.py [B=4096] [reps=30] [noise_m=0] [kind=ring]"""
 import os
 import sys
@@ -60,7 +60,6 @@ for _ in range(3):
     tot += ms
 cells = int(d_cur.item())
 algo = 8 * B * n + 16 * cells
-print(f"path={os.environ.get('RPLGPU_VOXEL_PATH', 'auto')} stage={os.environ.get('RPLGPU_VOXEL_STAGE', '-')} "
-      f"lib={Path(os.environ.get('RPLGPU_LIBRARY', 'default')).name} B={B} noise={noise} kind={kind} "
+print(f"lib={Path(os.environ.get('RPLGPU_LIBRARY', 'default')).name} B={B} noise={noise} kind={kind} "
       f"ms_best={best:.4f} ms_avg={tot / 3:.4f} cells={cells} status={int(d_st.max().item())} "
       f"frac={algo / (best * 1e-3) / 8e12:.3f}")
