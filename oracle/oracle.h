@@ -131,6 +131,16 @@ uint64_t orc_batch_cloud_check(const orc_node_t *nodes, size_t n_stride,
                                const uint32_t *got_npts, const uint32_t *got_keys, int threads,
                                uint32_t *res);
 
+/* whole-batch checks of device-made ascended scans / LaserScan arrays against orc_ascend /
+ * orc_publish_scan on all host threads (see oracle.cpp for what res[] holds) */
+uint64_t orc_batch_ascend_check(const orc_node_t *src, const orc_node_t *got, size_t n_stride,
+                                const uint32_t *n_per_scan, size_t B, int threads, uint32_t *res);
+uint64_t orc_batch_laserscan_check(const orc_node_t *nodes, size_t n_stride,
+                                   const uint32_t *n_per_scan, size_t B, const orc_params_t *p,
+                                   const float *got_ranges, const float *got_intens,
+                                   const uint32_t *got_count, size_t out_stride, int threads,
+                                   uint32_t *res);
+
 
 /* =====================================================================================
  * SURVEY.md §8(f) rows 1-2 — the step before the hot path: sample-data unpackers

@@ -197,12 +197,14 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
                                                    const uint32_t *__restrict__ n_per_scan,
                                                    uint32_t *__restrict__ status,
                                                    uint32_t *__restrict__ need_sort, uint32_t mark,
-                                                   uint32_t prefilled) {
+                                                   uint32_t prefilled, uint32_t *__restrict__ sort_stat) {
   __shared__ uint32_t s_keys[kMaxN];
   __shared__ uint32_t s_misc[8];
   __shared__ SortLds s_sort;
   if (SORT) {
     const uint32_t count = need_sort[0];
+    // (developer aid: how many scans of this call took the sort — rplgpu_debug_ascend_sorted)
+    if (sort_stat && blockIdx.x == 0 && threadIdx.x == 0) *sort_stat = count;
     // A grid of ONE workgroup (the single-scan call) leaves the list empty for the next call
     // itself, so that such a call needs no clearing command in front of it.
     if (gridDim.x == 1u) {
@@ -889,7 +891,8 @@ __global__ __launch_bounds__(256) void k_pack(const float4 *__restrict__ xyzi, u
 static bool ascend_streams(uint32_t B, uint32_t n_stride) { return !(B <= 8u && n_stride > 8192u); }
 
 hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
-                         uint32_t B, uint32_t *status, uint32_t *need_sort, bool defer_sort) {
+                         uint32_t B, uint32_t *status, uint32_t *need_sort, bool defer_sort,
+                         uint32_t *sort_stat) {
   if (B == 0) return hipSuccess;
   // (the list of unsorted scans starts empty: cleared when the handle is created and, after a
   // single-scan call, by the sorting kernel itself; batches clear it here)
@@ -906,23 +909,23 @@ hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const ui
   // samples the streaming kernel is the faster one, 18 vs 24 us); batches stream.
   if (!ascend_streams(B, n_stride))
     hipLaunchKernelGGL(k_ascend<false>, dim3(B), dim3(kBlock), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
-                       status, need_sort, mark, 0u);
+                       status, need_sort, mark, 0u, (uint32_t *)nullptr);
   else
     hipLaunchKernelGGL(k_ascend_stream, dim3(B), dim3(kAscT), 0, s, (uint2 *)nodes, n_stride, n_per_scan,
                        status, need_sort, mark);
   if (mark) return hipGetLastError();
-  return launch_ascend_sort(s, nodes, n_stride, n_per_scan, B, status, need_sort);
+  return launch_ascend_sort(s, nodes, n_stride, n_per_scan, B, status, need_sort, sort_stat);
 }
 
 // the sorting kernel over the list the kernels above left (second half of launch_ascend)
 hipError_t launch_ascend_sort(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
-                              uint32_t B, uint32_t *status, uint32_t *need_sort) {
+                              uint32_t B, uint32_t *status, uint32_t *need_sort, uint32_t *sort_stat) {
   if (B == 0) return hipSuccess;
   // (scans queued by the streaming kernel have their filled angle words in place and may have been
   // permuted by its local repair: the sort then trusts the stored words)
   const uint32_t prefilled = ascend_streams(B, n_stride) ? 1u : 0u;
   hipLaunchKernelGGL(k_ascend<true>, dim3(std::min<uint32_t>(B, 256u)), dim3(kBlock), 0, s,
-                     (uint2 *)nodes, n_stride, n_per_scan, status, need_sort, 0u, prefilled);
+                     (uint2 *)nodes, n_stride, n_per_scan, status, need_sort, 0u, prefilled, sort_stat);
   if (B != 1u)  // (invariant between calls: the list is empty)
     if (hipError_t e = hipMemsetAsync(need_sort, 0, 4, s); e != hipSuccess) return e;
   return hipGetLastError();

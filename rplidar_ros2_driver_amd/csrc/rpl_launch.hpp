@@ -20,9 +20,11 @@ namespace rpl {
 // sorting kernel rewrites the status word without it)
 constexpr uint32_t kAscendUnsorted = 0x80000000u;
 hipError_t launch_ascend(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
-                         uint32_t B, uint32_t *status, uint32_t *need_sort, bool defer_sort = false);
+                         uint32_t B, uint32_t *status, uint32_t *need_sort, bool defer_sort = false,
+                         uint32_t *sort_stat = nullptr);
 hipError_t launch_ascend_sort(hipStream_t s, void *nodes, uint32_t n_stride, const uint32_t *n_per_scan,
-                              uint32_t B, uint32_t *status, uint32_t *need_sort);
+                              uint32_t B, uint32_t *status, uint32_t *need_sort,
+                              uint32_t *sort_stat = nullptr);
 // publish_scan Mode A (rpl_laserscan.hip); `fast`: the mul+2*FMA divides were validated
 // A single scan straight into its serialised sensor_msgs/LaserScan (Mode A, validated fast
 // divides): the kernel writes the message prefix, patches stamp / scalars / array lengths and

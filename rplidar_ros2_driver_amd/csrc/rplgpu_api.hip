@@ -673,6 +673,16 @@ int32_t rplgpu_debug_set_cycle_buffer(rplgpu_handle_t h, void *d_buf) {
   h->dbg = (unsigned long long *)d_buf;
   return RPLGPU_OK;
 }
+// Developer aid (tests): how many scans of the handle's last rplgpu_ascend_batch_dev /
+// rplgpu_ascend_laserscan_batch_dev call failed the streaming kernel's order check and were sorted
+// by k_ascend<true>.  Waits for the stream.
+int32_t rplgpu_debug_ascend_sorted(rplgpu_handle_t h, uint32_t *count) {
+  if (!h || !count) return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, hipStreamSynchronize(h->stream));
+  RPL_HIP(h, hipMemcpy(count, h->d_small + 28, 4, hipMemcpyDeviceToHost));
+  return RPLGPU_OK;
+}
 int32_t rplgpu_debug_fast_div(rplgpu_handle_t h) {
   if (!h) return RPLGPU_ERR_INVALID_ARG;
   return (h->div4000_ok ? 1 : 0) | (h->leaf_ok ? 2 : 0) | (h->idx_ok ? 4 : 0);
@@ -694,7 +704,7 @@ int32_t rplgpu_ascend_batch_dev(rplgpu_handle_t h, rplgpu_node_t *d_nodes, uint3
   if (rc) return rc;
   RPL_HIP(h, hipSetDevice(h->device));
   RPL_HIP(h, rpl::launch_ascend(h->stream, d_nodes, n_stride, d_n_per_scan, B, d_status,
-                                h->d_need_sort));
+                                h->d_need_sort, false, h->d_small + 28));
   return RPLGPU_OK;
 }
 
@@ -726,7 +736,7 @@ int32_t rplgpu_ascend_laserscan_batch_dev(rplgpu_handle_t h, rplgpu_node_t *d_no
                      d_beam_count);
   if (rc || !write_ascended) return rc;
   RPL_HIP(h, rpl::launch_ascend(h->stream, d_nodes, n_stride, d_n_per_scan, B, d_status,
-                                h->d_need_sort));
+                                h->d_need_sort, false, h->d_small + 28));
   return RPLGPU_OK;
 }
 

@@ -78,6 +78,45 @@ class Oracle:
         lib.orc_batch_cloud_check.argtypes = [vp, sz, vp, sz, C.POINTER(OParams), vp, vp, vp, vp,
                                               C.c_int, vp]
         lib.orc_batch_cloud_check.restype = C.c_uint64
+        lib.orc_batch_ascend_check.argtypes = [vp, vp, sz, vp, sz, C.c_int, vp]
+        lib.orc_batch_ascend_check.restype = C.c_uint64
+        lib.orc_batch_laserscan_check.argtypes = [vp, sz, vp, sz, C.POINTER(OParams), vp, vp, vp, sz,
+                                                  C.c_int, vp]
+        lib.orc_batch_laserscan_check.restype = C.c_uint64
+
+    def batch_ascend_check(self, src: np.ndarray, got: np.ndarray, lens: np.ndarray, threads: int):
+        """Every scan of `src` (B x n_stride nodes, `lens[b]` used) through orc_ascend on all host
+        threads, compared with the device's in-place result `got`.  Returns (scans with a mismatch,
+        per-scan table: sl_result, differing angle words, differing nodes after canonicalising
+        equal-angle runs, valid nodes out of stable order)."""
+        B, n = src.shape
+        src = np.ascontiguousarray(src)
+        got = np.ascontiguousarray(got)
+        assert got.shape == src.shape and got.dtype == src.dtype
+        lens = np.ascontiguousarray(lens, np.uint32)
+        res = np.zeros((B, 4), np.uint32)
+        bad = int(self.lib.orc_batch_ascend_check(src.ctypes.data, got.ctypes.data, n, lens.ctypes.data, B,
+                                                  int(threads), res.ctypes.data))
+        return bad, res
+
+    def batch_laserscan_check(self, batch: np.ndarray, lens: np.ndarray, p: "OParams", ranges: np.ndarray,
+                              intens: np.ndarray, count: np.ndarray, threads: int):
+        """Every scan through orc_publish_scan on all host threads, compared with the device's
+        ranges / intensities (B x out_stride) and beam counts.  Returns (scans with a mismatch,
+        per-scan table: oracle count, count differs, differing range words, differing intensity
+        words not explained by an equal-(angle, dist) tie)."""
+        B, n = batch.shape
+        batch = np.ascontiguousarray(batch)
+        lens = np.ascontiguousarray(lens, np.uint32)
+        ranges = np.ascontiguousarray(ranges, np.float32)
+        intens = np.ascontiguousarray(intens, np.float32)
+        count = np.ascontiguousarray(count, np.uint32)
+        assert ranges.shape == intens.shape and ranges.shape[0] == B
+        res = np.zeros((B, 4), np.uint32)
+        bad = int(self.lib.orc_batch_laserscan_check(
+            batch.ctypes.data, n, lens.ctypes.data, B, C.byref(p), ranges.ctypes.data, intens.ctypes.data,
+            count.ctypes.data, ranges.shape[1], int(threads), res.ctypes.data))
+        return bad, res
 
     def batch_cloud_check(self, batch: np.ndarray, p: "OParams", arena: np.ndarray, start: np.ndarray,
                           npts: np.ndarray, keys, threads: int):
