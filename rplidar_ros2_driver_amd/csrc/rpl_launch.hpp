@@ -80,10 +80,6 @@ inline uint64_t voxel_store_need(uint32_t group, uint32_t n_stride) {
   const uint64_t s = n_stride < kMaxN ? n_stride : kMaxN;
   return (uint64_t)(group ? group : 1u) * (s + 2u * ((s + 127u) / 128u) + 1u);
 }
-// queue entries whose sort keys a voxel workgroup holds in LDS = the most a key band has; a
-// workgroup's share of the store: the records, the temporary cell area (same size), the band store
-constexpr uint32_t kVoxelKeyCap = 8192u;
-__host__ __device__ inline uint64_t voxel_store_entries_per_wg(uint64_t recs) { return 2u * recs + kVoxelKeyCap; }
 hipError_t launch_ror_mask(hipStream_t s, const void *nodes, uint32_t n_stride,
                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                            const Tables &T, uint32_t *mask, uint32_t mask_stride);

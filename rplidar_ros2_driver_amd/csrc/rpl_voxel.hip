@@ -2,10 +2,9 @@
 // (extensions E1 + E2 + E4 of SURVEY.md §8 a-ext) in ONE streaming pass over the packed
 // 8-byte nodes (reference layout src/sdk/include/sl_lidar_cmd.h:272-278).
 //
-// Geometry: persistent workgroups of RPL_VOXEL_THREADS threads (512 = 8 wave64, TWO per compute
-// unit since round 6: phase R of one scan runs under phase S of the other workgroup's scan), every
-// workgroup owns one scan (or one E8 group of scans) at a time and draws the next from a
-// device-side counter.
+// Geometry: persistent workgroups of RPL_VOXEL_THREADS threads (default 1024 = 16 wave64, one per
+// compute unit; 512 = two per compute unit with a 4096-record queue each), every workgroup owns
+// one scan (or one E8 group of scans) at a time and draws the next from a device-side counter.
 //
 // Phase S (streaming, straight-line code):
 //   * a wave works on BLOCKS of 128 consecutive samples; one buffer_load_dwordx4 per lane = TWO
@@ -26,19 +25,15 @@
 //     (ds_bpermute) from the hot loop.  Every block's records are preceded by one MARKER entry
 //     (empty key, zero prefix), so "the entry before it" is always right and no record carries a
 //     first-of-block flag (round 2: two compares, two selects and two ORs per block).
-// The record queue (round 6): the 16-byte records go to a per-workgroup RECORD STORE in global
-// memory (rewritten scan after scan by the same compute unit: it lives in L2); LDS holds only what
-// phase R sorts — the 32-bit KEY of the first kKeyCap queue entries, entry i of the scan at position
-// i of both.  (Rounds 1-5 kept the whole record in LDS: 115 KiB per scan, one scan per compute unit,
-// phase R with nothing streaming next to it.)  A scan is streamed ONCE whatever its content.
-// Phase R (per key band, regular data-parallel passes over <= kKeyCap queue entries):
-//   counting sort of the keys by row + rank inside the row -> (key, entry index) in (iy, ix) order ->
-//   heads of equal-key groups = cells -> one thread per cell fetches its records (and the entry in
-//   front of each: prefix -> run sum) from the record store, sums and writes the output point.
-// A scan whose entries all fit the key queue is one band.  Otherwise (noisy or random scans, fused
-// groups) bands of keys are cut from the record store (histogram of the rows, or bisection): a band's
-// records are normalised to run sums and set apart in the workgroup's band store; every band re-reads
-// the RECORDS (16 B per run, from L2), not the scan.
+// The record queue: the first kRecCap entries of a scan live in LDS; whatever comes after them
+// (noisy or random scans, very large rings) goes to a per-workgroup record store in global
+// memory (it stays in L2).  A scan is therefore streamed ONCE whatever its content.
+// Phase R (per key band, regular data-parallel passes over <= kRecCap queue entries):
+//   prefix -> run sums, counting sort by row + rank inside the row -> records in (iy, ix)
+//   order -> segmented integer sums over equal keys -> one output point per cell.
+// A scan whose records all fit the LDS queue is one band and never touches the record store.
+// Otherwise the LDS part joins the rest in the store and the key range is bisected until a band
+// fits; every band re-reads the RECORDS (16 B per run, from L2), not the scan.
 //
 // Fixed point: offset = (x - ix*leaf) * 2^K with 2^-K = ulp(leaf) (K = 28 for 5 cm), summed as
 // wrapping 32-bit integers (a block prefix stays below 2^32; the tiny negative offsets of a
@@ -58,7 +53,7 @@
 namespace rpl {
 
 #ifndef RPL_VOXEL_THREADS
-#define RPL_VOXEL_THREADS 512
+#define RPL_VOXEL_THREADS 1024
 #endif
 #ifndef RPL_VOXEL_WGS_PER_CU  // resident workgroups per compute unit the LDS layout is sized for
 #define RPL_VOXEL_WGS_PER_CU (RPL_VOXEL_THREADS == 512 ? 2 : 1)
@@ -66,16 +61,16 @@ namespace rpl {
 constexpr int kVB = RPL_VOXEL_THREADS;                   // threads of a voxel workgroup
 constexpr int kVW = kVB / 64;                            // its waves
 constexpr int kVWG = RPL_VOXEL_WGS_PER_CU;               // workgroups per compute unit
-constexpr uint32_t kKeyCap = kVoxelKeyCap;               // queue entries whose keys LDS holds (a band's at most)
-constexpr uint32_t kEntPerThread = kKeyCap / kVB;        // 16 (512 threads) or 8
-constexpr uint32_t kRowCap = 2048u;                      // rows the counting sort of a band handles
-constexpr uint32_t kRowsPerThread = kRowCap / kVB;       // rows a thread scans: 4 or 2
+constexpr uint32_t kRecCap = kVWG == 2 ? 4096u : 7168u;  // run records the LDS queue holds
+constexpr uint32_t kRecPerThread = kRecCap / kVB;        // 7 (one workgroup per CU), 8 or 4
+constexpr uint32_t kRowCap = kVWG == 2 ? 1024u : 2u * kVB;  // rows the counting sort of a band handles
+constexpr uint32_t kRowsPerThread = kRowCap / kVB;       // rows a thread scans: 2, or 1 (1024 threads x 2)
+constexpr uint32_t kBucketCap = kRecCap + 3u * kRowCap;  // row lists padded to multiples of 4
 constexpr uint32_t kEmptyKey = 0xFFFFFFFFu;
 constexpr float kKeyMagic = 8421376.0f;                  // 2^23 + 32768
-static_assert(kEntPerThread % 4u == 0u && kEntPerThread >= 4u, "a thread owns whole 16-byte groups of keys");
-static_assert(kRowsPerThread >= 1u && kRowsPerThread * kVB == kRowCap, "the row scan covers every row");
-static_assert(kKeyCap * 2u <= 2u * kRowCap * 4u, "the cell-head list (u16) lives in the row arrays");
-static_assert(kKeyCap <= 65536u, "entry indices of a band are 16-bit");
+static_assert(kRowsPerThread == 1u || kRowsPerThread == 2u, "the row scan handles one or two rows per thread");
+static_assert(kBucketCap * 4u <= kRecCap * 16u, "the row lists live inside the record array");
+static_assert(kRecCap * 2u <= 2u * kRowCap * 4u, "the cell-head list (u16) lives in the row arrays");
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -110,20 +105,19 @@ __device__ __forceinline__ void wave_incl_scan3_dpp(uint32_t &a, uint32_t &b, ui
 }
 
 struct VoxelLds {
-  // S: the KEY of queue entry i (a marker entry carries the empty key); the records themselves are in
-  //    the record store.  R: first the (ix << 16 | entry index) lists of the rows (the keys sit in
-  //    registers then), afterwards the keys in (iy, ix) order
-  uint32_t key[kKeyCap];
-  uint16_t sidx[kKeyCap];  // R: entry index of the record at sorted position r
-  // rows[0 .. kRowCap): first list slot of a row; rows[kRowCap .. 2 kRowCap): one past its last
-  // used slot; later the u16 cell heads
+  // S: {key, prefix_x, prefix_y, first-of-pass flag (bit 24) | prefix(count<<16 | intensity)}
+  // R: first the (ix << 16 | record index) lists of the rows (the records sit in registers
+  //    then), afterwards the records in (iy, ix) order {key, sum_x, sum_y, count<<16 | isum}
+  uint4 rec[kRecCap];
+  // rows[0 .. kRowCap): (first padded slot << 16) | first compact slot of a row;
+  // rows[kRowCap .. 2 kRowCap): one past the last used padded slot; later the u16 cell heads
   uint32_t rows[2u * kRowCap];
   uint32_t band_lo[66], band_hi[66];
   uint32_t misc[16];  // 0 queue tail, 1 status, 2 overflow, 3 sp, 4 rowmin, 5 rowmax, 7 out_base
   uint32_t tmp[32];
   double rcp[256];  // RN(1/count) for count < 256 (copied once per workgroup from the host table)
 };
-static_assert(sizeof(VoxelLds) * kVWG <= 160u * 1024u, "the workgroups of a compute unit share 160 KiB");
+static_assert(kVWG != 2 || sizeof(VoxelLds) <= 80u * 1024u, "two workgroups per compute unit");
 
 // Exclusive scan of one value per thread over the kVB threads.  `tmp` = kVW + 1 words of LDS.
 __device__ __forceinline__ uint32_t vx_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
@@ -160,20 +154,12 @@ __device__ __forceinline__ f2 div_by2(f2 a, float d, float rd) {
   return __builtin_elementwise_fma(e, rr, q);
 }
 
-// stores the compiler must not merge or re-type (see voxel_block_pass)
-// (left to the compiler, LDS and record-store variants of a store have been sunk into ONE flat store
-// through a selected pointer, and a flat instruction anywhere in the streaming loop makes every wait
-// for the prefetched loads a vmcnt(0) — flat accesses return out of order.  The compiler does not
-// see these stores: the stream ends with an explicit wait for them before its barrier.)
+// 16-byte stores the compiler must not merge or re-type (see voxel_block_pass)
 __device__ __forceinline__ void lds_store128(uint32_t lds_byte_addr, u32x4 v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(lds_byte_addr), "v"(v) : "memory");
 }
-// (s_nop: a store of more than 8 bytes reads its data registers over several cycles and a VALU
-// instruction that overwrites one of them within the next wait state changes what is stored — a hazard
-// the compiler pads for its own stores and cannot see inside inline assembly; found in round 6, when
-// the instruction behind the store happened to reuse the register of the second dword)
 __device__ __forceinline__ void glb_store128(void *p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
 }
 
 // E8 (include/rplgpu_msg.h): what happens to a point between polar->XY and the grid when a GROUP
@@ -289,49 +275,12 @@ constexpr int kBridge = RPL_VOXEL_BRIDGE;
 // Only the kernel instance the launcher picks for batches known to be noisy compiles kPassSplit:
 // inlined next to the plain path it costs a clean batch 1.5-2.7 % (profiles/r03/voxel_split_r03.txt).
 enum : int { kPassPlain = 0, kPassSplit = 2 };
-// Where a block's queue entries go: the workgroup's record store, their keys to the LDS key queue while
-// it has room (the position comes from an LDS atomic).
-// A wave stages its records in a ring of kRingEntries 16-byte entries in LDS (the arrays phase R
-// uses for its lists are free while a scan is streamed) and moves them to the queue 64 at a time
-// (voxel_ring_flush): ONE coalesced 1 KiB store per ~5 blocks instead of two or three scattered
-// 16-byte stores per block (round 6, first form: the compute unit's vector-memory path, shared by
-// the raw loads and the table gathers, became the bottleneck), one queue reservation per flush
-// instead of one LDS atomic round trip per block, and the entry in front of a record — what its
-// prefix has to be reduced by — is the ring entry in front of it, so the queue holds RUN SUMS and
-// needs no marker entries.
-constexpr uint32_t kRingEntries = 256u;  // pending < 64 at the start of a block, a block adds <= 128
+// Where a block's queue entries go: the per-scan queue (LDS while it has room, the workgroup's
+// record store after that; the position comes from an LDS atomic).
 struct QueueSink {
   VoxelLds &L;
   uint4 *G;
-  uint32_t ring_ent;  // first entry of this wave's ring in the staging area (wave-uniform)
-  uint32_t tail;      // entries this wave has staged so far (wave-uniform) ...
-  uint32_t flushed;   // ... and moved to the queue
 };
-static_assert(kVW * kRingEntries * 16u <= sizeof(VoxelLds::sidx) + sizeof(VoxelLds::rows), "the staging rings live in the list arrays");
-static_assert(offsetof(VoxelLds, rows) == offsetof(VoxelLds, sidx) + sizeof(VoxelLds::sidx) && offsetof(VoxelLds, sidx) % 16u == 0u, "... which are contiguous");
-// ring entries [S.flushed, S.flushed + count), count <= 64 -> queue entries (record store + key queue).
-// A ring entry holds {key, block prefix x, y, first-of-block flag (bit 31) | block prefix (count << 16 | intensity)}.
-__device__ __forceinline__ void voxel_ring_flush(QueueSink &S, uint32_t count) {
-  const uint32_t l = lane_id();
-  const uint32_t e = S.flushed + l;
-  const uint4 *stage = reinterpret_cast<const uint4 *>(S.L.sidx) + S.ring_ent;
-  const uint4 cur = stage[e & (kRingEntries - 1u)];
-  const uint4 prv = stage[(e - 1u) & (kRingEntries - 1u)];  // (staged by an earlier block at the latest: intact)
-  uint32_t base = 0u;
-  if (l == 0u) base = atomicAdd(&S.L.misc[0], count);
-  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-  const bool first = (cur.w >> 31) != 0u;
-  u32x4 r;
-  r.x = cur.x;
-  r.y = cur.y - (first ? 0u : prv.y);
-  r.z = cur.z - (first ? 0u : prv.z);
-  r.w = (cur.w & 0x7FFFFFFFu) - (first ? 0u : (prv.w & 0x7FFFFFFFu));
-  if (l < count) {
-    glb_store128(S.G + base + l, r);
-    if (base + l < kKeyCap) S.L.key[base + l] = cur.x;
-  }
-  S.flushed += count;
-}
 template <bool FILL, int NS, int MODE = kPassPlain>
 __device__ __forceinline__ bool voxel_block_pass(QueueSink &S, const bool (&ok)[NS], uint32_t (&key)[NS],
                                                  const uint32_t (&qx)[NS], const uint32_t (&qy)[NS],
@@ -398,8 +347,16 @@ __device__ __forceinline__ bool voxel_block_pass(QueueSink &S, const bool (&ok)[
   }
   if (total == 0u) return false;  // wave-uniform: nothing kept in this block
   if (MODE == kPassSplit && total > kSplitAbove) return true;  // wave-uniform: the caller splits the block
-  // room in the ring: what earlier blocks staged goes to the queue 64 entries at a time (wave-uniform)
-  while (S.tail - S.flushed >= 64u) voxel_ring_flush(S, 64u);
+  // reserve queue entries (the records + their marker): one LDS atomic by lane 0, its round trip
+  // overlaps the scans below (hand-placed so that the compiler's atomic optimiser does not wait
+  // for it right away)
+  uint32_t base = 0u;
+  if (lane_id() == 0) {
+    asm volatile("ds_add_rtn_u32 %0, %1, %2"
+                 : "=v"(base)
+                 : "v"((uint32_t)(uintptr_t)&S.L.misc[0]), "v"(total + 1u)
+                 : "memory");
+  }
   // lane totals -> inclusive block prefix of the lane's LAST sample; the others by subtraction
   uint32_t Px = qx[0], Py = qy[0], Pc = ci[0];
 #pragma unroll
@@ -415,9 +372,10 @@ __device__ __forceinline__ bool voxel_block_pass(QueueSink &S, const bool (&ok)[
   for (int j = 0; j < NS; ++j)
     before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[j] >> 32),
                                        __builtin_amdgcn_mbcnt_lo((uint32_t)m[j], before));
-  const uint32_t base = S.tail;
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(base)::"memory");
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
   uint32_t pos[NS];
-  pos[0] = base + before;  // entries are staged in sample order
+  pos[0] = base + 1u + before;  // entries are queued in sample order behind the marker
 #pragma unroll
   for (int j = 0; j + 1 < NS; ++j) {  // pos[j+1] = pos[j] + (a record ends at sample j): the mask is the carry-in
     uint64_t carry_out;
@@ -428,15 +386,31 @@ __device__ __forceinline__ bool voxel_block_pass(QueueSink &S, const bool (&ok)[
 #pragma unroll
   for (int j = NS - 2; j >= 0; --j)
     rec[j] = u32x4{key[j], rec[j + 1].y - qx[j + 1], rec[j + 1].z - qy[j + 1], rec[j + 1].w - ci[j + 1]};
-  // the block's first record: its prefix IS its run sum (flag: nothing is subtracted when it is flushed)
+  const u32x4 marker = {kEmptyKey, 0u, 0u, 0u};
+  // The stores are written as ds_write / global_store instructions by hand: left to the compiler,
+  // the LDS and the record-store variants of a store are sunk into ONE flat store through a
+  // selected pointer, and a flat instruction anywhere in the loop makes every wait for the
+  // prefetched loads a vmcnt(0) (flat accesses return out of order).  The compiler does not see
+  // these stores: the stream loop ends with an explicit wait for them before its barrier.
+  VoxelLds &L = S.L;
+  uint4 *const G = S.G;
+  const uint32_t lds_rec = (uint32_t)(uintptr_t)&L.rec[0];
+  if (base + 1u + total <= kRecCap) {  // wave-uniform: the usual case, everything goes to LDS
+    if (lane_id() == 0) lds_store128(lds_rec + base * 16u, marker);
 #pragma unroll
-  for (int j = 0; j < NS; ++j) rec[j].w |= (pos[j] == base) ? 0x80000000u : 0u;
-  // (hand-written store instructions: see lds_store128)
-  const uint32_t ring = (uint32_t)(uintptr_t)&S.L.sidx[0] + S.ring_ent * 16u;
+    for (int j = 0; j < NS; ++j)
+      if (__builtin_amdgcn_inverse_ballot_w64(m[j])) lds_store128(lds_rec + pos[j] * 16u, rec[j]);
+  } else {  // past (or across) the end of the LDS queue: the record store takes the rest
+    if (lane_id() == 0) {
+      if (base < kRecCap) lds_store128(lds_rec + base * 16u, marker); else glb_store128(G + base, marker);
+    }
 #pragma unroll
-  for (int j = 0; j < NS; ++j)
-    if (__builtin_amdgcn_inverse_ballot_w64(m[j])) lds_store128(ring + ((pos[j] & (kRingEntries - 1u)) << 4), rec[j]);
-  S.tail = base + total;
+    for (int j = 0; j < NS; ++j) {
+      if (__builtin_amdgcn_inverse_ballot_w64(m[j])) {
+        if (pos[j] < kRecCap) lds_store128(lds_rec + pos[j] * 16u, rec[j]); else glb_store128(G + pos[j], rec[j]);
+      }
+    }
+  }
   return false;
 }
 
@@ -510,16 +484,17 @@ struct PhaseClock {
 };
 
 // ------------------------------------------------------------------------------
-// Phase R for one key band: the keys of the band's queue entries in LDS (L.key[0 .. L.misc[0])) and
-// their 16-byte records {key, sum x, sum y, count << 16 | intensity sum} in global memory (`Q`: the
-// scan's record store, or the band store of a scan cut into bands) -> output cells in (iy, ix) order.
-// Returns 0 = done (ncell written to *ncell_out), 1 = the band must be bisected (too many rows).
+// Phase R for one key band: the queue of run records in LDS -> output cells in (iy, ix) order.
+// `normalised`: the records already hold run sums (they came from the record store).
+// Returns 0 = done (ncell written to *ncell_out), 1 = the band must be bisected (too many rows;
+// the record array is untouched in that case).
 // ------------------------------------------------------------------------------
 template <bool DBG>
-__device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, const uint4 *__restrict__ Q,
+__device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
                                                  float4 *__restrict__ out, uint32_t out_stride,
                                                  uint32_t b, uint32_t *ncell_out, int mode,
-                                                 const VoxelArena &arena, const float4 *out_buffer) {
+                                                 const VoxelArena &arena, bool normalised,
+                                                 const float4 *out_buffer) {
   PhaseClock<DBG> pc;
   pc.start();
   auto flush_dbg = [&]() {
@@ -534,26 +509,43 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
   const int vbias = p.vox_bias;
   const uint32_t nrec = L.misc[0];
   if (DBG && p.dbg && threadIdx.x == 0) pc.acc[7] += (unsigned long long)nrec << 40;
-  // thread t owns the queue entries 4 (t + k kVB) .. + 3, k = 0, 1, ...
-  uint32_t mine[kEntPerThread];
+  // thread t owns the queue records t, t + kVB, ... ; prefix -> run sum against the record just
+  // before it unless it is the first record of its wave-pass
+  uint4 mine[kRecPerThread];
   uint32_t rmin = 0xFFFFFFFFu, rmax = 0u;
 #pragma unroll
-  for (int k = 0; k < (int)kEntPerThread / 4; ++k) {
-    const uint32_t i0 = 4u * (threadIdx.x + (uint32_t)k * kVB);
-    uint4 v = make_uint4(kEmptyKey, kEmptyKey, kEmptyKey, kEmptyKey);
-    // whole 256-entry slices beyond the queue tail are skipped (wave-uniform)
-    if ((i0 & ~255u) < nrec) v = *reinterpret_cast<const uint4 *>(&L.key[i0]);
-    const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const bool ok = i0 + (uint32_t)e < nrec;  // (beyond the tail the array holds an earlier scan's keys)
-      mine[4 * k + e] = ok ? kk[e] : kEmptyKey;
+  for (int k = 0; k < (int)kRecPerThread; ++k) {
+    const uint32_t idx = threadIdx.x + (uint32_t)k * kVB;
+    uint4 m = make_uint4(kEmptyKey, 0u, 0u, 0u);
+    // whole 64-record slices beyond the queue tail are skipped (wave-uniform); the previous
+    // record comes from the lane to the left
+    if ((idx & ~63u) < nrec) {
+      const uint4 raw = L.rec[idx];  // idx < kRecCap always
+      // (a marker entry carries the empty key: it is the zero prefix in front of a block's
+      // records and nothing else)
+      const bool ok = idx < nrec && raw.x != kEmptyKey;
+      m = raw;
+      if (!normalised) {
+        uint4 pr;  // the queue entry before this one: the lane to the left holds it
+        pr.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw.y, 0x138, 0xF, 0xF, false);
+        pr.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw.z, 0x138, 0xF, 0xF, false);
+        pr.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw.w, 0x138, 0xF, 0xF, false);
+        if (lane_id() == 0u && idx > 0u) {
+          const uint4 t = L.rec[idx - 1u];
+          pr.y = t.y; pr.z = t.z; pr.w = t.w;
+        }
+        m.y -= pr.y;  // (entry 0 of a queue is a marker: a record always has a predecessor)
+        m.z -= pr.z;
+        m.w -= pr.w;
+      }
+      if (!ok) m = make_uint4(kEmptyKey, 0u, 0u, 0u);
       if (ok) {
-        rmin = min(rmin, kk[e] >> 16);
-        rmax = max(rmax, kk[e] >> 16);
-        atomicAdd(&rowstart[(kk[e] >> 16) & (kRowCap - 1u)], 1u);  // counting sort over rows
+        rmin = min(rmin, m.x >> 16);
+        rmax = max(rmax, m.x >> 16);
+        atomicAdd(&rowstart[(m.x >> 16) & (kRowCap - 1u)], 1u);  // counting sort over rows
       }
     }
+    mine[k] = m;
   }
   rmin = wave_min_lane63(rmin);  // DPP reductions: the totals land in lane 63
   rmax = wave_max_lane63(rmax);
@@ -561,7 +553,7 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
     atomicMin(&L.misc[4], rmin);
     atomicMax(&L.misc[5], rmax);
   }
-  __syncthreads();  // every key is in registers: the key array is free from here on
+  __syncthreads();  // every record is in registers: the record array is free from here on
   pc.lap(1);
   rmin = L.misc[4];
   const uint32_t out_base = L.misc[7];
@@ -571,128 +563,116 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
       flush_dbg();
       return 1u;
     }
-    uint32_t *bucket = L.key;  // (ix << 16 | entry index) by row
-    uint16_t *rowid = L.sidx;  // physical row of every list slot
-    {  // exclusive scan over the kRowCap rows in row order (kRowsPerThread per thread); a row iy
-       // lives at iy mod kRowCap, so scan position j is the physical row (j + rmin) mod kRowCap
-      uint32_t cnt[kRowsPerThread], sum = 0u;
-#pragma unroll
-      for (uint32_t r = 0; r < kRowsPerThread; ++r) {
-        cnt[r] = rowstart[(kRowsPerThread * threadIdx.x + r + rmin) & (kRowCap - 1u)];
-        sum += cnt[r];
-      }
+    uint32_t *bucket = reinterpret_cast<uint32_t *>(L.rec);  // (ix << 16 | record index) by row
+    uint32_t pad_total, nreal;
+    {  // exclusive scan over the kRowCap rows in row order (2 per thread); a row iy lives at
+       // iy mod kRowCap, so scan position j is the physical row (j + rmin) mod kRowCap.  Two
+       // sums in one word: compact positions (low half) and positions with every row padded
+       // to a multiple of four entries (high half: the rank step reads whole 16-byte blocks
+       // and needs no position masks)
+      const uint32_t p0 = (kRowsPerThread * threadIdx.x + rmin) & (kRowCap - 1u);
+      const uint32_t p1 = (kRowsPerThread * threadIdx.x + 1u + rmin) & (kRowCap - 1u);
+      const uint32_t r0 = rowstart[p0], r1 = kRowsPerThread == 2u ? rowstart[p1] : 0u;
+      const uint32_t w0 = r0 | (((r0 + 3u) & ~3u) << 16), w1 = r1 | (((r1 + 3u) & ~3u) << 16);
       uint32_t tot;
-      uint32_t ex = vx_excl_scan(sum, L.tmp, &tot);  // (tot == nrec)
-#pragma unroll
-      for (uint32_t r = 0; r < kRowsPerThread; ++r) {
-        const uint32_t pr = (kRowsPerThread * threadIdx.x + r + rmin) & (kRowCap - 1u);
-        rowstart[pr] = ex;
-        rowfill[pr] = ex;
-        ex += cnt[r];
+      const uint32_t ex = vx_excl_scan(w0 + w1, L.tmp, &tot);
+      rowstart[p0] = ex;
+      rowfill[p0] = ex >> 16;
+      if (kRowsPerThread == 2u) {
+        rowstart[p1] = ex + w0;
+        rowfill[p1] = (ex + w0) >> 16;
       }
+      pad_total = tot >> 16;
+      nreal = tot & 0xFFFFu;  // records of the band (the queue entries minus the markers)
     }
+    // padding entries compare as "not smaller than anything"
+    for (uint32_t i = threadIdx.x * 4u; i < pad_total; i += kVB * 4u)
+      *reinterpret_cast<uint4 *>(&bucket[i]) =
+          make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     __syncthreads();
     pc.lap(3);
+    // (behind the row lists: the physical row of every list slot and, later, the rank of every
+    // record — both 16-bit, both inside the record array, which is free while the records sit
+    // in registers)
+    uint16_t *rowid = reinterpret_cast<uint16_t *>(bucket + kBucketCap);
+    uint16_t *rankof = rowid + kBucketCap;
+    static_assert(kBucketCap * 6u + kRecCap * 2u <= kRecCap * 16u, "scratch fits the record array");
 #pragma unroll
-    for (int k = 0; k < (int)kEntPerThread; ++k) {
-      if (mine[k] != kEmptyKey) {
-        const uint32_t idx = 4u * (threadIdx.x + (uint32_t)(k / 4) * kVB) + (uint32_t)(k & 3);
-        const uint32_t row = (mine[k] >> 16) & (kRowCap - 1u);
+    for (int k = 0; k < (int)kRecPerThread; ++k) {
+      if (mine[k].x != kEmptyKey) {
+        const uint32_t idx = threadIdx.x + (uint32_t)k * kVB;
+        const uint32_t row = (mine[k].x >> 16) & (kRowCap - 1u);
         const uint32_t pos = atomicAdd(&rowfill[row], 1u);
-        bucket[pos] = (mine[k] << 16) | idx;  // (ix, entry index): unique
+        bucket[pos] = (mine[k].x << 16) | idx;  // (ix, record index): unique
         rowid[pos] = (uint16_t)row;
       }
     }
     __syncthreads();
     pc.lap(4);
-    // rank inside the row = number of smaller entries of the same row; final position = first slot of
-    // the row + rank.  The work is handed out by LIST SLOT: thread t ranks the entries at slots t,
-    // t + kVB, ... — the lanes of a wave then hold neighbouring slots, i.e. entries of the same or
-    // adjacent rows, whose lists they read at the same time (LDS broadcast), and the entries of a long
-    // row (the top and bottom of a ring; with range noise hundreds of records) are spread over many
-    // threads.  Four slots at a time so that the dependent LDS round trips (slot -> row -> list)
-    // of the four overlap.  A thread keeps (ix | entry index) and (row | final position) of its slots
-    // until every list has been read.
-    uint32_t keep_me[kEntPerThread], keep_rp[kEntPerThread];
+    // rank inside the row = number of smaller entries of the same row.  The work is handed out
+    // by LIST SLOT, not by record: thread t ranks the entries at slots t, t + kVB, ... — the
+    // entries of a long row (a ring running along x, with range noise hundreds of records) are
+    // then spread over as many threads, which read the same blocks at the same time (LDS
+    // broadcast), instead of one thread walking its 7 rows alone whatever their length
+    // (noisy scans: 43 k -> cycles of the v1 kernel's rank step, p99 150 k).
+    for (uint32_t q = threadIdx.x; q < pad_total; q += kVB) {
+      const uint32_t me = bucket[q];
+      if (me != 0xFFFFFFFFu) {
+        const uint32_t row = rowid[q];
+        const uint32_t st = rowstart[row], s1 = rowfill[row];
+        const uint32_t s0 = st >> 16;  // padded start, a multiple of 4; s1 > s0
+        uint32_t rank = st & 0xFFFFu;
+        // the first two blocks are read together (one LDS round trip covers rows of <= 8)
+        const uint4 v0 = *reinterpret_cast<const uint4 *>(&bucket[s0]);
+        const uint4 v1 = *reinterpret_cast<const uint4 *>(&bucket[min(s0 + 4u, kBucketCap - 4u)]);
+        rank += (v0.x < me) + (v0.y < me) + (v0.z < me) + (v0.w < me);
+        if (s0 + 4u < s1) {
+          rank += (v1.x < me) + (v1.y < me) + (v1.z < me) + (v1.w < me);
+          for (uint32_t m = s0 + 8u; m < s1; m += 16u) {  // long rows: four blocks per trip
+            uint4 w[4];  // (blocks past the row's end belong to the next rows or are padding:
+                         //  they are read — inside the array — but not counted)
 #pragma unroll
-    for (int j0 = 0; j0 < (int)kEntPerThread; j0 += 4) {
-      if ((uint32_t)j0 * kVB < nrec) {  // block-uniform
-        uint32_t me[4], row[4], s0[4], len[4];
-        uint4 v0[4];
+            for (int j = 0; j < 4; ++j)
+              w[j] = *reinterpret_cast<const uint4 *>(&bucket[min(m + 4u * j, kBucketCap - 4u)]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t q = threadIdx.x + (uint32_t)(j0 + u) * kVB;
-          me[u] = q < nrec ? bucket[q] : 0xFFFFFFFFu;
-          row[u] = q < nrec ? (uint32_t)rowid[q] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          s0[u] = rowstart[row[u]];
-          len[u] = rowfill[row[u]] - s0[u];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v0[u] = *reinterpret_cast<const uint4 *>(&bucket[s0[u] & ~3u]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          // slots [s0, s0 + len) of the list, read as aligned groups of four; a slot of the group
-          // outside the row (its neighbours' entries) is recognised by its position, not its value
-          uint32_t m = s0[u] & ~3u, rank = 0u;
-          uint4 v = v0[u];
-          while (true) {
-            const uint32_t d = m - s0[u];  // (wraps below the row's first slot: fails the test)
-            rank += ((d < len[u]) & (v.x < me[u])) + ((d + 1u < len[u]) & (v.y < me[u])) +
-                    ((d + 2u < len[u]) & (v.z < me[u])) + ((d + 3u < len[u]) & (v.w < me[u]));
-            m += 4u;
-            if (m >= s0[u] + len[u] || me[u] == 0xFFFFFFFFu) break;
-            v = *reinterpret_cast<const uint4 *>(&bucket[m]);  // (m < kKeyCap: inside the array)
+            for (int j = 0; j < 4; ++j)
+              if (m + 4u * j < s1) rank += (w[j].x < me) + (w[j].y < me) + (w[j].z < me) + (w[j].w < me);
           }
-          keep_me[j0 + u] = me[u];
-          keep_rp[j0 + u] = row[u] | ((s0[u] + rank) << 16);
         }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) keep_me[j0 + u] = 0xFFFFFFFFu, keep_rp[j0 + u] = 0u;
-      }
-    }
-    __syncthreads();  // the sorted keys overwrite the lists
-#pragma unroll
-    for (int j = 0; j < (int)kEntPerThread; ++j) {
-      if (keep_me[j] != 0xFFFFFFFFu) {
-        const uint32_t prow = keep_rp[j] & 0xFFFFu, at = keep_rp[j] >> 16;
-        const uint32_t iy = rmin + ((prow - rmin) & (kRowCap - 1u));
-        L.key[at] = (iy << 16) | (keep_me[j] >> 16);
-        L.sidx[at] = (uint16_t)keep_me[j];
+        rankof[me & 0xFFFFu] = (uint16_t)rank;
       }
     }
     __syncthreads();
+    uint32_t rk[kRecPerThread];
+#pragma unroll
+    for (int k = 0; k < (int)kRecPerThread; ++k)
+      rk[k] = rankof[threadIdx.x + (uint32_t)k * kVB];  // (garbage for empty slots: not used)
+    __syncthreads();  // the sorted records overwrite the lists
+#pragma unroll
+    for (int k = 0; k < (int)kRecPerThread; ++k)
+      if (mine[k].x != kEmptyKey) L.rec[rk[k]] = mine[k];
+    __syncthreads();
     pc.lap(5);
-    // heads of equal-key groups -> cell index; thread t owns the sorted positions [E t, E t + E)
-    const uint32_t r_lo = threadIdx.x * kEntPerThread;
+    // heads of equal-key groups -> cell index; thread t owns sorted records [8t, 8t+8)
+    const uint32_t r_lo = threadIdx.x * kRecPerThread;
     uint32_t headbits = 0, nheads = 0;
-    if (r_lo < nrec) {
-      uint32_t prevkey = r_lo > 0 ? L.key[r_lo - 1] : kEmptyKey;
+    uint32_t prevkey = (r_lo > 0 && r_lo <= nreal) ? L.rec[r_lo - 1].x : kEmptyKey;
 #pragma unroll
-      for (int k = 0; k < (int)kEntPerThread / 4; ++k) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(&L.key[r_lo + 4u * k]);
-        const uint32_t kk[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t r = r_lo + 4u * k + e;
-          const uint32_t key = (r < nrec) ? kk[e] : kEmptyKey;
-          if (r < nrec && key != prevkey) {
-            headbits |= 1u << (4 * k + e);
-            ++nheads;
-          }
-          prevkey = key;
-        }
+    for (int k = 0; k < (int)kRecPerThread; ++k) {
+      const uint32_t r = r_lo + k;
+      const uint32_t key = (r < nreal) ? L.rec[r].x : kEmptyKey;
+      if (r < nreal && key != prevkey) {
+        headbits |= 1u << k;
+        ++nheads;
       }
+      prevkey = key;
     }
     uint32_t cell = vx_excl_scan(nheads, L.tmp, &ncell);
     pc.lap(6);
     // position of every cell's first record (16-bit entries; the row arrays are free again)
     uint16_t *heads = reinterpret_cast<uint16_t *>(L.rows);
 #pragma unroll
-    for (int k = 0; k < (int)kEntPerThread; ++k)
+    for (int k = 0; k < (int)kRecPerThread; ++k)
       if ((headbits >> k) & 1u) heads[cell++] = (uint16_t)(r_lo + k);
     __syncthreads();
     // one cell per thread, coalesced 16-byte output rows.  All sums are exact in fp64
@@ -716,82 +696,57 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p, 
     } else if (mode == kEmitCountOnly) {
       nemit = 0u;  // several bands: first learn the total, the cells are written in a second go
     }
-    // Four cells per thread and trip: the records come from global memory (the record store lives in
-    // L2, a round trip behind the other workgroup's streaming loads), so all the gathers of a trip are
-    // issued before the first is used.  A cell is 1.13 records on average: the head and the record
-    // behind it (the head again when it is alone: the same line) are fetched, the rest of a longer
-    // cell serially.
-    for (uint32_t c0 = threadIdx.x; c0 - threadIdx.x < nemit; c0 += 4u * kVB) {
-      uint32_t r[4], key[4], i0[4], i1[4];
-      bool m1[4];
-      uint4 q0[4], q1[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t c = c0 + (uint32_t)u * kVB;
-        r[u] = c < nemit ? (uint32_t)heads[c] : 0u;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t r1 = min(r[u] + 1u, kKeyCap - 1u);
-        key[u] = L.key[r[u]];
-        m1[u] = (r[u] + 1u < nrec) && (L.key[r1] == key[u]);
-        i0[u] = L.sidx[r[u]];
-        i1[u] = m1[u] ? (uint32_t)L.sidx[r1] : i0[u];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        q0[u] = Q[i0[u]];
-        q1[u] = Q[i1[u]];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t c = c0 + (uint32_t)u * kVB;
-        if (c < nemit) {
-          double sx = run_sum_f64(q0[u].y), sy = run_sum_f64(q0[u].z);
-          // count and intensity sum are packed per RECORD (<= 128 samples: 16 bits each suffice);
-          // per CELL they are summed apart -- a large or close cell collects thousands of samples
-          // and its intensity sum passes 2^16 (found by tests/test_gpu_fuzz.py)
-          uint32_t cnt = q0[u].w >> 16, isum = q0[u].w & 0xFFFFu;
-          if (m1[u]) {
-            sx += run_sum_f64(q1[u].y);
-            sy += run_sum_f64(q1[u].z);
-            cnt += q1[u].w >> 16;
-            isum += q1[u].w & 0xFFFFu;
-            for (uint32_t rr = r[u] + 2u; rr < nrec; ++rr) {  // segmented sum over the rest of this cell's records
-              if (L.key[rr] != key[u]) break;
-              const uint4 q = Q[L.sidx[rr]];
-              sx += run_sum_f64(q.y);
-              sy += run_sum_f64(q.z);
-              cnt += q.w >> 16;
-              isum += q.w & 0xFFFFu;
-            }
-          }
-          const double ix = (double)((int)(key[u] & 0xFFFFu) - 32768);
-          const double iy = (double)((int)(key[u] >> 16) - 32768);
-          // RN(1/count): from the LDS copy of the host-built table for small counts, else the IEEE
-          // fp64 divide (correctly rounded, i.e. the same value; ~25 instructions); a dependent
-          // gather from the table in global memory (L2 latency) per cell costs more than either
-          const double dc = (double)cnt;
-          const double rc = cnt < 256u ? L.rcp[cnt] : 1.0 / dc;
-          const double Sx = fma(dc, ix * dL - dbias, sx);  // coordinate sums in units of 2^-K m
-          const double Sy = fma(dc, iy * dL - dbias, sy);
-          const double si = (double)isum;
-          double qx = Sx * rc, qy = Sy * rc, qi = si * rc;
-          qx = fma(fma(-qx, dc, Sx), rc, qx);
-          qy = fma(fma(-qy, dc, Sy), rc, qy);
-          qi = fma(fma(-qi, dc, si), rc, qi);
-          if (arena.xyi && (mode == kEmitArenaFirst || mode == kEmitArenaKnown)) {
-            float *f = reinterpret_cast<float *>(arena.base) + 3u * (size_t)((out - arena.base) + out_base + c);
-            f[0] = (float)(qx * inv_scale);
-            f[1] = (float)(qy * inv_scale);
-            f[2] = (float)qi;
-          } else {
-            out[out_base + c] = make_float4((float)(qx * inv_scale), (float)(qy * inv_scale), 0.0f,
-                                            (float)qi);
-          }
-          if (cell_keys) cell_keys[out_base + c] = key[u];  // (block-uniform pointer, usually null)
+    for (uint32_t c = threadIdx.x; c < nemit; c += kVB) {
+      uint32_t r = heads[c];
+      // a cell is 1.13 records on average: fetch the head and the two records behind it in one
+      // round trip, continue serially only when all three belong to the cell
+      const uint4 q0 = L.rec[r];
+      const uint4 q1 = L.rec[min(r + 1u, kRecCap - 1u)];
+      const uint4 q2 = L.rec[min(r + 2u, kRecCap - 1u)];
+      const uint32_t key = q0.x;
+      const bool m1 = (r + 1u < nreal) && (q1.x == key);
+      const bool m2 = m1 && (r + 2u < nreal) && (q2.x == key);
+      double sx = run_sum_f64(q0.y), sy = run_sum_f64(q0.z);
+      // count and intensity sum are packed per RECORD (<= 128 samples: 16 bits each suffice);
+      // per CELL they are summed apart -- a large or close cell collects thousands of samples
+      // and its intensity sum passes 2^16 (found by tests/test_gpu_fuzz.py)
+      uint32_t cnt = q0.w >> 16, isum = q0.w & 0xFFFFu;
+      if (m1) { sx += run_sum_f64(q1.y); sy += run_sum_f64(q1.z); cnt += q1.w >> 16; isum += q1.w & 0xFFFFu; }
+      if (m2) {
+        sx += run_sum_f64(q2.y); sy += run_sum_f64(q2.z); cnt += q2.w >> 16; isum += q2.w & 0xFFFFu;
+        for (r += 3u; r < nreal; ++r) {  // segmented sum over the rest of this cell's records
+          const uint4 q = L.rec[r];
+          if (q.x != key) break;
+          sx += run_sum_f64(q.y);
+          sy += run_sum_f64(q.z);
+          cnt += q.w >> 16;
+          isum += q.w & 0xFFFFu;
         }
       }
+      const double ix = (double)((int)(key & 0xFFFFu) - 32768);
+      const double iy = (double)((int)(key >> 16) - 32768);
+      // RN(1/count): from the LDS copy of the host-built table for small counts, else the IEEE
+      // fp64 divide (correctly rounded, i.e. the same value; ~25 instructions); a dependent
+      // gather from the table in global memory (L2 latency) per cell costs more than either
+      const double dc = (double)cnt;
+      const double rc = cnt < 256u ? L.rcp[cnt] : 1.0 / dc;
+      const double Sx = fma(dc, ix * dL - dbias, sx);  // coordinate sums in units of 2^-K m
+      const double Sy = fma(dc, iy * dL - dbias, sy);
+      const double si = (double)isum;
+      double qx = Sx * rc, qy = Sy * rc, qi = si * rc;
+      qx = fma(fma(-qx, dc, Sx), rc, qx);
+      qy = fma(fma(-qy, dc, Sy), rc, qy);
+      qi = fma(fma(-qi, dc, si), rc, qi);
+      if (arena.xyi && (mode == kEmitArenaFirst || mode == kEmitArenaKnown)) {
+        float *f = reinterpret_cast<float *>(arena.base) + 3u * (size_t)((out - arena.base) + out_base + c);
+        f[0] = (float)(qx * inv_scale);
+        f[1] = (float)(qy * inv_scale);
+        f[2] = (float)qi;
+      } else {
+        out[out_base + c] = make_float4((float)(qx * inv_scale), (float)(qy * inv_scale), 0.0f,
+                                        (float)qi);
+      }
+      if (cell_keys) cell_keys[out_base + c] = key;  // (block-uniform pointer, usually null)
     }
   }
   __syncthreads();
@@ -896,9 +851,6 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
       }
     }
   }
-  // what is left in the ring (wave-uniform)
-  while (sink.tail - sink.flushed >= 64u) voxel_ring_flush(sink, 64u);
-  if (sink.tail != sink.flushed) voxel_ring_flush(sink, sink.tail - sink.flushed);
   if (DBG && dbg_slot && threadIdx.x == 0)
     for (int i = 0; i < 5; ++i) atomicAdd(&dbg_slot[8 + i], sub[i]);
 }
@@ -950,10 +902,11 @@ __device__ __forceinline__ void voxel_stream_dispatch(QueueSink &sink, const KPa
 }
 
 // ------------------------------------------------------------------------------
-// The persistent per-item loop: draw a work item, let `first_band(b, bl, flags)` stream it — every
-// queue entry at its own index in this workgroup's record store G, the keys of the entries
-// [0, kKeyCap) in the LDS key queue, the total in L.misc[0] — then turn key bands of them into cells
-// (phase R) and publish the item's results.  item0: first item of this launch; B: its items.
+// The persistent per-item loop shared by the fused kernel and by k_voxel_cells: draw a work item,
+// let `first_band(b, bl, flags)` put the item's queue entries in place — entries [0, kRecCap) in the
+// LDS queue, the rest at their own index in this workgroup's record store G, the total in
+// L.misc[0] — then turn key bands of them into cells (phase R) and publish the item's results.
+// item0: first item of this launch (a launch may be one stage of a batch); B: its items.
 // ------------------------------------------------------------------------------
 template <bool DBG, class FirstBand>
 __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, const Tables &T,
@@ -963,7 +916,6 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
                                                 uint32_t item0, const VoxelArena &arena,
                                                 FirstBand &&first_band) {
   if (threadIdx.x < 256) L.rcp[threadIdx.x] = T.rcp[threadIdx.x];  // (first barrier below publishes it)
-  uint4 *const Bs = G + 2u * (size_t)T.voxel_store_recs;  // the band store, behind the records and the cell area
   // persistent workgroups; the first item is blockIdx.x, the next ones come from a shared counter,
   // so a workgroup that drew cheap scans simply takes more of them
   for (uint32_t bl = blockIdx.x; bl < B;) {
@@ -1005,10 +957,9 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
       L.misc[8] = 0xFFFFFFFFu;  // occupied key range of the band (known after a failed selection)
       L.misc[9] = 0u;
     }
-    // the row histogram of this band is filled while the keys are loaded in phase R (rows
+    // the row histogram of this band is filled while the records are loaded in phase R (rows
     // are addressed modulo kRowCap, so the first row need not be known yet)
-    if (!first)
-      for (uint32_t t = threadIdx.x; t < kRowCap; t += kVB) L.rows[t] = 0u;
+    for (uint32_t t = threadIdx.x; t < kRowCap; t += kVB) L.rows[t] = 0u;
     __syncthreads();
 
     if (first) {
@@ -1017,17 +968,16 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
       // the record stores of phase S are hand-written instructions the compiler does not track
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();  // (workgroup-scope release / acquire: covers the record store too)
-      // (the staging rings of phase S lived in the list arrays)
-      for (uint32_t t = threadIdx.x; t < kRowCap; t += kVB) L.rows[t] = 0u;
-      __syncthreads();
       pc.lap(0);
       n_all = L.misc[0];
       if (threadIdx.x == 0 && T.voxel_stats) {  // queue statistics of the launch (see SPLIT)
         atomicAdd(&T.voxel_stats[0], (unsigned long long)n_all);
         atomicAdd(&T.voxel_stats[1], 1ull);
       }
-      if (n_all > kKeyCap) {
-        // more entries than the key queue holds: the bands below are cut from the record store
+      if (n_all > kRecCap) {
+        // the scan did not fit the LDS queue: its first kRecCap records join the others in the
+        // record store, and the bands below are cut from the store
+        for (uint32_t i = threadIdx.x; i < kRecCap; i += kVB) G[i] = L.rec[i];
         from_store = true;
         if (threadIdx.x == 0) {
           L.misc[2] = 1u;
@@ -1049,7 +999,7 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
         // (A scan of up to three queues' worth of records keeps the bisection: its first cut is iy = 0,
         // which halves a ring; measured on rings with 3 cm of range noise, 14-20 k records per scan:
         // 1.64 ms per batch bisected, 1.82 with histogram bands.)
-        if (n_all > 3u * (kKeyCap - kKeyCap / 16u)) {
+        if (n_all > 3u * (kRecCap - kRecCap / 16u)) {
           uint32_t rmn = 0xFFFFFFFFu, rmx = 0u;
           constexpr int KU = 8;  // key loads in flight per thread (one at a time: 29 round trips per pass)
           for (uint32_t i0 = threadIdx.x; i0 < n_all; i0 += KU * kVB) {
@@ -1101,7 +1051,7 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
             uint32_t tot;
             uint32_t ex = vx_excl_scan(mine, L.tmp, &tot);
             // as few bands as 15/16-full queues allow, equally full
-            const uint32_t want = (tot + (kKeyCap - kKeyCap / 16u) - 1u) / (kKeyCap - kKeyCap / 16u);
+            const uint32_t want = (tot + (kRecCap - kRecCap / 16u) - 1u) / (kRecCap - kRecCap / 16u);
             const uint32_t kBandFill = max((tot + want - 1u) / max(want, 1u), 1u);
             // a band boundary in front of bin b: the running count passes a multiple of kBandFill
             uint32_t flag[kRowsPerThread], nflag = 0u, prev_cnt = before_me, e = ex;
@@ -1142,29 +1092,42 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
       }
     } else {
       // ---- a band of a scan that lives in the record store: select its records ----------
-      // the keys of the band's records are appended to the LDS key queue, the records to the same
-      // positions of the workgroup's band store
+      // record i -> run sums against record i - 1 (unless first of its wave-pass), exactly what
+      // phase R does for the LDS queue; the records of the band are appended to the LDS queue
       bool fits = true;
       uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;  // keys of this band's records seen by this lane
       constexpr int NJ = 4;  // records per thread and trip: four independent loads in flight
       for (uint32_t i0 = 0; i0 < n_all; i0 += NJ * kVB) {
-        uint4 m[NJ];
+        uint4 raw[NJ], prl[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const uint32_t i = i0 + (uint32_t)j * kVB + threadIdx.x;
-          m[j] = make_uint4(kEmptyKey, 0u, 0u, 0u);
-          if (i < n_all) m[j] = G[i];
+          raw[j] = make_uint4(kEmptyKey, 0u, 0u, 0u);
+          prl[j] = make_uint4(0u, 0u, 0u, 0u);
+          if (i < n_all) raw[j] = G[i];
+          // the record before a wave's first one lives in another wave's registers: lane 0 loads it
+          if (lane_id() == 0u && i > 0u && i < n_all) prl[j] = G[i - 1u];
         }
         bool in[NJ];
         uint64_t msk[NJ];
         uint32_t cnt = 0;
+        uint4 m[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const uint32_t i = i0 + (uint32_t)j * kVB + threadIdx.x;
-          in[j] = (i < n_all) && ((m[j].x - klo) <= (khi - klo));
+          uint4 pr;  // record i - 1: the lane to the left holds it
+          pr.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw[j].y, 0x138, 0xF, 0xF, false);
+          pr.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw[j].z, 0x138, 0xF, 0xF, false);
+          pr.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw[j].w, 0x138, 0xF, 0xF, false);
+          if (lane_id() == 0u) { pr.y = prl[j].y; pr.z = prl[j].z; pr.w = prl[j].w; }
+          m[j] = raw[j];  // (markers: empty key, outside every band; entry 0 is a marker)
+          m[j].y -= pr.y;
+          m[j].z -= pr.z;
+          m[j].w -= pr.w;
+          in[j] = (i < n_all) && ((raw[j].x - klo) <= (khi - klo));
           if (in[j]) {
-            kmin = min(kmin, m[j].x);
-            kmax = max(kmax, m[j].x);
+            kmin = min(kmin, raw[j].x);
+            kmax = max(kmax, raw[j].x);
           }
           msk[j] = __builtin_amdgcn_ballot_w64(in[j]);
           cnt += (uint32_t)__popcll(msk[j]);
@@ -1173,16 +1136,12 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
           uint32_t base = 0u;
           if (lane_id() == 0) base = atomicAdd(&L.misc[0], cnt);
           base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          if (base + cnt > kKeyCap) {
+          if (base + cnt > kRecCap) {
             fits = false;  // the band holds more than the queue: it will be bisected
           } else {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-              if (in[j]) {
-                const uint32_t at = base + (uint32_t)__popcll(msk[j] & lanemask_lt());
-                L.key[at] = m[j].x;
-                Bs[at] = m[j];
-              }
+              if (in[j]) L.rec[base + (uint32_t)__popcll(msk[j] & lanemask_lt())] = m[j];
               base += (uint32_t)__popcll(msk[j]);
             }
           }
@@ -1253,9 +1212,13 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
     } else if (emit_mode != kEmitLegacy) {
       out_limit = 0xFFFFFFFFu;  // (first band: bounded inside, at the reservation)
     }
-    if (voxel_reduce<DBG>(L, p, from_store ? Bs : G, out, out_limit, b, &ncell, emit_mode, arena,
+    if (voxel_reduce<DBG>(L, p, out, out_limit, b, &ncell, emit_mode, arena, from_store,
                           arena.base ? arena.base : xyzi)) {
-      from_store = true;  // (the queue spans too many rows: cut bands from the record store)
+      if (!from_store) {  // the LDS queue spans too many rows: cut bands from the record store
+        for (uint32_t i = threadIdx.x; i < n_all; i += kVB) G[i] = L.rec[i];
+        from_store = true;
+        __syncthreads();
+      }
       bisect();
       leave_single_band_mode();
       continue;
@@ -1359,14 +1322,14 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(kVB * kVWG 
   __shared__ VoxelLds L;
   // this workgroup's record store (T.voxel_store_recs entries, voxel_store_need(): every sample
   // of the work item could end a run, plus the block markers)
-  uint4 *G = store + (size_t)blockIdx.x * voxel_store_entries_per_wg(T.voxel_store_recs);  // records, cell area, band store
+  uint4 *G = store + (size_t)blockIdx.x * 2u * T.voxel_store_recs;  // records, then the cell area
   const float2 *cs = p.inverted ? T.cs_inv : T.cs;
   const uint32_t ishift = p.is_new_protocol ? 0u : 2u;  // :591-592
   const uint32_t ibfe_off = 16u + ishift, ibfe_w = 0xFFu >> ishift;  // shift, mask
   const uint32_t q_min16 = p.clip_enable ? (min(p.q_min, 256u) << 16) : 0u;
   const bool use_xf = (group > 1u) || motion || pose2d;  // block-uniform
   auto phase_s = [&](uint32_t b, uint32_t, uint32_t &flags) {
-    QueueSink sink{L, G, (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_id() * kRingEntries)), 0u, 0u};
+    QueueSink sink{L, G};
     const uint32_t s_lo = b * group, s_hi = min(n_scans, s_lo + group);
     for (uint32_t sc = s_lo; sc < s_hi; ++sc) {
       // (readfirstlane: the value is wave-uniform, and must live in scalar registers for the
@@ -1440,7 +1403,7 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   const uint32_t n_scans = B;
   B = (B + group - 1u) / group;  // work items
   if (!T.voxel_store || T.voxel_store_wgs == 0) return hipErrorInvalidValue;
-  // (the handle allocates voxel_store_entries_per_wg() entries per workgroup: records, cell area, band store)
+  // (the handle allocates 2 x voxel_store_recs entries per workgroup: records, then the cell area)
   if (voxel_store_need(group, n_stride) > T.voxel_store_recs) return hipErrorInvalidValue;
   VoxelArena ar;
   ar.base = (float4 *)arena;
@@ -1448,6 +1411,7 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   ar.capacity = arena_capacity;
   ar.scan_start = scan_start;
   ar.xyi = (arena && arena_xyi) ? 1 : 0;
+  if (kVWG == 2 && group > 1) return hipErrorInvalidValue;  // (fused groups: 16-wave geometry only)
   // persistent workgroups of the handle's device (no more than the handle owns record stores
   // for); the item queue is cleared by a memset ahead of every launch (an aborted launch can
   // therefore not poison the next one)

@@ -209,8 +209,8 @@ bool voxel_split_for(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride, uint
     split = c->voxel_split;
     if (items != 0 && entries <= items * group * 70000ull) {  // (sanity: a torn or stale pair)
       const unsigned long long avg = entries / (items * group);  // per scan, not per work item
-      if (!split && avg > 6200ull) split = true;        // (a clean C3 scan: ~3050; no marker entries since round 6)
-      else if (split && avg < 3700ull) split = false;   // (1 cm noise, two classes: ~5700)
+      if (!split && avg > 6500ull) split = true;        // (a clean C3 scan: ~3300)
+      else if (split && avg < 4000ull) split = false;   // (1 cm noise, two classes: ~6200)
     }
   }
   if (with_stats) {  // this launch's statistics will describe `id`
@@ -583,9 +583,8 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   // at most two workgroups per CU and never more than scans in a batch)
   c->vstore_wgs = std::min<uint32_t>(c->max_b, rpl::voxel_max_workgroups(c->n_cu));
   c->vstore_recs = (uint32_t)rpl::voxel_store_need(1u, rpl::kMaxN);
-  // (every workgroup's record store is followed by its temporary cell area of the same size and by
-  // its band store)
-  if (hipMalloc(&c->d_vstore, (size_t)c->vstore_wgs * rpl::voxel_store_entries_per_wg(c->vstore_recs) * 16u) != hipSuccess) {
+  // (x 2: every workgroup's record store is followed by its temporary cell area of the same size)
+  if (hipMalloc(&c->d_vstore, (size_t)c->vstore_wgs * c->vstore_recs * 32u) != hipSuccess) {
     c->err = "record store allocation failed";
     return fail(RPLGPU_ERR_HIP);
   }
@@ -856,7 +855,7 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
     RPL_HIP(h, hipSetDevice(h->device));
     RPL_HIP(h, hipStreamSynchronize(h->stream));
     void *bigger = nullptr;
-    if (hipMalloc(&bigger, (size_t)h->vstore_wgs * rpl::voxel_store_entries_per_wg(need) * 16u) != hipSuccess) {
+    if (hipMalloc(&bigger, (size_t)h->vstore_wgs * need * 32u) != hipSuccess) {
       h->err = "record store allocation failed";
       (void)hipGetLastError();
       return RPLGPU_ERR_HIP;
