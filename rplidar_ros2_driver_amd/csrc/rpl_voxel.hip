@@ -158,8 +158,13 @@ __device__ __forceinline__ f2 div_by2(f2 a, float d, float rd) {
 __device__ __forceinline__ void lds_store128(uint32_t lds_byte_addr, u32x4 v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(lds_byte_addr), "v"(v) : "memory");
 }
+// (s_nop: a store of more than 8 bytes reads its data registers over several cycles, and a VALU
+// instruction that overwrites one of them within the next wait state changes what is stored — a hazard
+// the compiler pads for its own stores and cannot see inside inline assembly.  Round 6 hit it in an
+// experimental form of this kernel, profiles/r06/voxel_keys_in_lds_r06.txt; here the instruction behind
+// the store has never reused a data register, and must not start to after some unrelated change.)
 __device__ __forceinline__ void glb_store128(void *p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // E8 (include/rplgpu_msg.h): what happens to a point between polar->XY and the grid when a GROUP
