@@ -610,7 +610,7 @@ def main():
             n_chunks = args.chunks
         else:
             n_chunks = best_chunks(world, 0.449 * launch_rel(B_total) / launch_rel(4096), 12.0 * 2670.0 * B_total,
-                                   B_total, gather_root=args.exchange == "gather")
+                                   B_total)
         exch = CloudExchange(gpu, dist, dev, world, rank, B, n, out_stride, n_chunks,
                              root=0 if args.exchange == "gather" else None)
         if exch.native and exch.comm_ranks != world:
@@ -669,10 +669,17 @@ def main():
                         "comm_ranks": exch.comm_ranks, "exchange": args.exchange,
                         "model_ms_per_step": round(predicted_step_ms(
                             world, ms_c * world, 12.0 * world * exch.chunks * (exch.slot or 0), exch.chunks,
-                            gather_root=args.exchange == "gather", scans_total=B_total), 4),
+                            scans_total=B_total), 4),
+                        # both exchanges' rows: the model prices them the same — see
+                        # sharding.predicted_step_ms — so one row per chunk count serves both
+                        "model_rows_ms": {str(c): round(predicted_step_ms(
+                            world, ms_c * world, 12.0 * world * exch.chunks * (exch.slot or 0), c,
+                            scans_total=B_total), 4) for c in (1, 2, 4, 8)},
                         "model_note": "DESIGN.md section 7: a piece = one launch over the rank's scans / chunks (measured "
                                       "launch-time curve) + its slot on one 76.8 GB/s link + 0.015 ms, pieces "
-                                      "pipelined; measured = overlapped_ms; chunks chosen by the same model",
+                                      "pipelined; measured = overlapped_ms; chunks chosen by the same model; "
+                                      "all-gather and gather-to-root are priced the same (the root's inbound slots "
+                                      "arrive on different links; nothing with two ranks has been measured)",
                         "note": "compute = the rank's whole block in one launch, no exchange; "
                                 "exchange_only = RCCL all-gather of the last step's clouds; "
                                 "overlapped = the timed step (chunked, two streams)"}

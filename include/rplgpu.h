@@ -117,7 +117,7 @@ int32_t rplgpu_abi_version(void);
 /* on_configure: binds to HIP device `device_id`, builds the Q14 angle / cos / sin
  * tables on the host with the reference's own expressions and uploads them,
  * allocates staging for max_batch scans of max_samples_per_scan samples
- * (max_samples_per_scan <= RPLGPU_MAX_SAMPLES_PER_SCAN). */
+ * (max_samples_per_scan <= RPLGPU_MAX_SAMPLES_PER_SCAN, max_batch < 2^24). */
 int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t max_batch,
                       rplgpu_handle_t *out);
 int32_t rplgpu_destroy(rplgpu_handle_t h); /* on_cleanup */

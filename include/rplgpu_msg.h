@@ -172,7 +172,11 @@ int32_t rplgpu_transform_clouds_dev(rplgpu_handle_t h, float *d_xyzi, uint32_t o
  *   s = a * (1 + a2 * (-1/6 + a2 * (1/120)))            (Horner, every operation rounded to
  *   c = 1 + a2 * (-1/2 + a2 * (1/24 + a2 * (-1/720)))    float32 once, no FMA)
  *   x' = (c*x - s*y) + vx*tau;   y' = (s*x + c*y) + vy*tau
- * valid for |a| <= 0.5 rad (polynomial error < 2e-8).  Output as rplgpu_cloud_batch_dev. */
+ * stated for |a| <= 0.5 rad.  These ARE the definition of E6 (the oracle evaluates the same
+ * polynomials, so parity does not depend on their accuracy); against the true rotation s is short by
+ * a^7 / 5040 and c by a^8 / 40320: 2e-8 / 7e-10 at 0.27 rad (a 10 Hz scan at 2.7 rad/s), 1.5e-6 / 1e-7
+ * at 0.5 rad (round 6 corrects the "< 2e-8 at 0.5 rad" this comment used to claim).  Output as
+ * rplgpu_cloud_batch_dev. */
 int32_t rplgpu_cloud_deskew_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
                                       uint32_t n_stride, const uint32_t *d_n_per_scan, uint32_t B,
                                       const rplgpu_params_t *p, const float *d_motion,
@@ -211,7 +215,16 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
  *   tau = t0 + float(i) * time_increment      (product rounded to float32, then the sum)
  * and the formulas of rplgpu_cloud_deskew_batch_dev apply unchanged.  NULL (the default) switches it
  * off: tau = float(i) * time_increment, bit for bit as before.  The buffer is the caller's and must
- * stay valid until the launches that use it have completed. */
+ * stay valid until the launches that use it have completed.
+ * DOMAIN: the sin / cos polynomials of E6 are stated for |a| = |wz * tau| <= 0.5 rad, and with an
+ * offset tau covers [t0, t0 + n * time_increment]: the caller must keep |wz| * max(|t0|, |t0 + n *
+ * time_increment|) <= 0.5 rad (a few scan periods of offset at a realistic yaw rate leave it: 1 rad/s
+ * and t0 = 0.6 s already do).  Nothing checks this — beyond the domain the rotation is still the
+ * degree-5 / -6 Taylor value (s short by 5.5e-6 at 0.6 rad, 2e-4 at 1 rad), and the oracle computes the same.
+ * NOT consulted by: rplgpu_cloud_arena_dev, rplgpu_cloud_arena_xyi_dev, rplgpu_cloud_batch_dev,
+ * rplgpu_scan_to_cloud[_msg] and the LaserScan entry points (no E6 there), nor by
+ * rplgpu_cloud_fused_voxel_dev when d_motion is NULL together with NULL offsets (with offsets set and
+ * d_motion NULL that call is refused: RPLGPU_ERR_INVALID_ARG). */
 int32_t rplgpu_set_scan_time_offsets_dev(rplgpu_handle_t h, const float *d_t0);
 /* The whole arena as ONE serialised PointCloud2 (the fused cloud of BASELINE config 5):
  * width = min(*d_total_points, arena_capacity) with d_total_points the arena cursor of

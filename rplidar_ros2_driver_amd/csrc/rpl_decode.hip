@@ -1831,8 +1831,19 @@ static hipError_t launch_decode_staged(hipStream_t s, int ans, const uint8_t *by
     {
       static std::mutex mu;
       static std::set<std::pair<const void *, int>> done_for;
-      int dev = 0;
-      (void)hipGetDevice(&dev);
+      // (the attribute lands on the CURRENT device: it must be the one the launch goes to — the
+      // stream's.  ADVICE r5: the result of hipGetDevice was ignored and a caller that had not made
+      // the handle's device current would have had the attribute recorded for the wrong device.)
+      int dev = -1;
+      if (const hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+      if (s) {
+        hipDevice_t sdev;
+        if (hipStreamGetDevice(s, &sdev) == hipSuccess) {
+          if ((int)sdev != dev) return hipErrorInvalidDevice;
+        } else {
+          (void)hipGetLastError();
+        }
+      }
       std::lock_guard<std::mutex> lk(mu);
       const auto key = std::make_pair(reinterpret_cast<const void *>(kfn), dev);
       if (!done_for.count(key)) {

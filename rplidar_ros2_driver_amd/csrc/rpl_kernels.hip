@@ -188,7 +188,7 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
                                            uint32_t *__restrict__ status,
                                            uint32_t *__restrict__ need_sort, uint32_t *s_keys,
                                            uint32_t *s_misc, SortLds &s_sort, uint32_t mark = 0u,
-                                           bool prefilled = false);
+                                           bool prefilled = false, uint32_t wrapped = 0u);
 
 // mark: a status bit the queueing kernels set on a scan they hand to the sorting kernel — a
 // single-scan call launches that kernel only when the bit came back (kAscendUnsorted, internal)
@@ -212,8 +212,10 @@ __global__ __launch_bounds__(kBlock) void k_ascend(uint2 *__restrict__ nodes, ui
       if (threadIdx.x == 0) need_sort[0] = 0u;
     }
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
-      ascend_one<SORT>(need_sort[1u + k], nodes, n_stride, n_per_scan, status, need_sort, s_keys,
-                       s_misc, s_sort, 0u, prefilled != 0u);
+      // (a list entry: scan index | wrapped fills at the scan's front << 24, see k_ascend_stream)
+      const uint32_t entry = need_sort[1u + k];
+      ascend_one<SORT>(entry & 0x00FFFFFFu, nodes, n_stride, n_per_scan, status, need_sort, s_keys,
+                       s_misc, s_sort, 0u, prefilled != 0u, entry >> 24);
       __syncthreads();  // LDS is reused by the next scan
     }
   } else {
@@ -227,7 +229,7 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
                                            uint32_t *__restrict__ status,
                                            uint32_t *__restrict__ need_sort, uint32_t *s_keys,
                                            uint32_t *s_misc, SortLds &s_sort, uint32_t mark,
-                                           bool prefilled) {
+                                           bool prefilled, uint32_t wrapped) {
   const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   uint2 *scan = nodes + (size_t)b * n_stride;
 
@@ -238,12 +240,17 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
     // writes the fills of a scan it queues, too) and nodes may have MOVED since (its local repair),
     // so an invalid node's index no longer says which angle it was given — the stored words are the
     // truth.  What is left of :171-181 is the sort; ties stay in the order they are in (the repair
-    // is a stable permutation, so that is still the input order).
+    // is a stable permutation, so that is still the input order) — except for the `wrapped` fills
+    // that kernel put at the scan's FRONT (:174-176: an angle near zero): they are the LAST nodes of
+    // the input, every other node sits `wrapped` places up, and a fill must rank behind a node of
+    // equal angle.  The key's tie field is therefore the place in the INPUT, not in the buffer.
+    wrapped = min(wrapped, n);
 #pragma unroll
     for (int j = 0; j < kIters; ++j) {
       const uint32_t i = sample_index(j);
-      if (i < n) s_keys[i] = (nd_q14(v[j]) << 16) | i;
+      if (i < n) s_keys[i] = (nd_q14(v[j]) << 16) | (i < wrapped ? n - wrapped + i : i - wrapped);
     }
+    // (sort_keys_to_positions leaves the final position of the node whose tie field is t in s_keys[t])
     __syncthreads();
     sort_keys_to_positions(s_keys, n, s_sort);
     load_scan(scan, n, v);
@@ -254,7 +261,7 @@ __device__ __forceinline__ void ascend_one(uint32_t b, uint2 *__restrict__ nodes
     for (int j = 0; j < kIters; ++j) {
       const uint32_t i = sample_index(j);
       if (i < n) {
-        const uint32_t pos = s_keys[i];
+        const uint32_t pos = s_keys[i < wrapped ? n - wrapped + i : i - wrapped];
         if (pos != i) scan[pos] = v[j];
       }
     }
@@ -650,11 +657,15 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
     const uint32_t my = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.y);
     if (need && pos < nm && (t & 31u) != col) scan[pos + W] = make_uint2(mx, my);
   }
-  // ---- the wrapped fills: to the front, in index order
+  // ---- the wrapped fills: to the front, in index order.  Nothing is stored before the workgroup's
+  // verdict: a scan that goes to the sorting kernel after all must reach it as "W fills in index
+  // order, then every other node W places up" — that kernel's tie rule counts on it (with
+  // the fills merged into the front, a fill ranked ahead of a node of equal angle and smaller index).
+  uint2 front_v = make_uint2(0u, 0u);  // what this thread puts at place threadIdx.x (W < 16: wave 0's window)
+  bool front_store = false;
   if (W >= 16u) {
     // The node behind them must be LARGER: with an equal word it would have to come first (ties keep
     // the input order, and it has the smaller index).
-    if (threadIdx.x < W) scan[threadIdx.x] = s_wrap[threadIdx.x];
     if (threadIdx.x == 0u && nd_q14(s_wrap[W - 1u]) >= s_edge[0]) bad |= 1u;
   } else if (W && wv == 0u) {
     // A few wrapped fills, whose angles may interleave with the first samples' (jitter): the first 16
@@ -684,16 +695,25 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
     const uint32_t pv = asc_dpp_mov<0x111>(0u, t);
     if (c16 < 16u) bad |= (pv > t) | (c16 == 15u && (t & 15u) != 15u);
     const uint32_t src = (t & 15u) * 4u;
-    const uint32_t mx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.x);
-    const uint32_t my = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.y);
-    if (inwin) scan[c16] = make_uint2(mx, my);
+    front_v.x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.x);
+    front_v.y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.y);
+    front_store = inwin;
   }
   // ---- boundaries that needed no repair are in order by construction of `need`; the rest was checked
   if (__builtin_amdgcn_ballot_w64(bad != 0u) && lane_id() == 0u) atomicOr(&s_misc[2], 1u);
   __syncthreads();
-  // still not ascending: queue the scan for the sorting kernel (need_sort[0] = count, then the list)
-  if (threadIdx.x == 0 && s_misc[2]) {
-    need_sort[1u + atomicAdd(&need_sort[0], 1u)] = b;
+  const bool unsorted = s_misc[2] != 0u;  // block-uniform
+  if (W) {
+    if (W >= 16u || unsorted) {
+      if (threadIdx.x < W) scan[threadIdx.x] = s_wrap[threadIdx.x];  // (the nodes behind them are W places up already)
+    } else if (front_store) {
+      scan[threadIdx.x] = front_v;  // (wave 0, lanes 0-15: the sorted window)
+    }
+  }
+  // still not ascending: queue the scan for the sorting kernel (need_sort[0] = count, then the list:
+  // scan index | wrapped fills at its front << 24)
+  if (threadIdx.x == 0 && unsorted) {
+    need_sort[1u + atomicAdd(&need_sort[0], 1u)] = b | (W << 24);
     if (mark && status) status[b] |= mark;
   }
 }

@@ -68,10 +68,15 @@ struct rplgpu_ctx {
   // k_cloud_voxel's queue statistics of the previous launch, copied to pinned memory behind every
   // launch (no synchronisation): they choose the kernel instance of the NEXT launch (voxel_split)
   unsigned long long *h_vstats = nullptr;
-  bool voxel_split = false;
   uint32_t stats_group = 1;           // scans per work item of the launch the statistics come from
   bool stats_valid = false;           // ... and which batch that launch was over (voxel_split_for)
   VoxelBatchId stats_id;
+  // the decision per batch identity, for the last few identities (a caller that alternates two staging
+  // buffers, or launches a batch in chunks — rplgpu's own exchange pipeline does — has several alive)
+  struct VoxelDecision { VoxelBatchId id; bool split = false; bool valid = false; };
+  VoxelDecision decisions[8];
+  uint32_t next_decision = 0;
+  int32_t last_split = 0;             // the instance the last batch launch took (rplgpu_debug_voxel_instance)
   uint32_t n_cu = 0;                  // compute units of `device`
   void *d_vstore = nullptr;           // k_cloud_voxel record stores (one per resident workgroup)
   int32_t force_split = -1;           // RPLGPU_VOXEL_SPLIT: -1 follow the statistics, 0 / 1 forced
@@ -197,29 +202,48 @@ rpl::KParams to_kparams(const rplgpu_params_t &p) {
 // group size) left in pinned memory behind it (read here without waiting: a stale or torn value
 // only picks the other instance once — the results are the same either way).  A batch the handle
 // has not launched before — another buffer or another shape — runs the plain instance; what an
-// unrelated earlier batch looked like decides nothing (round 4: it did).
+// unrelated earlier batch looked like decides nothing (round 4: it did).  Round 6: the
+// decision is kept per batch identity for the last eight identities, so that a caller alternating two
+// staging buffers, or launching a batch in chunks (CloudExchange.step does), converges as well — the
+// statistics always describe the previous launch and update THAT batch's entry.
 bool voxel_split_for(rplgpu_ctx *c, const void *d_nodes, uint32_t n_stride, uint32_t B, uint32_t group) {
   group = std::max(1u, std::min(group, std::max(B, 1u)));
   const VoxelBatchId id{d_nodes, n_stride, B, group};
   const bool with_stats = c->h_vstats && (B + group - 1u) / group >= 64u;  // (launch_cloud_voxel's rule)
-  bool split = false;
-  if (c->h_vstats && c->stats_valid && c->stats_id == id) {
+  auto find = [&](const VoxelBatchId &k) -> rplgpu_ctx::VoxelDecision * {
+    for (auto &d : c->decisions)
+      if (d.valid && d.id == k) return &d;
+    return nullptr;
+  };
+  // the statistics in pinned memory describe the handle's PREVIOUS launch with statistics: they
+  // update that batch's decision, whichever batch is launched now
+  if (c->h_vstats && c->stats_valid) {
     const unsigned long long entries = __atomic_load_n(&c->h_vstats[0], __ATOMIC_RELAXED);
     const unsigned long long items = __atomic_load_n(&c->h_vstats[1], __ATOMIC_RELAXED);
-    split = c->voxel_split;
-    if (items != 0 && entries <= items * group * 70000ull) {  // (sanity: a torn or stale pair)
-      const unsigned long long avg = entries / (items * group);  // per scan, not per work item
-      if (!split && avg > 6500ull) split = true;        // (a clean C3 scan: ~3300)
-      else if (split && avg < 4000ull) split = false;   // (1 cm noise, two classes: ~6200)
+    const uint32_t g = c->stats_group;
+    if (items != 0 && entries <= items * g * 70000ull) {  // (sanity: a torn or stale pair)
+      rplgpu_ctx::VoxelDecision *d = find(c->stats_id);
+      if (!d) {
+        d = &c->decisions[c->next_decision];
+        c->next_decision = (c->next_decision + 1u) % (uint32_t)(sizeof(c->decisions) / sizeof(c->decisions[0]));
+        d->id = c->stats_id;
+        d->split = false;
+        d->valid = true;
+      }
+      const unsigned long long avg = entries / (items * g);  // per scan, not per work item
+      if (!d->split && avg > 6500ull) d->split = true;        // (a clean C3 scan: ~3300)
+      else if (d->split && avg < 4000ull) d->split = false;   // (1 cm noise, two classes: ~6200)
     }
   }
+  const rplgpu_ctx::VoxelDecision *mine = find(id);
+  const bool split = mine ? mine->split : false;
   if (with_stats) {  // this launch's statistics will describe `id`
     c->stats_id = id;
     c->stats_valid = true;
-    c->voxel_split = split;
     c->stats_group = group;
   }
-  return c->force_split >= 0 ? c->force_split != 0 : split;
+  c->last_split = (c->force_split >= 0 ? c->force_split != 0 : split) ? 1 : 0;
+  return c->last_split != 0;
 }
 
 rpl::Tables tables_of(rplgpu_ctx *c) {
@@ -512,8 +536,9 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
                       rplgpu_handle_t *out) {
   if (!out) return RPLGPU_ERR_INVALID_ARG;
   *out = nullptr;
+  // (max_batch < 2^24: the ascend kernels' list of scans to sort packs a scan index into 24 bits)
   if (max_samples_per_scan == 0 || max_samples_per_scan > RPLGPU_MAX_SAMPLES_PER_SCAN ||
-      max_batch == 0)
+      max_batch == 0 || max_batch >= (1u << 24))
     return RPLGPU_ERR_INVALID_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RPLGPU_ERR_NO_DEVICE;
@@ -683,6 +708,9 @@ int32_t rplgpu_debug_ascend_sorted(rplgpu_handle_t h, uint32_t *count) {
   RPL_HIP(h, hipMemcpy(count, h->d_small + 28, 4, hipMemcpyDeviceToHost));
   return RPLGPU_OK;
 }
+// Developer aid (tests): the block-aggregation instance the handle's last voxel batch launch took
+// (0 plain, 1 two-class) — what RPLGPU_VOXEL_AGG_AUTO decided for it.
+int32_t rplgpu_debug_voxel_instance(rplgpu_handle_t h) { return h ? h->last_split : RPLGPU_ERR_INVALID_ARG; }
 int32_t rplgpu_debug_fast_div(rplgpu_handle_t h) {
   if (!h) return RPLGPU_ERR_INVALID_ARG;
   return (h->div4000_ok ? 1 : 0) | (h->leaf_ok ? 2 : 0) | (h->idx_ok ? 4 : 0);

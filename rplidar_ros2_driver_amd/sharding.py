@@ -210,14 +210,18 @@ def launch_rel(scans: float) -> float:
 
 
 def predicted_step_ms(world: int, compute_ms_one_gpu: float, cloud_bytes_total: float, chunks: int,
-                      gather_root: bool = False, link_gbs: float = 76.8, scans_total: int = 4096) -> float:
+                      link_gbs: float = 76.8, scans_total: int = 4096) -> float:
     """DESIGN.md section 7's model of a step on `world` GPUs (strong scaling of one batch of `scans_total`
     scans): every rank computes 1/world of the batch in `chunks` launches — a launch priced with the measured
     launch-time curve, scaled to `compute_ms_one_gpu` (the whole batch in one launch on one GPU) — a piece's
     exchange starts when the piece is computed and pieces follow one another on the links.  All-gather: a link
-    carries one rank's share of a piece (the links of a rank work in parallel); gather to root: the root's links
-    carry the same (one slot each) but nothing else moves.  Every piece also pays the exchange's fixed cost.
-    Returns milliseconds."""
+    carries one rank's share of a piece (the links of a rank work in parallel).  Gather to root is priced THE
+    SAME (the model used to take a `gather_root` flag and ignore it): the step is the slowest rank's,
+    that is the root's — its world - 1 inbound slots arrive on world - 1 different links, one slot per link
+    like the all-gather's, and it runs the same unpack; what the gather saves (no inbound traffic, no unpack on
+    the other ranks, 1/world of the HBM writes) is not on the step's critical path.  Whether the grouped
+    send / receive costs more or less per piece than ncclAllGather is not known: no run with two ranks has
+    ever been made.  Every piece also pays the exchange's fixed cost.  Returns milliseconds."""
     if world <= 1:
         return compute_ms_one_gpu
     comp = compute_ms_one_gpu * launch_rel(scans_total / world / chunks) / launch_rel(scans_total)
@@ -230,7 +234,7 @@ def predicted_step_ms(world: int, compute_ms_one_gpu: float, cloud_bytes_total: 
 
 
 def best_chunks(world: int, compute_ms_one_gpu: float, cloud_bytes_total: float, scans_total: int,
-                gather_root: bool = False, candidates=(1, 2, 4, 8)) -> int:
+                candidates=(1, 2, 4, 8)) -> int:
     """The chunk count the model prefers (ties: fewer chunks).  One rank: one chunk — there is nothing to hide."""
     if world <= 1:
         return 1
@@ -238,7 +242,7 @@ def best_chunks(world: int, compute_ms_one_gpu: float, cloud_bytes_total: float,
     for c in candidates:
         if c > max(scans_total // world, 1):
             break
-        ms = predicted_step_ms(world, compute_ms_one_gpu, cloud_bytes_total, c, gather_root, scans_total=scans_total)
+        ms = predicted_step_ms(world, compute_ms_one_gpu, cloud_bytes_total, c, scans_total=scans_total)
         if ms < best_ms * 0.995:
             best, best_ms = c, ms
     return best

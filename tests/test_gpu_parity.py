@@ -953,6 +953,87 @@ def test_ascend_wrap_zone(gpu, oracle):
         assert moved_front >= 5  # the cases really exercise the wrap
 
 
+def _filled_words(src):
+    """The angle word ascendScanData gives every node BEFORE it sorts (src/sdk/src/sl_lidar_driver.cpp:
+    171-178), for scans whose node 0 is valid (no head chain): float32 operations one by one, as the SDK."""
+    n = len(src)
+    f32 = np.float32
+    assert src["dist_mm_q2"][0] != 0
+    inc = f32(360.0) / f32(n)
+    front = f32(src["angle_z_q14"][0]) * f32(90.0) / f32(16384.0)
+    i = np.arange(n, dtype=np.float32)
+    e = front + i * inc
+    e = np.where(e > f32(360.0), e - f32(360.0), e).astype(np.float32)
+    q = ((e * f32(16384.0) / f32(90.0)).astype(np.uint32) & 0xFFFF).astype(np.uint16)
+    return np.where(src["dist_mm_q2"] == 0, q, src["angle_z_q14"])
+
+
+def test_ascend_tie_rule_with_wrapped_fills(gpu, oracle):
+    """This library's tie rule — nodes of equal angle word keep their INPUT order — where it is hardest
+    to keep: wrapped fills (the last nodes of the input, moved to the front of the result)
+    against nodes of equal word and smaller index, in the shapes that end in the sorting kernel: sixteen
+    or more wrapped fills whose last word equals the first node's, and a few wrapped fills in a scan
+    that is out of order somewhere else.  Expected = the input with its filled words, sorted stably."""
+    torch = _torch()
+    n = 32000
+    cases = []
+    # (k wrapped fills; the scan's angle offset q0 keeps the wrap zone — q0 / 2.05 indices — within the 64 the
+    # streaming kernel handles itself; far: disorder elsewhere)
+    for k, q0, far in ((16, 40, False), (40, 100, False), (60, 128, False), (3, 20, True), (12, 40, True),
+                       (20, 50, True), (1, 10, True)):
+        scan = synth.make_scan(4321 + k, 0, n, invalid_p=0.05)
+        scan["angle_z_q14"] = np.minimum(scan["angle_z_q14"].astype(np.uint32) + q0, 65535).astype(np.uint16)
+        scan["dist_mm_q2"][0] = 4000
+        scan["dist_mm_q2"][n - k - 8: n - k] = 5000  # (valid nodes in front of the zone)
+        scan["dist_mm_q2"][n - k:] = 0
+        w = _filled_words(scan)
+        # a valid node at the scan's front gets the word of the LAST wrapped fill: a tie with the smaller index
+        # (node 0 itself cannot: the fills are interpolated from its angle and always come out below it)
+        scan["dist_mm_q2"][1] = 4400
+        scan["angle_z_q14"][1] = w[n - 1]
+        assert np.array_equal(_filled_words(scan)[n - k:], w[n - k:]) and w[n - 1] < q0  # it did wrap
+        w = _filled_words(scan)
+        zone = np.flatnonzero((w < q0) & (np.arange(n) > n // 2))  # indices whose interpolated angle wrapped
+        assert zone.min() >= n - 64 and np.all(scan["dist_mm_q2"][zone.min(): n - k] != 0)  # the fills ARE the zone's invalid nodes
+        if far:  # disorder no local repair reaches: the scan goes to the sorting kernel whatever the front does
+            a, b = 9000, 9400
+            scan["dist_mm_q2"][[a, b]] = 6000
+            scan["angle_z_q14"][[a, b]] = scan["angle_z_q14"][[b, a]]
+            # ... and one of the nodes in there carries a wrapped fill's word: the same tie, far from the front
+            scan["angle_z_q14"][a + 5] = w[n - 1 - (k // 2)]
+            scan["dist_mm_q2"][a + 5] = 7000
+        cases.append(scan)
+    cases = cases + cases  # (more than eight scans: batches of up to eight long scans take k_ascend<false>,
+    B = len(cases)         #  not the streaming kernel this test is about)
+    assert B > 8
+    batch = np.stack(cases)
+    dev = torch.device("cuda:0")
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8).copy()).to(dev)
+    d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    gpu.ascend_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, d_st.data_ptr())
+    gpu.synchronize()
+    asc = d_nodes.cpu().numpy().view(NODE_DTYPE).reshape(B, n)
+    assert np.all(d_st.cpu().numpy() == 0)
+    for b in range(B):
+        src = batch[b]
+        want, res = oracle.ascend(src)
+        assert res == 0
+        filled = src.copy()
+        filled["angle_z_q14"] = _filled_words(src)
+        assert np.array_equal(np.sort(filled["angle_z_q14"]), want["angle_z_q14"]), b  # (the emulation is the SDK's)
+        expect = filled[np.argsort(filled["angle_z_q14"], kind="stable")]
+        assert asc[b].tobytes() == expect.tobytes(), b
+        assert oracle_lib.canon_equal_angle_runs(asc[b]).tobytes() == \
+            oracle_lib.canon_equal_angle_runs(want).tobytes(), b
+    # the single-scan seam takes the same kernels
+    one = batch[1].copy()
+    assert gpu.ascend(one) == 0
+    f = batch[1].copy()
+    f["angle_z_q14"] = _filled_words(batch[1])
+    assert one.tobytes() == f[np.argsort(f["angle_z_q14"], kind="stable")].tobytes()
+
+
 # ------------------------------------------------------------- the plain cloud of a batch (E1 + E2)
 def test_plain_cloud_batch(gpu, oracle):
     """The unvoxelised cloud of a batch (k_cloud) against the oracle, bit for bit: ragged lengths

@@ -386,3 +386,60 @@ def test_bench_batches_laserscan_matches_oracle(gpu, oracle, bench_regime):
     check(p, "one_pass_with_nodes")
     got = d_nodes.cpu().numpy().view(synth.NODE_DTYPE).reshape(B, n)
     _assert_ascend(oracle, batch, got, lens, (regime, "one_pass_with_nodes"))
+
+
+def test_voxel_aggregation_auto_converges_per_batch(gpu, oracle):
+    """RPLGPU_VOXEL_AGG_AUTO picks the block-aggregation instance of a batch from THAT batch's own
+    queue statistics (its previous launch).  ADVICE r5: with one remembered batch identity a caller
+    that alternates two staging buffers, or launches a batch in chunks (the exchange pipeline does),
+    never matched and stayed on the plain instance for noisy data.  Decisions are now kept for the last
+    eight identities: a noisy and a clean batch launched alternately each settle on their own instance
+    from the second launch on, and so do the two halves of a noisy batch launched as chunks."""
+    import torch
+    from rplidar_ros2_driver_amd import abi
+    lib = abi.load_library()
+    lib.rplgpu_debug_voxel_instance.argtypes = [C.c_void_p]
+    dev = torch.device("cuda:0")
+    B, n = 256, 32000
+    noisy = synth.make_batch(2026, B, n, noise_m=0.01)
+    clean = synth.make_batch(2026, B, n)
+    p = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1, voxel_leaf=0.05)
+    d = {k: torch.from_numpy(v.view(np.uint8).reshape(B, n * 8)).to(dev) for k, v in (("noisy", noisy), ("clean", clean))}
+    d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
+    cap = B * n
+    d_arena = torch.empty(cap, 4, dtype=torch.float32, device=dev)
+    d_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_start = torch.zeros(B, dtype=torch.int64, device=dev)
+    d_np = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    gpu.set_voxel_aggregation(0)
+
+    def launch(buf, lo, cnt):
+        gpu.cloud_arena_dev(buf.data_ptr() + lo * n * 8, n, d_len.data_ptr(), cnt, p, d_arena.data_ptr(), cap,
+                            d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+        inst = lib.rplgpu_debug_voxel_instance(gpu._h)
+        gpu.synchronize()  # (the statistics of this launch are in pinned memory before the next decision)
+        assert int(d_st.max()) == 0
+        return inst, int(d_cur.item())
+
+    seen = {"noisy": [], "clean": []}
+    cells = {"noisy": set(), "clean": set()}
+    for rnd in range(4):
+        for k in ("noisy", "clean"):
+            inst, total = launch(d[k], 0, B)
+            seen[k].append(inst)
+            cells[k].add(total)
+    assert seen["noisy"] == [0, 1, 1, 1], seen
+    assert seen["clean"] == [0, 0, 0, 0], seen
+    assert len(cells["noisy"]) == 1 and len(cells["clean"]) == 1  # either instance makes the same cloud
+    # a noisy batch in two chunks (two identities), three steps
+    halves = []
+    for step in range(3):
+        halves.append([launch(d["noisy"], lo, B // 2)[0] for lo in (0, B // 2)])
+    assert halves == [[0, 0], [1, 1], [1, 1]], halves
+    # the whole cloud against the oracle once, in the instance AUTO settled on
+    launch(d["noisy"], 0, B)
+    arena, start, npts = d_arena.cpu().numpy(), d_start.cpu().numpy(), d_np.cpu().numpy().astype(np.int64)
+    bad, res = oracle.batch_cloud_check(noisy, oracle_lib.copy_params(p), arena, start, npts, None, os.cpu_count() or 1)
+    assert bad == 0
+    assert float(res[:, 3].copy().view(np.float32).max()) <= XYZ_TOL
