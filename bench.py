@@ -786,8 +786,12 @@ def main():
                                "scan that fails the final order check goes to the sorting kernel"),
                 ("jitter10", 10, "jitter +-10: samples up to ~10 places from their sorted position, 89 % of "
                                  "the nodes rewritten; still repaired in the streaming pass"),
-                ("jitter20", 20, "jitter +-20: disorder reaches past the repair windows in part of the scans, "
-                                 "which take the sorting kernel (k_ascend<true>) on top")):
+                ("jitter20", 20, "jitter +-20: disorder reaches past the 32-sample repair windows in part of the scans; "
+                                 "round 6: those boundaries are repaired by merging the two sorted 128-sample chunks "
+                                 "(phase C), nothing goes to the sorting kernel any more"),
+                ("jitter64", 64, "jitter +-64 (round 6): nodes up to ~40 places from home; every chunk needs dozens of "
+                                 "odd-even rounds and every boundary a merge, still one launch of the streaming kernel "
+                                 "(round 5: every scan through the one-workgroup sort, 2.6 ms)")):
             vb = synth.make_batch(args.seed + 11, Bv, n, jitter=jit)
             d_v = torch.from_numpy(vb.view(np.uint8).reshape(Bv, n * 8)).to(dev)
             d_w = d_v.clone()

@@ -406,7 +406,7 @@ typedef uint32_t asc_u32x4 __attribute__((ext_vector_type(4)));
 // window to the sorted chunks around it).  A scan that fails a check — disorder reaching farther than
 // the rounds — is queued for k_ascend<true> as before, which then trusts the stored angle words
 // (`prefilled`).  Ties keep their input order, the library's tie rule (tests/canon.py).
-constexpr int kAscRounds = 16;   // phase A: at most this many (inside the lane, across lanes) rounds
+constexpr int kAscRounds = 128;  // phase A: at most this many (inside the lane, across lanes) rounds: sorts any chunk
 constexpr int kAscRoundsB = 16;  // phase B: at most this many pairs of (even, odd) rounds on 32 samples
 
 template <int CTRL>
@@ -414,7 +414,9 @@ __device__ __forceinline__ uint32_t asc_dpp_mov(uint32_t old, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, 0xF, false);
 }
 
-__global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nodes, uint32_t n_stride,
+// (eight waves per SIMD = 64 registers: the streaming pass is paced by the loads it keeps in flight;
+// round 6's merges would otherwise take 82 registers and the occupancy down to five)
+__global__ __launch_bounds__(kAscT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ascend_stream(uint2 *__restrict__ nodes, uint32_t n_stride,
                                                          const uint32_t *__restrict__ n_per_scan,
                                                          uint32_t *__restrict__ status,
                                                          uint32_t *__restrict__ need_sort, uint32_t mark) {
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
   __shared__ uint32_t s_edge[2 * (kMaxN / 128)];  // first / last angle word of every 128-sample chunk
   __shared__ uint4 s_xch[kAscW][64];              // phase A: the nodes of a chunk, by slot (wave-private)
   __shared__ uint2 s_wrap[64];                    // the wrapped fills at the scan's end (they go to its front)
+  __shared__ uint32_t s_tok[kAscW][256];          // phase C: the tokens of a pair of chunks (wave-private)
   const uint32_t b = blockIdx.x;
   const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane(
       (int)min(n_per_scan[b], min(n_stride, kMaxN)));  // never past the slot
@@ -564,11 +567,12 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
       if (__builtin_amdgcn_ballot_w64((qa > qc) | (qc > nxt_q))) {  // wave-uniform: local repair
         uint32_t ta = (qa << 8) | (2u * lane_id()), tc = (qc << 8) | (2u * lane_id() + 1u);
         // rounds in pairs until the chunk is in order (wave-uniform exit: +-3 words of jitter need
-        // two or three pairs) or kAscRounds are spent (then the checks below send the scan on)
-        // (The chunk that holds the wrapped fills is sorted to the end whatever it takes — 128 rounds
-        // sort any 128 tokens: a fill left in front of a node that stays would be stored in its place.)
-        const int max_rounds = (W && (pair >> 6) == ((n - 1u) >> 7)) ? 128 : kAscRounds;
-        for (int r = 0; r < max_rounds; r += 2) {
+        // two or three pairs; 128 rounds sort any 128 tokens — round 6: every chunk leaves this phase
+        // SORTED, which is what the merges of phase C build on; and a wrapped fill left in front of a
+        // node that stays would be stored in its place).  (Also built: a 28-stage bitonic network for
+        // chunks the first 16 rounds do not finish — four inlined copies of it cost the uniform case
+        // 14 % and +-64 words 14 %: profiles/r06/ascend_merge_r06.txt.)
+        for (int r = 0; r < kAscRounds; r += 2) {
 #pragma unroll
           for (int rr = 0; rr < 2; ++rr) {
             const uint32_t lo = min(ta, tc), hi = max(ta, tc);
@@ -623,6 +627,7 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
   // ---- phase B: chunk boundaries whose two sides are out of order
   const uint32_t nchunks = (npairs + 63u) >> 6;
   const uint32_t half = lane_id() >> 5, col = lane_id() & 31u;  // two 32-sample windows per wave
+  uint32_t win_failed = 0u;  // a window of this lane's could not repair its boundary
   for (uint32_t base = 1u; base < nchunks; base += (uint32_t)kAscT / 32u) {
     const uint32_t kb = base + wv * 2u + half;  // the boundary between chunk kb - 1 and chunk kb
     const bool need = kb < nchunks && s_edge[2u * kb - 1u] > s_edge[2u * kb];
@@ -648,66 +653,114 @@ __global__ __launch_bounds__(kAscT) void k_ascend_stream(uint2 *__restrict__ nod
       const uint32_t pv = asc_dpp_mov<0x138>(0u, t);
       if (!__builtin_amdgcn_ballot_w64(col != 0u && pv > t)) break;  // wave-uniform: both windows ascend
     }
-    // checks: the window ascends, its end samples did not move
+    // checks: the window ascends, its end samples did not move.  A window that fails (disorder that
+    // reaches farther than 16 places) is NOT stored: both chunks stay sorted, their edges stay out of
+    // order, and phase C merges the two chunks.
     const uint32_t pv = asc_dpp_mov<0x138>(0u, t);
-    bad |= need & ((col != 0u && pv > t) | ((col == 0u || col == 31u) && (t & 31u) != col));
+    const bool viol = need & ((col != 0u && pv > t) | ((col == 0u || col == 31u) && (t & 31u) != col));
+    const uint64_t vm = __builtin_amdgcn_ballot_w64(viol);
+    const bool win_ok = ((vm >> (lane_id() & 32u)) & 0xFFFFFFFFull) == 0ull;  // (this half-wave's window)
     // the nodes follow: source lane = same window, column = the token's low bits
     const uint32_t src = ((lane_id() & 32u) | (t & 31u)) * 4u;
     const uint32_t mx = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.x);
     const uint32_t my = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.y);
-    if (need && pos < nm && (t & 31u) != col) scan[pos + W] = make_uint2(mx, my);
+    if (need && win_ok) {
+      if (pos < nm && (t & 31u) != col) scan[pos + W] = make_uint2(mx, my);
+      if (col == 15u) s_edge[2u * kb - 1u] = t >> 8;  // the chunks' new edge words
+      if (col == 16u) s_edge[2u * kb] = t >> 8;
+    }
+    win_failed |= need && !win_ok;
   }
-  // ---- the wrapped fills: to the front, in index order.  Nothing is stored before the workgroup's
-  // verdict: a scan that goes to the sorting kernel after all must reach it as "W fills in index
-  // order, then every other node W places up" — that kernel's tie rule counts on it (with
-  // the fills merged into the front, a fill ranked ahead of a node of equal angle and smaller index).
-  uint2 front_v = make_uint2(0u, 0u);  // what this thread puts at place threadIdx.x (W < 16: wave 0's window)
-  bool front_store = false;
-  if (W >= 16u) {
-    // The node behind them must be LARGER: with an equal word it would have to come first (ties keep
-    // the input order, and it has the smaller index).
-    if (threadIdx.x == 0u && nd_q14(s_wrap[W - 1u]) >= s_edge[0]) bad |= 1u;
-  } else if (W && wv == 0u) {
-    // A few wrapped fills, whose angles may interleave with the first samples' (jitter): the first 16
-    // places of the result — the W fills, then the nodes that lead the rest — are one more window of
-    // the phase-B kind (wave 0, row 0).  A token's tie-break field puts a wrapped fill behind a node
-    // of equal angle (its index is the larger one); only the window's last place is an anchor.
-    const uint32_t c16 = lane_id();  // (rows 1-3 work on copies of nothing and store nothing)
-    const bool inwin = c16 < 16u && c16 < n;
-    uint2 v = make_uint2(0u, 0u);
-    if (inwin) v = c16 < W ? s_wrap[c16] : scan[c16];
-    const uint32_t tie = c16 < W ? 16u + c16 : c16 - W;
-    uint32_t t = ((inwin ? nd_q14(v) : 0x10000u) << 10) | ((tie & 31u) << 5) | (c16 & 15u);
-    const bool odd = (c16 & 1u) != 0u;
+  // ---- phase C (round 6): chunk boundaries that are still out of order — disorder beyond the
+  // windows' 16 places — are repaired by MERGING the two sorted chunks: odd boundaries first (pairs
+  // (0,1) (2,3) ...), then even ones ((1,2) (3,4) ...).  Two such passes sort anything whose
+  // nodes are at most 128 places from where they belong (every chunk is sorted when it gets here);
+  // only what is still out of order afterwards goes to the one-workgroup sorting kernel.  A wave
+  // merges two sorted runs A, B of up to 128 nodes that follow each other in the buffer: 256 tokens
+  // (angle word << 8 | tie field: unique) in LDS, every node's new place = its place in its own run +
+  // the number of smaller tokens in the other (a binary search), nodes stored where they moved.
+  // Tie field: A's nodes before B's (the input order of two chunks) — or behind them, for the
+  // wrapped fills (run A, at the scan's front), which are the LAST nodes of the input.
+  // (the barrier that publishes phase B's stores and edge words also tells every wave whether any
+  // boundary is left: a boundary phase B did not look at was in order, one it repaired is now)
+  const bool boundaries_left = __syncthreads_or((int)win_failed) != 0;
+  auto merge_runs = [&](uint32_t a0, uint32_t la, uint32_t lb, bool a_last, uint32_t edge0) {
+    // wave-uniform arguments; a0: A's first place in the buffer; edge0: s_edge index of A's first word
+    // (chunk merges only: la == 128) or 0xFFFFFFFF
+    const uint32_t e0 = 4u * lane_id();  // tokens e0 .. e0 + 3: run A in the slots 0-127, run B in 128-255
+    uint2 v[4];
+    uint32_t t[4];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {  // 16 samples: eight pairs of (even, odd) rounds sort anything
-      {
-        const uint32_t nx = asc_dpp_mov<0x101>(t, t);
-        const uint32_t pv = asc_dpp_mov<0x111>(t, t);
-        t = odd ? max(t, pv) : min(t, nx);
-      }
-      {
-        const uint32_t nx = asc_dpp_mov<0x101>(t, t);
-        const uint32_t pv = asc_dpp_mov<0x111>(t, t);
-        t = odd ? min(t, nx) : max(t, pv);
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t e = e0 + (uint32_t)r, k = e & 127u;
+      const bool in_a = e < 128u, live = in_a ? k < la : k < lb;
+      v[r] = live ? scan[a0 + (in_a ? k : la + k)] : make_uint2(0u, 0u);
+      const uint32_t tie = (in_a != a_last) ? k : 128u + k;
+      t[r] = ((live ? nd_q14(v[r]) : 0x10000u) << 8) | tie;  // (an empty slot: behind everything)
+    }
+    uint32_t *tok = s_tok[wv];
+    *reinterpret_cast<uint4 *>(&tok[e0]) = make_uint4(t[0], t[1], t[2], t[3]);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const uint32_t other = lane_id() < 32u ? 128u : 0u;  // the other run's tokens
+    uint32_t place[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint32_t c = 0u;  // tokens of the other run below mine
+#pragma unroll
+      for (uint32_t st = 64u; st >= 1u; st >>= 1) c += tok[other + c + st - 1u] < t[r] ? st : 0u;
+      c += tok[other + c] < t[r] ? 1u : 0u;  // (c <= 127 here)
+      place[r] = ((e0 + (uint32_t)r) & 127u) + c;  // place in the merged run
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (read before the next merge's tokens overwrite them)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t e = e0 + (uint32_t)r, k = e & 127u;
+      const bool in_a = e < 128u, live = in_a ? k < la : k < lb;
+      if (live) {
+        if (place[r] != (in_a ? k : la + k)) scan[a0 + place[r]] = v[r];
+        if (edge0 != 0xFFFFFFFFu) {  // the two chunks' new edge words
+          const uint32_t word = t[r] >> 8;
+          if (place[r] == 0u) s_edge[edge0] = word;
+          if (place[r] == 127u) s_edge[edge0 + 1u] = word;
+          if (place[r] == 128u) s_edge[edge0 + 2u] = word;
+          if (place[r] == 255u) s_edge[edge0 + 3u] = word;
+        }
       }
     }
-    const uint32_t pv = asc_dpp_mov<0x111>(0u, t);
-    if (c16 < 16u) bad |= (pv > t) | (c16 == 15u && (t & 15u) != 15u);
-    const uint32_t src = (t & 15u) * 4u;
-    front_v.x = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.x);
-    front_v.y = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)v.y);
-    front_store = inwin;
+  };
+  auto boundaries_bad = [&]() -> bool {  // block-uniform: some chunk boundary is out of order (one barrier)
+    uint32_t any = 0u;
+    for (uint32_t kb = 1u + threadIdx.x; kb < nchunks; kb += (uint32_t)kAscT)
+      any |= s_edge[2u * kb - 1u] > s_edge[2u * kb];
+    return __syncthreads_or((int)any) != 0;
+  };
+  if (boundaries_left) {
+    for (uint32_t first_kb = 1u; first_kb <= 2u; ++first_kb) {  // odd boundaries, then even ones
+      for (uint32_t kb = first_kb + 2u * wv; kb < nchunks; kb += 2u * (uint32_t)kAscW)
+        if (s_edge[2u * kb - 1u] > s_edge[2u * kb])  // wave-uniform
+          merge_runs(W + 128u * (kb - 1u), 128u, min(128u, nm - 128u * kb), false, 2u * kb - 2u);
+      __syncthreads();  // (the merged nodes and edge words, before the other parity reads them)
+    }
+    if (boundaries_bad()) bad |= 1u;
   }
-  // ---- boundaries that needed no repair are in order by construction of `need`; the rest was checked
+  // ---- the wrapped fills: to the front, in index order (their angles ascend).  Nothing is stored
+  // before the workgroup's verdict: a scan that goes to the sorting kernel after all must reach it as
+  // "W fills in index order, then every other node W places up" — that kernel's tie rule counts on it
+  // (ADVICE r5).  A fill belongs behind every node of smaller OR EQUAL word (ties keep the input
+  // order and the fills are the input's last nodes): when the nodes at the scan's front reach that
+  // far — jittered angles — the fills and the first chunk are one more merge.  It must not carry a
+  // fill past the first chunk: then the scan is the sorting kernel's.
+  if (W && nchunks > 1u && threadIdx.x == 0u && nd_q14(s_wrap[W - 1u]) >= s_edge[2]) bad |= 1u;
   if (__builtin_amdgcn_ballot_w64(bad != 0u) && lane_id() == 0u) atomicOr(&s_misc[2], 1u);
   __syncthreads();
   const bool unsorted = s_misc[2] != 0u;  // block-uniform
   if (W) {
-    if (W >= 16u || unsorted) {
-      if (threadIdx.x < W) scan[threadIdx.x] = s_wrap[threadIdx.x];  // (the nodes behind them are W places up already)
-    } else if (front_store) {
-      scan[threadIdx.x] = front_v;  // (wave 0, lanes 0-15: the sorted window)
+    if (threadIdx.x < W) scan[threadIdx.x] = s_wrap[threadIdx.x];  // (the nodes behind them are W places up already)
+    if (!unsorted && nd_q14(s_wrap[W - 1u]) >= s_edge[0]) {  // block-uniform
+      __syncthreads();  // (the fills are in the buffer)
+      if (wv == 0u) merge_runs(0u, W, min(128u, nm), true, 0xFFFFFFFFu);
     }
   }
   // still not ascending: queue the scan for the sorting kernel (need_sort[0] = count, then the list:

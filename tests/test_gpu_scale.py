@@ -253,14 +253,14 @@ def test_runs_across_dropped_lanes_patterns(gpu_mode, oracle):
 # --------------------------------------------------------------------------------------------
 # The PINNED rows at the bench scale (missing #2): every scan of the batches that
 # bench.py's `reference_path_gpu` times — the headline batch (seed 2026, exactly uniform angle words)
-# and the jitter regimes (seed 2026 + 11, +-1 / 3 / 10 / 20 words) — through the batch entry points of
+# and the jitter regimes (seed 2026 + 11, +-1 / 3 / 10 / 20 / 64 / 300 words) — through the batch entry points of
 # ascendScanData (src/sdk/src/sl_lidar_driver.cpp:128-184) and publish_scan
 # (src/rplidar_node.cpp:583-680), compared scan by scan with the oracle on all host cores
 # (oracle/oracle.cpp orc_batch_ascend_check / orc_batch_laserscan_check; the oracle itself is pinned
 # to the reference compiled here, tests/test_oracle_golden.py).
 # --------------------------------------------------------------------------------------------
 _BENCH_REGIMES = {"uniform_angles": (2026, 0), "jitter1": (2037, 1), "jitter3": (2037, 3),
-                  "jitter10": (2037, 10), "jitter20": (2037, 20)}
+                  "jitter10": (2037, 10), "jitter20": (2037, 20), "jitter64": (2037, 64), "jitter300": (2037, 300)}
 
 
 @pytest.fixture(scope="module", params=list(_BENCH_REGIMES))
@@ -290,8 +290,9 @@ def _assert_ascend(oracle, src, got, lens, tag):
 def test_bench_batches_ascend_matches_oracle(gpu, oracle, bench_regime):
     """rplgpu_ascend_batch_dev over all 4096 scans of a bench regime: the oracle's angle words at
     every position, the oracle's nodes after canonicalising equal-angle runs, the valid nodes in
-    stable order (this library's tie rule), the slot tails untouched, status 0; at +-20 words some
-    scans must have taken the sorting kernel (k_ascend<true>) — the configuration bench.py times."""
+    stable order (this library's tie rule), the slot tails untouched, status 0 — in the configuration
+    bench.py times; +-64 words exercises the chunk merges of round 6 on every boundary, +-300 words the
+    sorting kernel (k_ascend<true>) on (nearly) every scan."""
     import torch
     dev = torch.device("cuda:0")
     regime, batch = bench_regime
@@ -307,10 +308,12 @@ def test_bench_batches_ascend_matches_oracle(gpu, oracle, bench_regime):
     got = d_nodes.cpu().numpy().view(synth.NODE_DTYPE).reshape(B, n)
     res = _assert_ascend(oracle, batch, got, lens, regime)
     assert not res[:, 0].any()  # every scan has valid samples: SL_RESULT_OK
-    if regime == "jitter20":
-        assert 0 < nsorted < B, nsorted  # part of the scans — not all — failed the order check
-    if regime in ("uniform_angles", "jitter1"):
-        assert nsorted == 0, nsorted     # the order survives: the streaming kernel alone
+    # which kernel did the work (round 6: chunk merges keep everything up to +-128 words — nodes up to 128 places
+    # from home — in the streaming kernel; +-300 words is the sorting kernel's, k_ascend<true>)
+    if regime == "jitter300":
+        assert nsorted > B // 2, nsorted
+    else:
+        assert nsorted == 0, nsorted
     # a second batch of another kind for free: the ascended scans ascended again (their invalid
     # nodes now sit between the valid ones and are given the angle of their NEW place, so this is not
     # an identity beyond +-1) — again against the oracle, scan by scan

@@ -18,7 +18,11 @@ torch.cuda.set_stream(stream)
 gpu.set_stream(stream.cuda_stream)
 d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
 d_st = torch.zeros(B, dtype=torch.int32, device=dev)
-for jit in (0, 1, 2, 3, 6, 10, 20):
+import ctypes as C
+from rplidar_ros2_driver_amd import abi  # noqa: E402
+_lib = abi.load_library()
+JITS = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (0, 1, 2, 3, 6, 10, 20, 40, 64, 128, 300)
+for jit in JITS:
     vb = synth.make_batch(2037, B, n, jitter=jit)
     d_v = torch.from_numpy(vb.view(np.uint8).reshape(B, n * 8)).to(dev)
     d_w = d_v.clone()
@@ -36,4 +40,12 @@ for jit in (0, 1, 2, 3, 6, 10, 20):
     changed = int((x != y).any(dim=2).sum().item())
     reord = int((x[:, :, 2:6] != y[:, :, 2:6]).any(dim=2).any(dim=1).sum().item())
     frac = (8 * B * n + 8 * changed) / (ms * 1e-3) / 8e12
-    print(f"jitter={jit:2d} ms={ms:.4f} rewritten={changed / (B * n):.4f} scans_reordered={reord / B:.3f} frac={frac:.3f}")
+    nsort = C.c_uint32(0)
+    try:
+        _lib.rplgpu_debug_ascend_sorted.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        _lib.rplgpu_debug_ascend_sorted(gpu._h, C.byref(nsort))
+        ns = nsort.value
+    except AttributeError:
+        ns = -1
+    print(f"jitter={jit:3d} ms={ms:.4f} rewritten={changed / (B * n):.4f} scans_reordered={reord / B:.3f} "
+          f"to_sort_kernel={ns} frac={frac:.3f}")
