@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp; export RPL_SYNTH_CACHE=/tmp/rplc
 # --no-c5: every k_cloud_voxel dispatch of the profiled command is the headline launch
-BENCH="python $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-variants --no-single $*"
+BENCH="python $R/bench.py --steps 5 --warmup 1 --cpu-seconds 0 --no-variants --no-single --no-live-traffic $*"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH > $OUT/stats.log 2>&1
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
