@@ -342,6 +342,21 @@ int32_t rplgpu_set_cell_key_output(rplgpu_handle_t h, uint32_t *d_cell_keys);
 #define RPLGPU_VOXEL_AGG_TWO_CLASS 2
 int32_t rplgpu_set_voxel_aggregation(rplgpu_handle_t h, int32_t mode);
 
+/* How E5 (radius outlier removal) runs in front of the voxel grid in the ARENA entry points
+ * (rplgpu_cloud_arena_dev, rplgpu_cloud_arena_xyi_dev, rplgpu_cloud_fused_voxel_dev).  The results are
+ * identical in both modes; only the time differs.  INSIDE (the default): the voxel kernel applies E5
+ * while it streams a scan — a kept sample with ror_min_neighbors neighbours among its four nearest
+ * indices survives at once, the few others (islands between drop-outs, isolated returns) are settled
+ * exactly behind the pass (64 indices either side, then the whole scan) — so a scan is read ONCE.  A
+ * work item with more open samples than that (clutter: > 256 after the index test or > 8 after the
+ * window) is redone by the two kernels of TWO_KERNELS behind the launch.  TWO_KERNELS: k_ror_mask
+ * writes one keep bit per sample, the voxel kernel reads the scan again with the mask (rounds 1-5;
+ * also what rplgpu_cloud_batch_dev and the single-scan calls use, and any launch whose divides were
+ * not validated on this device). */
+#define RPLGPU_ROR_INSIDE 0
+#define RPLGPU_ROR_TWO_KERNELS 1
+int32_t rplgpu_set_ror_mode(rplgpu_handle_t h, int32_t mode);
+
 #ifdef __cplusplus
 }
 #endif

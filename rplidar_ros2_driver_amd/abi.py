@@ -86,6 +86,7 @@ ABI_SYMBOLS = [
     "rplgpu_set_cell_key_output",
     "rplgpu_set_scan_time_offsets_dev",
     "rplgpu_set_voxel_aggregation",
+    "rplgpu_set_ror_mode",
     # include/rplgpu_comm.h
     "rplgpu_comm_unique_id",
     "rplgpu_comm_init",
@@ -211,6 +212,7 @@ def load_library() -> C.CDLL:
     lib.rplgpu_default_params.restype = None
     lib.rplgpu_set_stream.argtypes = [vp, vp]
     lib.rplgpu_set_voxel_aggregation.argtypes = [vp, i32]
+    lib.rplgpu_set_ror_mode.argtypes = [vp, i32]
     lib.rplgpu_synchronize.argtypes = [vp]
     lib.rplgpu_ascend.argtypes = [vp, vp, sz, C.POINTER(u32)]
     lib.rplgpu_scan_to_laserscan.argtypes = [
@@ -537,6 +539,18 @@ class RplGpu:
         """0 = auto (from the previous batch launch's statistics), 1 = plain, 2 = two-class
         (include/rplgpu.h RPLGPU_VOXEL_AGG_*).  Results are identical in every mode."""
         self._check(self._lib.rplgpu_set_voxel_aggregation(self._h, int(mode)))
+
+    def set_ror_mode(self, mode: int = 0):
+        """0 = E5 inside the voxel kernel (arena entry points, one pass over the scans), 1 = two kernels
+        (include/rplgpu.h RPLGPU_ROR_*).  Results are identical in both modes."""
+        self._check(self._lib.rplgpu_set_ror_mode(self._h, int(mode)))
+
+    def debug_ror_listed(self) -> int:
+        """Work items the last E5-inside launch left to the two kernels (waits for the stream)."""
+        n = C.c_uint32(0)
+        self._lib.rplgpu_debug_ror_listed.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        self._check(self._lib.rplgpu_debug_ror_listed(self._h, C.byref(n)))
+        return int(n.value)
 
     def set_scan_time_offsets_dev(self, d_t0: int = 0):
         """Per scan of the following de-skew / fused launches: the time [s] of its first sample relative

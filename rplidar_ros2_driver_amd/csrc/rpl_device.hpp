@@ -38,6 +38,8 @@ struct Tables {
   unsigned long long *voxel_stats_host;  // pinned copy of voxel_stats, refreshed behind every launch (or null)
   int32_t voxel_split;     // host decision from the previous launch's statistics: the noisy-batch instance
   const float *scan_t0;       // per scan: time of its first sample relative to the fused instant (E6), or null
+  uint32_t *redo;             // E5 inside the voxel kernel: [0] number of work items it left to the two-kernel
+                              // path, [4 ...] their numbers (cleared in front of the launch); or null
 };
 
 struct KParams {

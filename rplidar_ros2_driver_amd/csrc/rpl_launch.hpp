@@ -70,19 +70,27 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               uint32_t group = 1, const float *motion = nullptr,
                               const float *pose2d = nullptr,
                               // the arena holds 12-byte points (x, y, intensity): the exchange payload
-                              bool arena_xyi = false);
+                              bool arena_xyi = false,
+                              // E5 (round 6): 1 = inside the pass (arena launches, validated divides; items it
+                              // cannot settle go on T.redo), 2 = the items of T.redo with `keepmask`
+                              int ror_mode = 0);
 // record stores k_cloud_voxel needs: one per resident workgroup (two per CU) ...
 uint32_t voxel_max_workgroups(uint32_t n_cu);
 // ... of this many 16-byte entries for work items of `group` scans of `n_stride` samples: every
 // sample can end a run record, and every block of 128 samples adds one marker entry
 // (two per block: the noisy-batch instance aggregates a block in two classes, each behind its own marker)
+// (round 6: the ROR instance's blocks own 124 samples, and a sample E5 settles late brings its own marker:
+// at most 2 x (256 + 8) entries per scan)
 inline uint64_t voxel_store_need(uint32_t group, uint32_t n_stride) {
   const uint64_t s = n_stride < kMaxN ? n_stride : kMaxN;
-  return (uint64_t)(group ? group : 1u) * (s + 2u * ((s + 127u) / 128u) + 1u);
+  return (uint64_t)(group ? group : 1u) * (s + 2u * ((s + 123u) / 124u) + 1u + 528u);
 }
+// `listed`: the scans of the work items on T.redo (count word, then item numbers; an item = `group`
+// consecutive scans) instead of all B scans: a persistent grid that reads the count on the device
 hipError_t launch_ror_mask(hipStream_t s, const void *nodes, uint32_t n_stride,
                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
-                           const Tables &T, uint32_t *mask, uint32_t mask_stride);
+                           const Tables &T, uint32_t *mask, uint32_t mask_stride,
+                           bool listed = false, uint32_t group = 1);
 hipError_t launch_validate_div(hipStream_t s, float d, float rd, uint32_t e_lo, uint32_t e_hi,
                                uint32_t *d_mismatches);
 hipError_t launch_pack(hipStream_t s, const float *xyzi, uint32_t out_stride,

@@ -25,6 +25,8 @@
 // three-row slice alone, two dependent gathers per candidate: 9 ms per scan.)
 //
 // Output: one bit per input sample (bit i of word i/32), 1 = the sample passed E1 AND E5.
+#include <algorithm>
+
 #include "rpl_device.hpp"
 #include "rpl_launch.hpp"
 
@@ -69,20 +71,33 @@ __device__ __forceinline__ float2 node_xy(uint2 nd, const float2 *__restrict__ c
 
 // FAST: dist / 4000 as mul + 2 FMA (validated bit-identical to the IEEE divide on this device,
 // rplgpu_api.hip validate_divisor) in stage 1, where every sample is converted
-template <bool FAST>
+// LISTED (round 6): the scans of the work items the voxel kernel's ROR instance could not settle itself
+// (T.redo: count word, then item numbers; an item = `group` consecutive scans of the `n_scans`), a
+// persistent grid that learns the count on the device — usually zero, and the launch ends at once.
+template <bool FAST, bool LISTED>
 __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ nodes,
                                                      uint32_t n_stride,
                                                      const uint32_t *__restrict__ n_per_scan,
                                                      KParams p, Tables T,
                                                      uint32_t *__restrict__ mask_out,
-                                                     uint32_t mask_stride) {
+                                                     uint32_t mask_stride, uint32_t group,
+                                                     uint32_t n_scans) {
   __shared__ RorLds L;
   uint16_t *const L_idx = reinterpret_cast<uint16_t *>(L.idx_or_win);
   float2 *const L_win = reinterpret_cast<float2 *>(L.idx_or_win);
+  for (uint32_t item = blockIdx.x;; item += gridDim.x) {  // (not LISTED: one trip, the scan blockIdx.x)
+  uint32_t b = item;
+  if (LISTED) {
+    const uint32_t listed = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.redo[0]);
+    if (item / group >= listed) break;
+    b = T.redo[4u + item / group] * group + item % group;
+    if (b >= n_scans) continue;  // (the last group of a batch may be short)
+  } else if (item != blockIdx.x) {
+    break;
+  }
 #ifdef RPL_ROR_DBG
   const unsigned long long dbg_entry = __builtin_amdgcn_s_memtime();
 #endif
-  const uint32_t b = blockIdx.x;
   const uint32_t n = min(n_per_scan[b], min(n_stride, kMaxN));  // never past the slot
   const uint2 *scan = nodes + (size_t)b * n_stride;
   uint32_t *mask = mask_out + (size_t)b * mask_stride;
@@ -492,6 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
   atomicOr(&L.late[2u * ((lane >> 1) * (uint32_t)kWaves + wave) + (lane & 1u)], mine);
   __syncthreads();
   for (uint32_t t = threadIdx.x; t < kMaxN / 32u && t < mask_stride; t += kBlock) mask[t] = L.late[t];
+  if (LISTED) __syncthreads();  // (the next listed scan reuses the LDS)
 #ifdef RPL_ROR_DBG
   __syncthreads();
   if (threadIdx.x == 0 && p.dbg) {
@@ -502,18 +518,27 @@ __global__ __launch_bounds__(kBlock) void k_ror_mask(const uint2 *__restrict__ n
     p.dbg[(size_t)b * 16 + 10] = __builtin_amdgcn_s_getreg(((6 - 1) << 11) | (0 << 6) | 4) ;  // HW_ID
   }
 #endif
+  }
 }
 
 hipError_t launch_ror_mask(hipStream_t s, const void *nodes, uint32_t n_stride,
                            const uint32_t *n_per_scan, uint32_t B, const KParams &p,
-                           const Tables &T, uint32_t *mask, uint32_t mask_stride) {
+                           const Tables &T, uint32_t *mask, uint32_t mask_stride, bool listed,
+                           uint32_t group) {
   if (B == 0) return hipSuccess;
+  if (listed) {
+    if (!T.redo || !p.fast_d4000 || group == 0) return hipErrorInvalidValue;
+    const uint32_t grid = std::min<uint32_t>(B, T.n_cu ? T.n_cu : 256u);
+    hipLaunchKernelGGL((k_ror_mask<true, true>), dim3(grid), dim3(kBlock), 0, s, (const uint2 *)nodes,
+                       n_stride, n_per_scan, p, T, mask, mask_stride, group, B);
+    return hipGetLastError();
+  }
   if (p.fast_d4000)
-    hipLaunchKernelGGL(k_ror_mask<true>, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
-                       n_per_scan, p, T, mask, mask_stride);
+    hipLaunchKernelGGL((k_ror_mask<true, false>), dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
+                       n_per_scan, p, T, mask, mask_stride, 1u, B);
   else
-    hipLaunchKernelGGL(k_ror_mask<false>, dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
-                       n_per_scan, p, T, mask, mask_stride);
+    hipLaunchKernelGGL((k_ror_mask<false, false>), dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, n_stride,
+                       n_per_scan, p, T, mask, mask_stride, 1u, B);
   return hipGetLastError();
 }
 

@@ -119,6 +119,18 @@ struct VoxelLds {
 };
 static_assert(kVWG != 2 || sizeof(VoxelLds) <= 80u * 1024u, "two workgroups per compute unit");
 
+// E5 inside the voxel kernel (the ROR instance, round 6): what the streaming pass leaves for the
+// exact steps behind it — the samples whose index neighbours did not settle them.
+constexpr uint32_t kRorTodoCap = 256;  // unsettled samples of a scan the kernel resolves itself
+constexpr uint32_t kRorFewCap = 8;     // ... of which may still be unsettled after the +-64 window
+struct RorSide {
+  uint32_t n_todo, n_todo2;
+  uint32_t few_cnt[kRorFewCap];
+  float2 few_pt[kRorFewCap];
+  uint16_t todo[kRorTodoCap];
+  uint16_t todo2[kRorFewCap];
+};
+
 // Exclusive scan of one value per thread over the kVB threads.  `tmp` = kVW + 1 words of LDS.
 __device__ __forceinline__ uint32_t vx_excl_scan(uint32_t v, uint32_t *tmp, uint32_t *total) {
   const uint32_t inc = wave_incl_scan_fast(v);
@@ -200,6 +212,12 @@ __device__ __forceinline__ f2 apply_xf(f2 xy, uint32_t sample_index, const ScanX
   return o;
 }
 
+// What E5 needs of a sample when it runs inside the streaming pass (see voxel_stream, HASROR)
+struct RorPre {
+  f2 xy;    // E2 point in the sensor frame (in front of any E6 / E8 transform)
+  bool e1;  // passed E1 (whatever the cell-range test says later)
+};
+
 // Per-sample arithmetic of phase S for one 8-byte node (lo, hi) and its table entry `c`: the sort
 // key and the three quantities that are summed per cell.  Straight-line: a dropped sample is
 // computed with dist 0 — x = y = 0, floor 0, remainder 0 — so its offsets are zero without any
@@ -214,7 +232,7 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
                                              uint32_t ibfe_w, uint32_t &key, uint32_t &qx,
                                              uint32_t &qy, uint32_t &ci, uint32_t &flags,
                                              uint32_t sample_index = 0u,
-                                             const ScanXf *xf = nullptr) {
+                                             const ScanXf *xf = nullptr, RorPre *ror = nullptr) {
   const uint32_t d = __builtin_amdgcn_alignbit(hi, lo, 16);  // unaligned u32 at byte 2
   bool kept = (d - p.d_lo) <= p.d_span;                      // E1 (and :584)
   if (HASQ) kept = kept & ((hi & 0x00FF0000u) >= q_min16);
@@ -222,6 +240,10 @@ __device__ __forceinline__ bool voxel_sample(uint32_t lo, uint32_t hi, float2 c,
   const float dm = FAST_DIV ? div_by(df, 4000.0f, 0.00025f) : df / 4000.0f;  // :590
   const f2 cv = {c.x, c.y};
   f2 xy = cv * dm;                                                             // E2
+  if (ror) {  // (compile-time: the fused E5 instance) the point E5 sees: sensor frame, E1 only
+    ror->xy = xy;
+    ror->e1 = kept;
+  }
   if (XF) xy = apply_xf(xy, sample_index, *xf);                                // E6 + pose (E8)
   f2 t;
   if (FAST_DIV) {
@@ -773,14 +795,27 @@ __device__ __forceinline__ uint32_t voxel_reduce(VoxelLds &L, const KParams &p,
 // at a stride of 8 entries — the texture addresser became the bottleneck; transposed through LDS
 // each block waits for two LDS round trips on top of the loads: profiles/r03/voxel_phaseS_r03.txt.)
 // ------------------------------------------------------------------------------
-template <bool FAST_DIV, bool SAFE, bool SPLIT, bool DBG, bool HASQ, bool HASMASK, bool XF, int AHEAD>
+// HASROR (round 6, the ROR instance of the kernel): E5 runs INSIDE the pass.  A block then OWNS 124
+// samples and reads 128: lanes 0 and 63 hold the pair in front of and behind the block's own samples
+// (block k = the bytes [992 k - 16, 992 k + 1008) of the scan), so that every owned sample has its
+// index neighbours at +-1, +-2 in the two lanes next to it.  A lane tests its two samples against
+// each other and against the pair of the lane behind it (four distance tests, the oracle's
+// expression: products then sum); what the lane in front found comes over as a shifted scalar mask.
+// A kept sample with `ror_k` neighbours among those four is settled (it survives E5); one without is
+// dropped from the aggregation here and listed in `rs` for the exact steps behind the pass
+// (ror_resolve).  Dropped and unsettled samples are transparent to the runs (FILL).
+template <bool FAST_DIV, bool SAFE, bool SPLIT, bool DBG, bool HASQ, bool HASMASK, bool XF, int AHEAD,
+          bool HASROR = false>
 __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
                                              const float2 *__restrict__ cs,
                                              const __amdgpu_buffer_rsrc_t scan_rsrc, uint32_t blk0,
                                              uint32_t blk_end, const uint32_t *__restrict__ ror_bits,
                                              uint32_t mask_stride, const ScanXf &xf, uint32_t q_min16,
                                              uint32_t ibfe_off, uint32_t ibfe_w, uint32_t &flags,
-                                             unsigned long long *dbg_slot) {
+                                             unsigned long long *dbg_slot, RorSide *rs = nullptr,
+                                             uint32_t oob_off = 0u) {
+  static_assert(!HASROR || (HASQ && !HASMASK), "the ROR instance: quality test on, no mask word");
+  constexpr uint32_t kBlkBytes = HASROR ? 992u : 1024u, kBlkSamples = HASROR ? 124u : 128u;
   // raw pairs run AHEAD blocks in front of the block being aggregated, the table entries GA blocks (their
   // addresses come out of the raw pair: GA < AHEAD); both live in register rings of N slots, the loop is
   // unrolled N times so that the rings cost no moves
@@ -791,11 +826,19 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
     const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(scan_rsrc, (int)byte_off, 0, RPL_RAW_AUX);
     return make_uint4(t.x, t.y, t.z, t.w);
   };
-  const uint32_t lane_off = lane_id() * 16u;
+  // (HASROR: lane 0 of block 0 would read the 16 bytes in front of the scan: it reads past the
+  // resource instead — `oob_off`, a multiple of 16 >= the scan's bytes — and gets zeros)
+  const uint32_t lane_off = HASROR ? lane_id() * 16u - 16u : lane_id() * 16u;
+  const bool first_lane = HASROR && lane_id() == 0u;
+  auto blk_off = [&](uint32_t blk) -> uint32_t {
+    const uint32_t o = blk * kBlkBytes + lane_off;
+    return (HASROR && blk == 0u) ? (first_lane ? oob_off : o) : o;
+  };
+  const bool owned = !HASROR || (lane_id() - 1u) < 62u;
   uint4 w[N];
   float2 cA[N], cB[N];
 #pragma unroll
-  for (int j = 0; j < AHEAD; ++j) w[j] = load_pair((blk0 + (uint32_t)(j * kVW)) * 1024u + lane_off);
+  for (int j = 0; j < AHEAD; ++j) w[j] = load_pair(blk_off(blk0 + (uint32_t)(j * kVW)));
   auto gat = [&](uint32_t word) -> float2 { return cs[word & 0xFFFFu]; };
 #pragma unroll
   for (int j = 0; j < GA; ++j) {
@@ -804,6 +847,9 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
   }
   unsigned long long sub[5] = {0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0ull;
   for (uint32_t blk4 = blk0; blk4 < blk_end; blk4 += (uint32_t)(N * kVW)) {
+    if (HASROR) {  // a cluttered scan (more unsettled samples than the list holds) is given up at once
+      if ((uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&rs->n_todo) > kRorTodoCap) break;
+    }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
       const uint32_t blk = blk4 + (uint32_t)k * kVW;
@@ -814,7 +860,7 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
       if (DBG) t0 = clock64();
       cA[(k + GA) % N] = gat(w[(k + GA) % N].x);
       cB[(k + GA) % N] = gat(w[(k + GA) % N].z);
-      w[(k + AHEAD) % N] = load_pair((blk + (uint32_t)AHEAD * kVW) * 1024u + lane_off);
+      w[(k + AHEAD) % N] = load_pair(blk_off(blk + (uint32_t)AHEAD * kVW));
       if (DBG) {  // [8] issue of the loads (incl. the wait for the raw pair the gathers need)
         asm volatile("" : "+v"(cA[(k + GA) % N].x), "+v"(cB[(k + GA) % N].x)::"memory");
         t1 = clock64();
@@ -831,20 +877,74 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
           for (int j = 0; j < 2; ++j)
             if (!((two >> j) & 1u)) { lo[j] &= 0x0000FFFFu; hi[j] &= 0xFFFF0000u; }
         }
-        const uint32_t i0 = blk * 128u + lane_id() * 2u;  // sample index inside the scan
+        // sample index inside the scan (HASROR: 124 blk - 2 + 2 lane; the halo lanes' value is never used)
+        const uint32_t i0 = HASROR ? blk * kBlkSamples + lane_id() * 2u - 2u : blk * 128u + lane_id() * 2u;
         bool ok[2];
         uint32_t key[2], qx[2], qy[2], ci[2];
+        RorPre pre[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           ok[j] = voxel_sample<FAST_DIV, SAFE, HASQ, XF>(lo[j], hi[j], c0[j], p, q_min16, ibfe_off,
                                                         ibfe_w, key[j], qx[j], qy[j], ci[j], flags,
-                                                        i0 + (uint32_t)j, &xf);
+                                                        i0 + (uint32_t)j, &xf, HASROR ? &pre[j] : nullptr);
+        if (HASROR) {
+          // a sample that did not pass E1 sits 1e30 m away: d2 = +inf fails the test against any real
+          // point (two such samples "see" each other, which nobody asks about)
+          const float far = 1.0e30f;
+          const float ax = pre[0].e1 ? pre[0].xy.x : far, ay = pre[0].e1 ? pre[0].xy.y : far;
+          const float bx = pre[1].e1 ? pre[1].xy.x : far, by = pre[1].e1 ? pre[1].xy.y : far;
+          auto behind = [&](float v) -> float {  // lane l + 1's value (lane 63: far)
+            return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(
+                (int)__float_as_uint(far), (int)__float_as_uint(v), 0x130, 0xF, 0xF, false));  // wave_shl:1
+          };
+          const float nax = behind(ax), nay = behind(ay), nbx = behind(bx), nby = behind(by);
+          const float r2 = p.ror_r2;
+          auto within = [&](float x0, float y0, float x1, float y1) -> uint64_t {
+            const float dx = x0 - x1, dy = y0 - y1;
+            const float d2 = dx * dx + dy * dy;  // products then sum (-ffp-contract=off): the oracle's test
+            return __builtin_amdgcn_ballot_w64(d2 <= r2);
+          };
+          const uint64_t t0 = within(ax, ay, bx, by);      // (2l, 2l+1)
+          const uint64_t t1 = within(bx, by, nax, nay);    // (2l+1, 2l+2)
+          const uint64_t t2 = within(ax, ay, nax, nay);    // (2l, 2l+2)
+          const uint64_t t3 = within(bx, by, nbx, nby);    // (2l+1, 2l+3)
+          auto addc = [](uint32_t v, uint64_t m) -> uint32_t {
+            uint32_t o;
+            uint64_t co;
+            asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(o), "=s"(co) : "v"(v), "s"(m));
+            return o;
+          };
+          // sample a: 2l+1 (t0), 2l+2 (t2), 2l-1 (lane l-1's t1), 2l-2 (lane l-1's t2)
+          // sample b: 2l (t0), 2l+2 (t1), 2l+3 (t3), 2l-1 (lane l-1's t3)
+          const uint32_t ca = addc(addc(addc(addc(0u, t0), t2), t1 << 1), t2 << 1);
+          const uint32_t cb = addc(addc(addc(addc(0u, t0), t1), t3), t3 << 1);
+          const bool sa = ca >= p.ror_k, sb = cb >= p.ror_k;
+          const bool ua = owned && pre[0].e1 && !sa, ub = owned && pre[1].e1 && !sb;
+          if (__builtin_amdgcn_ballot_w64(ua || ub) != 0ull) {  // wave-uniform, rare
+            if (ua) {
+              const uint32_t sl = atomicAdd(&rs->n_todo, 1u);
+              if (sl < kRorTodoCap) rs->todo[sl] = (uint16_t)i0;
+            }
+            if (ub) {
+              const uint32_t sl = atomicAdd(&rs->n_todo, 1u);
+              if (sl < kRorTodoCap) rs->todo[sl] = (uint16_t)(i0 + 1u);
+            }
+          }
+          ok[0] = ok[0] && owned && sa;
+          ok[1] = ok[1] && owned && sb;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            qx[j] = ok[j] ? qx[j] : 0u;
+            qy[j] = ok[j] ? qy[j] : 0u;
+            ci[j] = ok[j] ? ci[j] : 0u;
+          }
+        }
         if (DBG) {  // [9] wait for this block's table entries + sample arithmetic
           asm volatile("" : "+v"(qx[1]), "+v"(qy[0]), "+v"(ci[1]), "+v"(key[1])::"memory");
           t2 = clock64();
         }
         uint32_t key0[2] = {key[0], key[1]};  // (the FILL instance rewrites dropped samples' keys)
-        if (voxel_block_pass<HASQ || HASMASK, 2, SPLIT ? kPassSplit : kPassPlain>(sink, ok, key, qx, qy, ci))
+        if (voxel_block_pass<HASQ || HASMASK || HASROR, 2, SPLIT ? kPassSplit : kPassPlain>(sink, ok, key, qx, qy, ci))
           voxel_block_split<2>(sink, ok, key0, qx, qy, ci);
         if (DBG) {  // [10] block pass (issue only: its stores are not waited for)
           t3 = clock64();
@@ -858,6 +958,117 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
   }
   if (DBG && dbg_slot && threadIdx.x == 0)
     for (int i = 0; i < 5; ++i) atomicAdd(&dbg_slot[8 + i], sub[i]);
+}
+
+// ------------------------------------------------------------------------------
+// E5 inside the voxel kernel, the exact steps behind the streaming pass (block-uniform control flow,
+// called by every thread of the workgroup behind a barrier).  The pass settled every kept sample that
+// has `ror_k` neighbours among its four nearest indices; the list holds the others (islands between
+// drop-outs, isolated returns: ~12 of 32 000 samples on a ring with 10 % drop-outs).
+//   1b. one wave per listed sample tests the 64 samples before and the 64 after it (k_ror_mask's
+//       stage 1b, rpl_ror.hip);
+//   2.  what is still unsettled (at most kRorFewCap samples) is counted exhaustively: every thread
+//       runs the scan's samples past those few points.
+// A sample that turns out to have its neighbours is appended to the queue as a record of its own
+// behind its own marker (the sums are order independent).  Returns true when the scan has more
+// unsettled samples than these steps take (clutter: the work item is left to the two-kernel path).
+// ------------------------------------------------------------------------------
+template <bool FAST_DIV, bool SAFE, bool XF>
+__device__ __forceinline__ void ror_append(QueueSink &S, const uint2 *__restrict__ scan, uint32_t i,
+                                           const float2 *__restrict__ cs, const KParams &p,
+                                           uint32_t q_min16, uint32_t ibfe_off, uint32_t ibfe_w,
+                                           const ScanXf &xf, uint32_t &flags) {
+  const uint2 nd = scan[i];
+  uint32_t key, qx, qy, ci;
+  const bool k = voxel_sample<FAST_DIV, SAFE, true, XF>(nd.x, nd.y, cs[nd.x & 0xFFFFu], p, q_min16, ibfe_off,
+                                                        ibfe_w, key, qx, qy, ci, flags, i, &xf);
+  if (!k) return;  // (dropped late: outside the cell range — flagged)
+  const uint32_t base = atomicAdd(&S.L.misc[0], 2u);
+  const uint4 marker = make_uint4(kEmptyKey, 0u, 0u, 0u), rec = make_uint4(key, qx, qy, ci);
+  if (base < kRecCap) S.L.rec[base] = marker; else S.G[base] = marker;
+  if (base + 1u < kRecCap) S.L.rec[base + 1u] = rec; else S.G[base + 1u] = rec;
+}
+
+template <bool FAST_DIV, bool SAFE, bool XF>
+__device__ __forceinline__ bool ror_resolve(QueueSink &S, RorSide &R, const KParams &p,
+                                            const float2 *__restrict__ cs,
+                                            const uint2 *__restrict__ scan, uint32_t n,
+                                            const ScanXf &xf, uint32_t q_min16, uint32_t ibfe_off,
+                                            uint32_t ibfe_w, uint32_t &flags) {
+  const uint32_t n_todo = R.n_todo;  // (the caller's barrier is behind the pass)
+  if (n_todo == 0u) return false;
+  if (n_todo > kRorTodoCap) return true;
+  const float r2 = p.ror_r2, far = 1.0e30f;
+  const uint32_t need = p.ror_k;
+  auto point = [&](uint2 nd) -> float2 {  // E2 as voxel_sample computes it; `far` unless E1 keeps it
+    const uint32_t d = nd_dist(nd);
+    const float df = __uint2float_rn(d);
+    const float dm = FAST_DIV ? div_by(df, 4000.0f, 0.00025f) : df / 4000.0f;
+    const float2 c = cs[nd_q14(nd)];
+    const bool k = ((d - p.d_lo) <= p.d_span) && ((nd.y & 0x00FF0000u) >= q_min16);
+    return make_float2(k ? dm * c.x : far, k ? dm * c.y : far);
+  };
+  const uint32_t lane = lane_id();
+  for (uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id()); t < n_todo; t += (uint32_t)kVW) {
+    const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.todo[t]);
+    const float2 me = point(scan[i]);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const uint32_t q = side ? i + 1u + lane : i - 1u - lane;  // (wraps below 0: fails q < n)
+      bool hit = false;
+      if (q < n) {
+        const float2 pc = point(scan[q]);
+        const float dx = me.x - pc.x, dy = me.y - pc.y;
+        const float d2 = dx * dx + dy * dy;
+        hit = d2 <= r2;
+      }
+      cnt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit));
+    }
+    if (lane == 0u) {
+      if (cnt >= need) {
+        ror_append<FAST_DIV, SAFE, XF>(S, scan, i, cs, p, q_min16, ibfe_off, ibfe_w, xf, flags);
+      } else {
+        const uint32_t sl = atomicAdd(&R.n_todo2, 1u);
+        if (sl < kRorFewCap) R.todo2[sl] = (uint16_t)i;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t n2 = R.n_todo2;
+  if (n2 == 0u) return false;
+  if (n2 > kRorFewCap) return true;
+  if (threadIdx.x < n2) {
+    R.few_pt[threadIdx.x] = point(scan[R.todo2[threadIdx.x]]);
+    R.few_cnt[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  uint32_t hits[kRorFewCap];
+#pragma unroll
+  for (uint32_t u = 0; u < kRorFewCap; ++u) hits[u] = 0u;
+  for (uint32_t q = threadIdx.x; q < n; q += (uint32_t)kVB) {
+    const float2 pc = point(scan[q]);
+#pragma unroll
+    for (uint32_t u = 0; u < kRorFewCap; ++u) {
+      if (u < n2) {  // (block-uniform)
+        const float2 me = R.few_pt[u];
+        const float dx = me.x - pc.x, dy = me.y - pc.y;
+        const float d2 = dx * dx + dy * dy;
+        hits[u] += (q != (uint32_t)R.todo2[u] && d2 <= r2) ? 1u : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (uint32_t u = 0; u < kRorFewCap; ++u) {
+    if (u < n2) {
+      const uint32_t tot = wave_incl_scan_fast(hits[u]);  // (the wave's sum in lane 63)
+      if (lane == 63u && tot) atomicAdd(&R.few_cnt[u], tot);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < n2 && R.few_cnt[threadIdx.x] >= need)
+    ror_append<FAST_DIV, SAFE, XF>(S, scan, R.todo2[threadIdx.x], cs, p, q_min16, ibfe_off, ibfe_w, xf, flags);
+  return false;
 }
 
 // What of one scan the streaming code needs besides its nodes: the E5 keep bits and the E8 transform.
@@ -883,7 +1094,7 @@ __device__ __forceinline__ ScanSide scan_side(uint32_t sc, const uint32_t *__res
   return s;
 }
 // (one loop instance per uniform condition, so that none of them is tested per block)
-template <bool FAST_DIV, bool SAFE, bool SPLIT, bool DBG, int AHEAD>
+template <bool FAST_DIV, bool SAFE, bool SPLIT, bool DBG, int AHEAD, int RORM = 0>
 __device__ __forceinline__ void voxel_stream_dispatch(QueueSink &sink, const KParams &p,
                                                       const float2 *__restrict__ cs,
                                                       const __amdgpu_buffer_rsrc_t rsrc, uint32_t blk0,
@@ -891,12 +1102,27 @@ __device__ __forceinline__ void voxel_stream_dispatch(QueueSink &sink, const KPa
                                                       uint32_t mask_stride, bool use_xf,
                                                       uint32_t q_min16, uint32_t ibfe_off,
                                                       uint32_t ibfe_w, uint32_t &flags,
-                                                      unsigned long long *dbg_slot) {
+                                                      unsigned long long *dbg_slot,
+                                                      RorSide *rs = nullptr, uint32_t oob_off = 0u) {
+  if constexpr (RORM == 1) {  // E5 inside the pass: two loop instances (with / without the transform)
+    if (use_xf)
+      voxel_stream<FAST_DIV, SAFE, SPLIT, false, true, false, true, AHEAD, true>(
+          sink, p, cs, rsrc, blk0, blk_end, nullptr, 0u, sd.xf, q_min16, ibfe_off, ibfe_w, flags, nullptr, rs, oob_off);
+    else
+      voxel_stream<FAST_DIV, SAFE, SPLIT, false, true, false, false, AHEAD, true>(
+          sink, p, cs, rsrc, blk0, blk_end, nullptr, 0u, sd.xf, q_min16, ibfe_off, ibfe_w, flags, nullptr, rs, oob_off);
+    return;
+  }
 #define RPL_VS(HQ, HM, XFB)                                                                         \
   voxel_stream<FAST_DIV, SAFE, SPLIT, DBG, HQ, HM, XFB, AHEAD>(sink, p, cs, rsrc, blk0, blk_end, \
                                                                      sd.ror_bits, mask_stride, sd.xf, \
                                                                      q_min16, ibfe_off, ibfe_w, flags, \
                                                                      dbg_slot)
+  if constexpr (RORM == 2) {  // the listed items of the two-kernel E5 path: mask word always on
+    if (use_xf) RPL_VS(true, true, true);
+    else RPL_VS(true, true, false);
+    return;
+  }
   if (use_xf) {  // (E8 / de-skew: one instance, quality test and mask word always on)
     if (sd.ror_bits) RPL_VS(true, true, true);
     else RPL_VS(true, false, true);
@@ -913,7 +1139,11 @@ __device__ __forceinline__ void voxel_stream_dispatch(QueueSink &sink, const KPa
 // L.misc[0] — then turn key bands of them into cells (phase R) and publish the item's results.
 // item0: first item of this launch (a launch may be one stage of a batch); B: its items.
 // ------------------------------------------------------------------------------
-template <bool DBG, class FirstBand>
+// RORM (round 6): 0 = the kernel as it always was; 1 = E5 inside the pass — `first_band` returns true for
+// an item whose scans hold more unsettled samples than the kernel resolves itself, the item then goes
+// on T.redo (count word, then the item numbers) and nothing of it is published here; 2 = the items
+// of that list (their E5 masks made by k_ror_mask in between), B read from the list's count word.
+template <bool DBG, int RORM = 0, class FirstBand>
 __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, const Tables &T,
                                                 uint4 *__restrict__ G, float4 *__restrict__ xyzi,
                                                 uint32_t out_stride, uint32_t *__restrict__ n_points,
@@ -921,10 +1151,12 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
                                                 uint32_t item0, const VoxelArena &arena,
                                                 FirstBand &&first_band) {
   if (threadIdx.x < 256) L.rcp[threadIdx.x] = T.rcp[threadIdx.x];  // (first barrier below publishes it)
+  if constexpr (RORM == 2) B = min(B, (uint32_t)__builtin_amdgcn_readfirstlane((int)T.redo[0]));
   // persistent workgroups; the first item is blockIdx.x, the next ones come from a shared counter,
   // so a workgroup that drew cheap scans simply takes more of them
   for (uint32_t bl = blockIdx.x; bl < B;) {
-  const uint32_t b = item0 + bl;
+  const uint32_t b = RORM == 2 ? T.redo[4u + bl] : item0 + bl;
+  bool abandoned = false;  // block-uniform (RORM == 1)
   float4 *out = arena.base ? arena.base : xyzi + (size_t)b * out_stride;
   int emit_mode = arena.base ? kEmitArenaFirst : kEmitLegacy;
   unsigned long long arena_at = 0ull;  // first point of this scan in the arena
@@ -968,11 +1200,15 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
     __syncthreads();
 
     if (first) {
-      first_band(b, bl, flags);
+      abandoned = first_band(b, bl, flags);
       first = false;
       // the record stores of phase S are hand-written instructions the compiler does not track
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();  // (workgroup-scope release / acquire: covers the record store too)
+      if (RORM == 1 && abandoned) {  // block-uniform: left to the two-kernel path
+        if (threadIdx.x == 0) T.redo[4u + atomicAdd(&T.redo[0], 1u)] = b;
+        break;
+      }
       pc.lap(0);
       n_all = L.misc[0];
       if (threadIdx.x == 0 && T.voxel_stats) {  // queue statistics of the launch (see SPLIT)
@@ -1286,7 +1522,7 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
 
   if (flags) atomicOr(&L.misc[1], flags);
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && !abandoned) {
     const uint32_t total = L.misc[7];
     if (arena.base) {
       const unsigned long long room = arena_at >= arena.capacity ? 0ull : arena.capacity - arena_at;
@@ -1299,7 +1535,7 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
       if (status) status[b] = L.misc[1] | ((total > out_stride) ? RPLGPU_SCAN_OUT_TRUNCATED : 0u);
     }
   }
-  if (B <= gridDim.x) return;  // a workgroup per item (single scans, small batches): no queue
+  if (RORM != 2 && B <= gridDim.x) return;  // a workgroup per item (single scans, small batches): no queue
   if (threadIdx.x == 0) L.tmp[31] = gridDim.x + atomicAdd(&T.work_ctr[0], 1u);
   __syncthreads();  // LDS is reused by the next scan
   bl = L.tmp[31];
@@ -1314,7 +1550,9 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
 // voxel_block_split); the launcher picks it from the queue statistics of the handle's previous
 // launch (T.voxel_stats), so a clean batch runs code without a trace of that path.
 // ------------------------------------------------------------------------------
-template <bool FAST_DIV, bool SAFE, bool DBG, bool SPLIT>
+// RORM (round 6): 1 = the ROR instance — E5 inside the pass (voxel_stream HASROR, ror_resolve);
+// 2 = the work items that instance left on T.redo, with the masks k_ror_mask made for them.
+template <bool FAST_DIV, bool SAFE, bool DBG, bool SPLIT, int RORM = 0>
 __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(kVB * kVWG / 256, kVB * kVWG / 256))) void k_cloud_voxel(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, const uint32_t *__restrict__ keepmask, uint32_t mask_stride,
@@ -1333,7 +1571,8 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(kVB * kVWG 
   const uint32_t ibfe_off = 16u + ishift, ibfe_w = 0xFFu >> ishift;  // shift, mask
   const uint32_t q_min16 = p.clip_enable ? (min(p.q_min, 256u) << 16) : 0u;
   const bool use_xf = (group > 1u) || motion || pose2d;  // block-uniform
-  auto phase_s = [&](uint32_t b, uint32_t, uint32_t &flags) {
+  __shared__ RorSide Rs;  // (referenced by the ROR instance only: the others do not allocate it)
+  auto phase_s = [&](uint32_t b, uint32_t, uint32_t &flags) -> bool {
     QueueSink sink{L, G};
     const uint32_t s_lo = b * group, s_hi = min(n_scans, s_lo + group);
     for (uint32_t sc = s_lo; sc < s_hi; ++sc) {
@@ -1349,12 +1588,30 @@ __global__ __launch_bounds__(kVB) __attribute__((amdgpu_waves_per_eu(kVB * kVWG 
           __builtin_amdgcn_make_buffer_rsrc((void *)scan, 0, (int)(n * 8u), 0x00020000);
       const ScanSide sd = scan_side(sc, keepmask, mask_stride, motion, pose2d, T.scan_t0);
       const uint32_t blk0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id());
-      voxel_stream_dispatch<FAST_DIV, SAFE, SPLIT, DBG, RPL_VOXEL_AHEAD>(
-          sink, p, cs, scan_rsrc, blk0, (n + 127u) >> 7, sd, mask_stride, use_xf, q_min16, ibfe_off,
-          ibfe_w, flags, (DBG && p.dbg) ? p.dbg + 16 * b : nullptr);
+      if constexpr (RORM == 1) {
+        if (threadIdx.x == 0) { Rs.n_todo = 0u; Rs.n_todo2 = 0u; }
+        __syncthreads();
+        voxel_stream_dispatch<FAST_DIV, SAFE, SPLIT, false, RPL_VOXEL_AHEAD, 1>(
+            sink, p, cs, scan_rsrc, blk0, (n + 123u) / 124u, sd, 0u, use_xf, q_min16, ibfe_off, ibfe_w, flags,
+            nullptr, &Rs, (n * 8u + 15u) & ~15u);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the pass's hand-written record stores)
+        __syncthreads();
+        bool clutter;
+        if (use_xf)
+          clutter = ror_resolve<FAST_DIV, SAFE, true>(sink, Rs, p, cs, scan, n, sd.xf, q_min16, ibfe_off, ibfe_w, flags);
+        else
+          clutter = ror_resolve<FAST_DIV, SAFE, false>(sink, Rs, p, cs, scan, n, sd.xf, q_min16, ibfe_off, ibfe_w, flags);
+        if (clutter) return true;  // block-uniform
+        __syncthreads();           // (the lists are reused by the group's next scan)
+      } else {
+        voxel_stream_dispatch<FAST_DIV, SAFE, SPLIT, DBG, RPL_VOXEL_AHEAD, RORM>(
+            sink, p, cs, scan_rsrc, blk0, (n + 127u) >> 7, sd, mask_stride, use_xf, q_min16, ibfe_off,
+            ibfe_w, flags, (DBG && p.dbg) ? p.dbg + 16 * b : nullptr);
+      }
     }
+    return false;
   };
-  voxel_work_loop<DBG>(L, p, T, G, xyzi, out_stride, n_points, status, B, 0u, arena, phase_s);
+  voxel_work_loop<DBG, RORM>(L, p, T, G, xyzi, out_stride, n_points, status, B, 0u, arena, phase_s);
 }
 
 // ------------------------------------------------------------------------------
@@ -1401,8 +1658,10 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               uint32_t *status, float *arena, unsigned long long arena_capacity,
                               unsigned long long *arena_cursor, unsigned long long *scan_start,
                               uint32_t group, const float *motion, const float *pose2d,
-                              bool arena_xyi) {
+                              bool arena_xyi, int ror_mode) {
   if (B == 0) return hipSuccess;
+  if (ror_mode && (!p.fast_div || !T.redo || !arena || p.dbg)) return hipErrorInvalidValue;
+  if (ror_mode == 2 && !keepmask) return hipErrorInvalidValue;
   if (group == 0) group = 1;
   group = std::min(group, B);  // (a group larger than the batch is the whole batch)
   const uint32_t n_scans = B;
@@ -1427,14 +1686,14 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
     if (g > 0) grid = std::min<uint32_t>(grid, (uint32_t)g);
   }
   // queue statistics of the launch (they pick the NEXT launch's instance): batches only
-  const bool with_stats = T.voxel_stats && T.voxel_stats_host && B >= 64u;
+  const bool with_stats = T.voxel_stats && T.voxel_stats_host && B >= 64u && ror_mode != 2;
   Tables Tk = T;
   if (!with_stats) Tk.voxel_stats = nullptr;
   if (with_stats)
     if (hipError_t e = hipMemsetAsync(T.voxel_stats, 0, 16, s); e != hipSuccess) return e;
   // (a launch with a workgroup per item does not touch the queue: one command less in front of a
   // single-scan call)
-  if (grid < B)
+  if (grid < B || ror_mode == 2)
     if (hipError_t e = hipMemsetAsync(T.work_ctr, 0, 4, s); e != hipSuccess) return e;
 #define RPL_LAUNCH_VOXEL(FD, SF, DB, SP)                                                          \
   hipLaunchKernelGGL((k_cloud_voxel<FD, SF, DB, SP>), dim3(grid), dim3(kVB), 0, s, (const uint2 *)nodes, \
@@ -1444,6 +1703,20 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   do {                                                                                             \
     if (p.cell_range_safe) RPL_LAUNCH_VOXEL(FD, true, DB, SP); else RPL_LAUNCH_VOXEL(FD, false, DB, SP); \
   } while (0)
+#define RPL_LAUNCH_VOXEL_ROR(SF, SP, RM)                                                          \
+  hipLaunchKernelGGL((k_cloud_voxel<true, SF, false, SP, RM>), dim3(grid), dim3(kVB), 0, s,         \
+                     (const uint2 *)nodes, n_stride, n_per_scan, p, Tk, keepmask, mask_stride,      \
+                     (float4 *)xyzi, out_stride, n_points, status, B, ar, (uint4 *)T.voxel_store,   \
+                     group, n_scans, motion, pose2d)
+#define RPL_LAUNCH_VOXEL_ROR_SF(SP, RM)                                                           \
+  do {                                                                                             \
+    if (p.cell_range_safe) RPL_LAUNCH_VOXEL_ROR(true, SP, RM); else RPL_LAUNCH_VOXEL_ROR(false, SP, RM); \
+  } while (0)
+  if (ror_mode == 1) {  // E5 inside the pass
+    if (T.voxel_split) RPL_LAUNCH_VOXEL_ROR_SF(true, 1); else RPL_LAUNCH_VOXEL_ROR_SF(false, 1);
+  } else if (ror_mode == 2) {  // the items it listed, behind k_ror_mask
+    if (T.voxel_split) RPL_LAUNCH_VOXEL_ROR_SF(true, 2); else RPL_LAUNCH_VOXEL_ROR_SF(false, 2);
+  } else
   if (p.dbg) {  // developer aid: the instrumented build of the kernel (plain instance only)
     if (p.fast_div) RPL_LAUNCH_VOXEL_SF(true, true, false); else RPL_LAUNCH_VOXEL_SF(false, true, false);
   } else if (T.voxel_split) {  // the handle's previous launch saw a noisy batch
@@ -1453,6 +1726,8 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
   }
 #undef RPL_LAUNCH_VOXEL_SF
 #undef RPL_LAUNCH_VOXEL
+#undef RPL_LAUNCH_VOXEL_ROR_SF
+#undef RPL_LAUNCH_VOXEL_ROR
   if (with_stats) {  // the statistics follow the launch to pinned memory (no wait)
     if (hipError_t e = hipMemcpyAsync(T.voxel_stats_host, T.voxel_stats, 16, hipMemcpyDeviceToHost, s);
         e != hipSuccess)

@@ -53,6 +53,8 @@ struct rplgpu_ctx {
   std::vector<Pinned> pinned;      // buffers handed out by rplgpu_host_alloc (device-addressable)
   unsigned char *d_nodes = nullptr, *d_out = nullptr;
   uint32_t *d_rormask = nullptr;  // E5 keep bits, max_b scans x kMaskStride words
+  uint32_t *d_redo = nullptr;     // E5 inside the voxel kernel: [0] work items left to the two-kernel path, [4 ...] which
+  int32_t ror_fused = 1;          // RPLGPU_ROR_FUSED=0: always the two kernels (tests / A-B runs)
   uint32_t *d_need_sort = nullptr;  // ascend: [0] how many scans the sorting kernel must redo, [1..] which (B + 1 words)
   uint32_t need_sort_cap = 0;
   uint32_t *d_small = nullptr;  // [0]=n, [1]=count, [2]=status, [8]=divide-validation mismatches, [16] voxel work
@@ -262,6 +264,7 @@ rpl::Tables tables_of(rplgpu_ctx *c) {
   t.voxel_stats_host = c->h_vstats;
   t.voxel_split = c->force_split > 0 ? 1 : 0;  // (batch launches: voxel_split_for)
   t.scan_t0 = c->scan_t0;
+  t.redo = c->d_redo;
   return t;
 }
 
@@ -323,6 +326,7 @@ void free_ctx(rplgpu_ctx *c) {
   if (c->d_out) (void)hipFree(c->d_out);
   if (c->d_small) (void)hipFree(c->d_small);
   if (c->d_rormask) (void)hipFree(c->d_rormask);
+  if (c->d_redo) (void)hipFree(c->d_redo);
   if (c->d_need_sort) (void)hipFree(c->d_need_sort);
   if (c->d_dec) (void)hipFree(c->d_dec);
   if (c->d_scans) (void)hipFree(c->d_scans);
@@ -595,7 +599,8 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
       // per-call scratch of the batch entry points, sized once for max_batch (no allocation on
       // the per-call paths): ascend's "needs the sorting kernel" list and the E5 keep bits
       hipMalloc((void **)&c->d_need_sort, ((size_t)c->max_b + 1u) * 4u) != hipSuccess ||
-      hipMalloc((void **)&c->d_rormask, (size_t)c->max_b * kMaskStride * 4u) != hipSuccess) {
+      hipMalloc((void **)&c->d_rormask, (size_t)c->max_b * kMaskStride * 4u) != hipSuccess ||
+      hipMalloc((void **)&c->d_redo, ((size_t)c->max_b + 4u) * 4u) != hipSuccess) {
     c->err = "staging allocation failed";
     return fail(RPLGPU_ERR_HIP);
   }
@@ -629,6 +634,7 @@ int32_t rplgpu_create(int32_t device_id, uint32_t max_samples_per_scan, uint32_t
   if (const char *e = std::getenv("RPLGPU_SPIN_SYNC")) c->spin_sync = std::atoi(e) != 0;
   if (const char *e = std::getenv("RPLGPU_DEC_STAGE")) c->dec_stage = std::atoi(e) != 0;
   if (const char *e = std::getenv("RPLGPU_VOXEL_SPLIT")) c->force_split = std::atoi(e) != 0;  // developer aid
+  if (const char *e = std::getenv("RPLGPU_ROR_FUSED")) c->ror_fused = std::atoi(e) != 0;  // 0: E5 as two kernels (tests / A-B runs)
   std::memset(c->h_pin + c->flag_off, 0, kTail);
   if (hipMemset(c->d_small, 0, 128) != hipSuccess) {  // incl. the voxel kernel's scan queue
     c->err = "staging clear failed";
@@ -711,6 +717,19 @@ int32_t rplgpu_debug_ascend_sorted(rplgpu_handle_t h, uint32_t *count) {
 // Developer aid (tests): the block-aggregation instance the handle's last voxel batch launch took
 // (0 plain, 1 two-class) — what RPLGPU_VOXEL_AGG_AUTO decided for it.
 int32_t rplgpu_debug_voxel_instance(rplgpu_handle_t h) { return h ? h->last_split : RPLGPU_ERR_INVALID_ARG; }
+int32_t rplgpu_set_ror_mode(rplgpu_handle_t h, int32_t mode) {
+  if (!h || (mode != RPLGPU_ROR_INSIDE && mode != RPLGPU_ROR_TWO_KERNELS)) return RPLGPU_ERR_INVALID_ARG;
+  h->ror_fused = mode == RPLGPU_ROR_INSIDE ? 1 : 0;
+  return RPLGPU_OK;
+}
+// (tests / tools: work items the last E5-inside launch left to the two kernels; waits for the stream)
+int32_t rplgpu_debug_ror_listed(rplgpu_handle_t h, uint32_t *count) {
+  if (!h || !count) return RPLGPU_ERR_INVALID_ARG;
+  RPL_HIP(h, hipSetDevice(h->device));
+  RPL_HIP(h, hipStreamSynchronize(h->stream));
+  RPL_HIP(h, hipMemcpy(count, h->d_redo, 4, hipMemcpyDeviceToHost));
+  return RPLGPU_OK;
+}
 int32_t rplgpu_debug_fast_div(rplgpu_handle_t h) {
   if (!h) return RPLGPU_ERR_INVALID_ARG;
   return (h->div4000_ok ? 1 : 0) | (h->leaf_ok ? 2 : 0) | (h->idx_ok ? 4 : 0);
@@ -769,9 +788,12 @@ int32_t rplgpu_ascend_laserscan_batch_dev(rplgpu_handle_t h, rplgpu_node_t *d_no
 }
 
 // parameter checks, divisor validation and the E5 mask shared by the cloud entry points
+// `ror_inside` (optional): the caller can run E5 inside the voxel kernel (arena launches); set when
+// that is what happens — no mask is made here then, see voxel_with_ror
 static int32_t prepare_cloud(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
                              const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
-                             rpl::KParams *kp_out, const uint32_t **mask_out) {
+                             rpl::KParams *kp_out, const uint32_t **mask_out,
+                             bool *ror_inside = nullptr) {
   if (p->ror_enable && !(p->ror_radius > 0.0f && p->ror_radius <= 1.0e6f)) {
     h->err = "ror_radius must be in (0, 1e6] m";
     return RPLGPU_ERR_INVALID_ARG;
@@ -795,12 +817,45 @@ static int32_t prepare_cloud(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, ui
   kp.dbg = h->dbg;
   kp.cell_keys = h->cell_keys;
   *mask_out = nullptr;
+  if (ror_inside) *ror_inside = false;
   if (p->ror_enable) {  // E5 before E4: per-sample keep bits, then the cloud kernels apply them
-    RPL_HIP(h, rpl::launch_ror_mask(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
-                                    tables_of(h), h->d_rormask, kMaskStride));
-    *mask_out = h->d_rormask;
+    if (ror_inside && h->ror_fused && p->voxel_enable && kp.fast_div && !kp.dbg) {
+      *ror_inside = true;
+    } else {
+      RPL_HIP(h, rpl::launch_ror_mask(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
+                                      tables_of(h), h->d_rormask, kMaskStride));
+      *mask_out = h->d_rormask;
+    }
   }
   *kp_out = kp;
+  return RPLGPU_OK;
+}
+
+// E5 + E4 of an arena launch in ONE pass over the scans (round 6): the voxel kernel's ROR instance
+// settles a sample by its index neighbours while it streams the scan and resolves the few that stay
+// open itself (csrc/rpl_voxel.hip: voxel_stream HASROR, ror_resolve).  A work item with more open
+// samples than that (clutter: hundreds of isolated returns) is put on a list instead, and the two
+// kernels of rounds 1-5 — k_ror_mask, then the voxel kernel with the mask — run over the LISTED
+// items behind it: two launches that find an empty list on ring-like data and end at once.
+static int32_t voxel_with_ror(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
+                              const uint32_t *d_n_per_scan, uint32_t B, const rpl::KParams &kp,
+                              const rpl::Tables &T, uint32_t *d_n_points, uint32_t *d_status,
+                              float *d_arena, uint64_t arena_capacity, uint64_t *d_cursor,
+                              uint64_t *d_start, uint32_t group, const float *d_motion,
+                              const float *d_pose2d, bool xyi) {
+  RPL_HIP(h, hipMemsetAsync(h->d_redo, 0, 4, h->stream));
+  RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, T, nullptr,
+                                     kMaskStride, nullptr, 0, d_n_points, d_status, d_arena,
+                                     arena_capacity, reinterpret_cast<unsigned long long *>(d_cursor),
+                                     reinterpret_cast<unsigned long long *>(d_start), group, d_motion,
+                                     d_pose2d, xyi, 1));
+  RPL_HIP(h, rpl::launch_ror_mask(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, T, h->d_rormask,
+                                  kMaskStride, true, std::max(1u, std::min(group, B))));
+  RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, T, h->d_rormask,
+                                     kMaskStride, nullptr, 0, d_n_points, d_status, d_arena,
+                                     arena_capacity, reinterpret_cast<unsigned long long *>(d_cursor),
+                                     reinterpret_cast<unsigned long long *>(d_start), group, d_motion,
+                                     d_pose2d, xyi, 2));
   return RPLGPU_OK;
 }
 
@@ -818,11 +873,15 @@ static int32_t cloud_arena_impl(rplgpu_handle_t h, const rplgpu_node_t *d_nodes,
   }
   rpl::KParams kp;
   const uint32_t *mask = nullptr;
-  if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
+  bool ror_inside = false;
+  if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask, &ror_inside))) return rc;
   RPL_HIP(h, hipMemsetAsync(d_cursor, 0, 8, h->stream));
   static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "64-bit cursor");
   rpl::Tables T_arena = tables_of(h);
   T_arena.voxel_split = voxel_split_for(h, d_nodes, n_stride, B, 1u) ? 1 : 0;
+  if (ror_inside)
+    return voxel_with_ror(h, d_nodes, n_stride, d_n_per_scan, B, kp, T_arena, d_n_points, d_status, d_arena,
+                          arena_capacity, d_cursor, d_scan_start, 1u, nullptr, nullptr, xyi);
   RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
                                      T_arena, mask, kMaskStride, nullptr, 0, d_n_points,
                                      d_status, d_arena, arena_capacity,
@@ -894,10 +953,14 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
   }
   rpl::KParams kp;
   const uint32_t *mask = nullptr;
-  if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
+  bool ror_inside = false;
+  if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask, &ror_inside))) return rc;
   RPL_HIP(h, hipMemsetAsync(d_cursor, 0, 8, h->stream));
   rpl::Tables T_fused = tables_of(h);
   T_fused.voxel_split = voxel_split_for(h, d_nodes, n_stride, B, group) ? 1 : 0;
+  if (ror_inside)
+    return voxel_with_ror(h, d_nodes, n_stride, d_n_per_scan, B, kp, T_fused, d_n_points, d_status, d_arena,
+                          arena_capacity, d_cursor, d_group_start, group, d_motion, d_pose2d, false);
   RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp,
                                      T_fused, mask, kMaskStride, nullptr, 0, d_n_points,
                                      d_status, d_arena, arena_capacity,

@@ -1,0 +1,183 @@
+"""E5 inside the voxel kernel (round 6) against the two kernels of rounds 1-5 and the oracle.
+
+The arena entry points run E5 (radius outlier removal) in the voxel kernel's own streaming pass
+(csrc/rpl_voxel.hip: voxel_stream HASROR, ror_resolve; include/rplgpu.h RPLGPU_ROR_INSIDE) and hand a
+work item they cannot settle to ``k_ror_mask`` + the masked voxel kernel.  Both modes must give the
+same clouds byte for byte — per scan: the scans sit in the arena in completion order — on
+  * rings with drop-outs (nothing listed), with 1 .. 12 isolated returns per scan (the exact steps
+    behind the pass: the +-64 window, the exhaustive count for <= 8 leftovers, the list above that),
+  * uniformly random ranges (every scan listed at once),
+  * batches that mix the two, ragged scan lengths around the 124-sample block size, k = 1 .. 5,
+  * groups of scans sharing one grid (E8, de-skew + pose), including a listed group.
+E5 is not in the reference: the oracle is the spec of SURVEY.md §8(a-ext) ("parity unpinned")."""
+import os
+
+import numpy as np
+import pytest
+
+from rplidar_ros2_driver_amd import Params, synth
+from tests import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _arena(gpu, batch, lens, p, group=0, motion=None, pose=None):
+    import torch
+    dev = torch.device("cuda:0")
+    B, n = batch.shape
+    d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+    d_len = torch.from_numpy(np.asarray(lens, np.int32)).to(dev)
+    items = B if not group else (B + group - 1) // group
+    cap = B * n
+    d_arena = torch.empty(cap, 4, dtype=torch.float32, device=dev)
+    d_cur = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_start = torch.zeros(items, dtype=torch.int64, device=dev)
+    d_np = torch.full((items,), -1, dtype=torch.int32, device=dev)
+    d_st = torch.full((items,), -1, dtype=torch.int32, device=dev)
+    if group:
+        d_mo = torch.from_numpy(motion).to(dev) if motion is not None else None
+        d_po = torch.from_numpy(pose).to(dev) if pose is not None else None
+        gpu.cloud_fused_voxel_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, group, p,
+                                  d_mo.data_ptr() if d_mo is not None else 0,
+                                  d_po.data_ptr() if d_po is not None else 0, d_arena.data_ptr(), cap,
+                                  d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+    else:
+        gpu.cloud_arena_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_arena.data_ptr(), cap,
+                            d_cur.data_ptr(), d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
+    gpu.synchronize()
+    total = int(d_cur.item())
+    arena = d_arena[:total].cpu().numpy()
+    start, npts, st = d_start.cpu().numpy(), d_np.cpu().numpy().astype(np.int64), d_st.cpu().numpy()
+    assert npts.min() >= 0 and st.min() >= 0, "an item was never published"
+    assert total == int(npts.sum())
+    return [arena[start[i]:start[i] + npts[i]].tobytes() for i in range(items)], npts, st, arena, start
+
+
+def _both(gpu, batch, lens, p, **kw):
+    """(clouds inside, clouds two kernels, items listed by the inside launch)"""
+    gpu.set_ror_mode(0)
+    try:
+        a = _arena(gpu, batch, lens, p, **kw)
+        listed = gpu.debug_ror_listed()
+        gpu.set_ror_mode(1)
+        b = _arena(gpu, batch, lens, p, **kw)
+    finally:
+        gpu.set_ror_mode(0)
+    assert np.array_equal(a[1], b[1]), np.nonzero(a[1] != b[1])[0][:8]
+    assert np.array_equal(a[2], b[2])
+    diff = [i for i in range(len(a[0])) if a[0][i] != b[0][i]]
+    assert not diff, diff[:8]
+    return a, listed
+
+
+def _ring_with_outliers(seed, n, k_out, noise=0.01):
+    """A ring with 10 % drop-outs and `k_out` isolated returns: single samples far inside the ring whose
+    index neighbours are dropped or metres away."""
+    s = synth.make_scan(seed, 0, n, noise_m=noise, r0_range=(8.0, 25.0))
+    rng = np.random.default_rng(seed)
+    for i in rng.choice(np.arange(200, n - 200), size=k_out, replace=False):
+        s["dist_mm_q2"][i] = np.uint32(4000 * rng.uniform(0.5, 3.0))
+    return s
+
+
+P_C5 = dict(clip_enable=1, range_min=0.15, range_max=40.0, voxel_enable=1, voxel_leaf=0.05, ror_enable=1,
+            ror_radius=0.10, ror_min_neighbors=2)
+
+
+@pytest.mark.parametrize("agg", [1, 2])
+def test_rings_are_settled_inside_the_kernel(gpu, oracle, agg):
+    """C5-shaped scans: nothing is listed, the clouds equal the two kernels' and the oracle's."""
+    B, n = 96, 32000
+    batch = synth.make_batch(2031, B, n, noise_m=0.01)
+    p = Params.defaults(**P_C5)
+    gpu.set_voxel_aggregation(agg)
+    try:
+        (clouds, npts, st, arena, start), listed = _both(gpu, batch, [n] * B, p)
+    finally:
+        gpu.set_voxel_aggregation(0)
+    assert listed == 0
+    assert int(st.max()) == 0
+    bad, res = oracle.batch_cloud_check(batch[:32], oracle_lib.copy_params(p), arena, start[:32], npts[:32],
+                                        None, os.cpu_count() or 1)
+    assert bad == 0, res[(res[:, 1] != 0) | (res[:, 2] != 0)][:8]
+
+
+def test_isolated_returns_leftovers_and_the_list(gpu):
+    """0 .. 12 isolated returns per scan: up to 8 are counted exhaustively inside the kernel, more than
+    that puts the scan on the list — the clouds are the same either way."""
+    n = 32000
+    ks = [0, 1, 2, 3, 5, 8, 8, 9, 12, 1, 4, 7]
+    batch = np.stack([_ring_with_outliers(100 + i, n, k) for i, k in enumerate(ks)])
+    p = Params.defaults(**P_C5)
+    _, listed = _both(gpu, batch, [n] * len(ks), p)
+    assert 0 < listed <= 4, listed  # (a return may settle by chance: at most the scans with > 8)
+
+
+def test_uniform_ranges_are_all_listed(gpu):
+    B, n = 24, 32000
+    batch = synth.make_batch(7, B, n, kind="uniform")
+    p = Params.defaults(**P_C5)
+    _, listed = _both(gpu, batch, [n] * B, p)
+    assert listed == B
+
+
+def test_mixed_batch_ragged_lengths_and_k(gpu):
+    """Rings, random scans and short scans in one batch; lengths around the 124-sample blocks of the
+    inside pass; ror_min_neighbors 1 .. 5 (5: no sample can be settled by four index neighbours)."""
+    n = 8192
+    lens = [0, 1, 2, 3, 4, 5, 123, 124, 125, 126, 247, 248, 249, 250, 1000, 4000, 8191, 8192, 8192, 8192,
+            372, 496, 620, 6200]
+    B = len(lens)
+    batch = synth.make_batch(11, B, n, noise_m=0.005)
+    batch[3::5] = synth.make_batch(12, B, n, kind="uniform")[3::5]
+    for k in (1, 2, 3, 4, 5):
+        for radius in (0.03, 0.25):
+            p = Params.defaults(**{**P_C5, "ror_min_neighbors": k, "ror_radius": radius})
+            _both(gpu, batch, lens, p)
+    # the quality filter in front of E5
+    p = Params.defaults(**{**P_C5, "q_min": 100})
+    _both(gpu, batch, lens, p)
+    # inverted, new protocol
+    p = Params.defaults(**{**P_C5, "inverted": 1, "is_new_protocol": 1})
+    _both(gpu, batch, lens, p)
+
+
+def test_short_scans_against_the_oracle(gpu, oracle):
+    """Scans the quadratic oracle finishes quickly, E5 inside the kernel, every scan checked."""
+    n = 2048
+    B = 64
+    batch = synth.make_batch(21, B, n, noise_m=0.02, r0_range=(0.5, 6.0))
+    rng = np.random.default_rng(5)
+    for b in range(0, B, 3):  # isolated returns
+        for i in rng.choice(n, size=b % 11, replace=False):
+            batch[b]["dist_mm_q2"][i] = np.uint32(4000 * rng.uniform(0.3, 1.0))
+    p = Params.defaults(**{**P_C5, "ror_radius": 0.08})
+    gpu.set_ror_mode(0)
+    clouds, npts, st, arena, start = _arena(gpu, batch, [n] * B, p)
+    bad, res = oracle.batch_cloud_check(batch, oracle_lib.copy_params(p), arena, start, npts, None,
+                                        os.cpu_count() or 1)
+    assert bad == 0, res[(res[:, 1] != 0) | (res[:, 2] != 0)][:8]
+    assert np.array_equal(res[:, 0].astype(np.int64), npts)
+
+
+@pytest.mark.parametrize("group", [2, 8])
+def test_groups_sharing_one_grid(gpu, group):
+    """E8 + E5: the scans of a group stream into one queue, each with its own E5 pass; a group with one
+    cluttered scan is listed as a whole."""
+    n = 16000
+    B = 4 * group + 1  # (the last group is short)
+    batch = synth.make_batch(31, B, n, noise_m=0.01)
+    batch[group + 1] = synth.make_scan(32, 0, n, kind="uniform")
+    for b in (0, 2 * group):
+        batch[b] = _ring_with_outliers(300 + b, n, 3)
+    rng = np.random.default_rng(9)
+    motion = np.stack([[rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-0.3, 0.3), 0.1 / n]
+                       for _ in range(B)]).astype(np.float32)
+    ang = rng.uniform(-3, 3, B)
+    pose = np.stack([np.cos(ang), -np.sin(ang), rng.uniform(-2, 2, B), np.sin(ang), np.cos(ang),
+                     rng.uniform(-2, 2, B)], 1).astype(np.float32)
+    p = Params.defaults(**P_C5)
+    _, listed = _both(gpu, batch, [n] * B, p, group=group, motion=motion, pose=pose)
+    assert listed >= 1
+    _, listed = _both(gpu, batch, [n] * B, p, group=group)  # no transform: identity
+    assert listed >= 1
