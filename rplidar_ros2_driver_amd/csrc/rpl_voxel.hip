@@ -814,7 +814,7 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
                                              uint32_t ibfe_off, uint32_t ibfe_w, uint32_t &flags,
                                              unsigned long long *dbg_slot, RorSide *rs = nullptr,
                                              uint32_t oob_off = 0u) {
-  static_assert(!HASROR || (HASQ && !HASMASK), "the ROR instance: quality test on, no mask word");
+  static_assert(!HASROR || !HASMASK, "the ROR instance: no mask word");
   constexpr uint32_t kBlkBytes = HASROR ? 992u : 1024u, kBlkSamples = HASROR ? 124u : 128u;
   // raw pairs run AHEAD blocks in front of the block being aggregated, the table entries GA blocks (their
   // addresses come out of the raw pair: GA < AHEAD); both live in register rings of N slots, the loop is
@@ -888,14 +888,12 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
                                                         ibfe_w, key[j], qx[j], qy[j], ci[j], flags,
                                                         i0 + (uint32_t)j, &xf, HASROR ? &pre[j] : nullptr);
         if (HASROR) {
-          // a sample that did not pass E1 sits 1e30 m away: d2 = +inf fails the test against any real
-          // point (two such samples "see" each other, which nobody asks about)
-          const float far = 1.0e30f;
-          const float ax = pre[0].e1 ? pre[0].xy.x : far, ay = pre[0].e1 ? pre[0].xy.y : far;
-          const float bx = pre[1].e1 ? pre[1].xy.x : far, by = pre[1].e1 ? pre[1].xy.y : far;
-          auto behind = [&](float v) -> float {  // lane l + 1's value (lane 63: far)
+          // (a sample that did not pass E1 was computed with dist 0 and sits at the origin: a pair only
+          // counts when BOTH its samples passed E1 — scalar masks, no selects on the coordinates)
+          const float ax = pre[0].xy.x, ay = pre[0].xy.y, bx = pre[1].xy.x, by = pre[1].xy.y;
+          auto behind = [&](float v) -> float {  // lane l + 1's value (lane 63: its own, masked below)
             return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(
-                (int)__float_as_uint(far), (int)__float_as_uint(v), 0x130, 0xF, 0xF, false));  // wave_shl:1
+                (int)__float_as_uint(v), (int)__float_as_uint(v), 0x130, 0xF, 0xF, false));  // wave_shl:1
           };
           const float nax = behind(ax), nay = behind(ay), nbx = behind(bx), nby = behind(by);
           const float r2 = p.ror_r2;
@@ -904,10 +902,11 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
             const float d2 = dx * dx + dy * dy;  // products then sum (-ffp-contract=off): the oracle's test
             return __builtin_amdgcn_ballot_w64(d2 <= r2);
           };
-          const uint64_t t0 = within(ax, ay, bx, by);      // (2l, 2l+1)
-          const uint64_t t1 = within(bx, by, nax, nay);    // (2l+1, 2l+2)
-          const uint64_t t2 = within(ax, ay, nax, nay);    // (2l, 2l+2)
-          const uint64_t t3 = within(bx, by, nbx, nby);    // (2l+1, 2l+3)
+          const uint64_t KA = __builtin_amdgcn_ballot_w64(pre[0].e1), KB = __builtin_amdgcn_ballot_w64(pre[1].e1);
+          const uint64_t t0 = within(ax, ay, bx, by) & KA & KB;            // (2l, 2l+1)
+          const uint64_t t1 = within(bx, by, nax, nay) & KB & (KA >> 1);   // (2l+1, 2l+2)
+          const uint64_t t2 = within(ax, ay, nax, nay) & KA & (KA >> 1);   // (2l, 2l+2)
+          const uint64_t t3 = within(bx, by, nbx, nby) & KB & (KB >> 1);   // (2l+1, 2l+3)
           auto addc = [](uint32_t v, uint64_t m) -> uint32_t {
             uint32_t o;
             uint64_t co;
@@ -918,9 +917,32 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
           // sample b: 2l (t0), 2l+2 (t1), 2l+3 (t3), 2l-1 (lane l-1's t3)
           const uint32_t ca = addc(addc(addc(addc(0u, t0), t2), t1 << 1), t2 << 1);
           const uint32_t cb = addc(addc(addc(addc(0u, t0), t1), t3), t3 << 1);
-          const bool sa = ca >= p.ror_k, sb = cb >= p.ror_k;
-          const bool ua = owned && pre[0].e1 && !sa, ub = owned && pre[1].e1 && !sb;
-          if (__builtin_amdgcn_ballot_w64(ua || ub) != 0ull) {  // wave-uniform, rare
+          bool sa = ca >= p.ror_k, sb = cb >= p.ror_k;
+          bool ua = owned && pre[0].e1 && !sa, ub = owned && pre[1].e1 && !sb;
+          if (__builtin_amdgcn_ballot_w64(ua || ub) != 0ull) {  // wave-uniform, rare (one block in twenty)
+            // The wave holds 128 consecutive samples of the scan: an unsettled one is first run past ALL of
+            // them (its point from a scalar lane read, two tests per lane, two ballots) — any kept samples
+            // within r will do, and what a sample misses among its four index neighbours is nearly always
+            // a few indices further on.  No memory access; only what this leaves goes on the list.
+            uint64_t late[2] = {0ull, 0ull};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              uint64_t m = __builtin_amdgcn_ballot_w64(j ? ub : ua);
+              while (m) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                const float mx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(j ? bx : ax), (int)l));
+                const float my = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(j ? by : ay), (int)l));
+                uint64_t ha = within(mx, my, ax, ay) & KA, hb = within(mx, my, bx, by) & KB;
+                if (j) hb &= ~(1ull << l); else ha &= ~(1ull << l);  // (not the sample itself)
+                if ((uint32_t)__popcll(ha) + (uint32_t)__popcll(hb) >= p.ror_k) late[j] |= 1ull << l;
+              }
+            }
+            const bool la = __builtin_amdgcn_inverse_ballot_w64(late[0]), lb = __builtin_amdgcn_inverse_ballot_w64(late[1]);
+            sa = sa || la;
+            sb = sb || lb;
+            ua = ua && !la;
+            ub = ub && !lb;
             if (ua) {
               const uint32_t sl = atomicAdd(&rs->n_todo, 1u);
               if (sl < kRorTodoCap) rs->todo[sl] = (uint16_t)i0;
@@ -944,7 +966,9 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
           t2 = clock64();
         }
         uint32_t key0[2] = {key[0], key[1]};  // (the FILL instance rewrites dropped samples' keys)
-        if (voxel_block_pass<HASQ || HASMASK || HASROR, 2, SPLIT ? kPassSplit : kPassPlain>(sink, ok, key, qx, qy, ci))
+        // (the ROR instance without quality filter runs the PLAIN pass: its drops are E1's runs of dist 0 plus
+        // a rare unsettled sample, which ends a run like any dropped sample)
+        if (voxel_block_pass<HASQ || HASMASK, 2, SPLIT ? kPassSplit : kPassPlain>(sink, ok, key, qx, qy, ci))
           voxel_block_split<2>(sink, ok, key0, qx, qy, ci);
         if (DBG) {  // [10] block pass (issue only: its stores are not waited for)
           t3 = clock64();
@@ -974,19 +998,82 @@ __device__ __forceinline__ void voxel_stream(QueueSink &sink, const KParams &p,
 // unsettled samples than these steps take (clutter: the work item is left to the two-kernel path).
 // ------------------------------------------------------------------------------
 template <bool FAST_DIV, bool SAFE, bool XF>
-__device__ __forceinline__ void ror_append(QueueSink &S, const uint2 *__restrict__ scan, uint32_t i,
-                                           const float2 *__restrict__ cs, const KParams &p,
+__device__ __forceinline__ void ror_append(QueueSink &S, uint2 nd, float2 c, uint32_t i, const KParams &p,
                                            uint32_t q_min16, uint32_t ibfe_off, uint32_t ibfe_w,
                                            const ScanXf &xf, uint32_t &flags) {
-  const uint2 nd = scan[i];
   uint32_t key, qx, qy, ci;
-  const bool k = voxel_sample<FAST_DIV, SAFE, true, XF>(nd.x, nd.y, cs[nd.x & 0xFFFFu], p, q_min16, ibfe_off,
+  const bool k = voxel_sample<FAST_DIV, SAFE, true, XF>(nd.x, nd.y, c, p, q_min16, ibfe_off,
                                                         ibfe_w, key, qx, qy, ci, flags, i, &xf);
   if (!k) return;  // (dropped late: outside the cell range — flagged)
   const uint32_t base = atomicAdd(&S.L.misc[0], 2u);
   const uint4 marker = make_uint4(kEmptyKey, 0u, 0u, 0u), rec = make_uint4(key, qx, qy, ci);
   if (base < kRecCap) S.L.rec[base] = marker; else S.G[base] = marker;
   if (base + 1u < kRecCap) S.L.rec[base + 1u] = rec; else S.G[base + 1u] = rec;
+}
+
+// E2 as voxel_sample computes it from a node and its (cos, sin) entry; 1e30 m away unless E1 keeps the node
+template <bool FAST_DIV>
+__device__ __forceinline__ float2 ror_point(uint2 nd, float2 c, const KParams &p, uint32_t q_min16) {
+  const uint32_t d = nd_dist(nd);
+  const float df = __uint2float_rn(d);
+  const float dm = FAST_DIV ? div_by(df, 4000.0f, 0.00025f) : df / 4000.0f;
+  const bool k = ((d - p.d_lo) <= p.d_span) && ((nd.y & 0x00FF0000u) >= q_min16);
+  return make_float2(k ? dm * c.x : 1.0e30f, k ? dm * c.y : 1.0e30f);
+}
+
+// Step 2 of ror_resolve: the scan's samples past the <= kRorFewCap points still open, ONE point per pass
+// over the scan (a counter and a point in registers: with all eight points tested in one unrolled pass the
+// kernel spilt 58 vector and 367 scalar registers and lost 13 % on a batch that never gets here).
+#ifndef RPL_ROR_KU
+#define RPL_ROR_KU 4
+#endif
+template <bool FAST_DIV, bool SAFE, bool XF>
+__device__ __forceinline__ void ror_exhaustive(QueueSink &S, RorSide &R, const KParams &p,
+                                               const float2 *__restrict__ cs,
+                                               const uint2 *__restrict__ scan, uint32_t n,
+                                               const ScanXf &xf, uint32_t q_min16, uint32_t ibfe_off,
+                                               uint32_t ibfe_w, uint32_t n2, uint32_t &flags) {
+  uint32_t tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // (nothing of this step is hoisted out of the kernel's item loop)
+  const float r2 = p.ror_r2;
+  const uint2 none = make_uint2(0u, 0u);  // (dist 0: never kept)
+  if (tid < kRorFewCap) R.few_cnt[tid] = 0u;
+  __syncthreads();
+  constexpr int KU = RPL_ROR_KU;
+  for (uint32_t u = 0; u < n2; ++u) {  // block-uniform
+    const uint32_t iu = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.todo2[u]);
+    const uint2 nu = scan[iu];
+    const float2 me = ror_point<FAST_DIV>(nu, cs[nd_q14(nu)], p, q_min16);
+    uint32_t hits = 0u;
+    // KU nodes per thread and trip, their loads and their gathers issued together (the scan is in L2 / the
+    // Infinity Cache: the pass just streamed it)
+    for (uint32_t q0 = tid; q0 < n; q0 += (uint32_t)(KU * kVB)) {
+      uint2 nd[KU];
+      float2 c[KU];
+#pragma unroll
+      for (int j = 0; j < KU; ++j) {
+        const uint32_t q = q0 + (uint32_t)(j * kVB);
+        nd[j] = q < n ? scan[q] : none;
+      }
+#pragma unroll
+      for (int j = 0; j < KU; ++j) c[j] = cs[nd_q14(nd[j])];
+#pragma unroll
+      for (int j = 0; j < KU; ++j) {
+        const uint32_t q = q0 + (uint32_t)(j * kVB);
+        const float2 pc = ror_point<FAST_DIV>(nd[j], c[j], p, q_min16);
+        const float dx = me.x - pc.x, dy = me.y - pc.y;
+        const float d2 = dx * dx + dy * dy;
+        hits += (q != iu && d2 <= r2) ? 1u : 0u;
+      }
+    }
+    const uint32_t tot = wave_incl_scan_fast(hits);  // (the wave's sum in lane 63)
+    if ((tid & 63u) == 63u && tot) atomicAdd(&R.few_cnt[u], tot);
+  }
+  __syncthreads();
+  if (tid < n2 && R.few_cnt[tid] >= p.ror_k) {
+    const uint2 nd = scan[R.todo2[tid]];
+    ror_append<FAST_DIV, SAFE, XF>(S, nd, cs[nd_q14(nd)], R.todo2[tid], p, q_min16, ibfe_off, ibfe_w, xf, flags);
+  }
 }
 
 template <bool FAST_DIV, bool SAFE, bool XF>
@@ -998,36 +1085,25 @@ __device__ __forceinline__ bool ror_resolve(QueueSink &S, RorSide &R, const KPar
   const uint32_t n_todo = R.n_todo;  // (the caller's barrier is behind the pass)
   if (n_todo == 0u) return false;
   if (n_todo > kRorTodoCap) return true;
-  const float r2 = p.ror_r2, far = 1.0e30f;
+  const float r2 = p.ror_r2;
   const uint32_t need = p.ror_k;
-  auto point = [&](uint2 nd) -> float2 {  // E2 as voxel_sample computes it; `far` unless E1 keeps it
-    const uint32_t d = nd_dist(nd);
-    const float df = __uint2float_rn(d);
-    const float dm = FAST_DIV ? div_by(df, 4000.0f, 0.00025f) : df / 4000.0f;
-    const float2 c = cs[nd_q14(nd)];
-    const bool k = ((d - p.d_lo) <= p.d_span) && ((nd.y & 0x00FF0000u) >= q_min16);
-    return make_float2(k ? dm * c.x : far, k ? dm * c.y : far);
-  };
+  const uint2 none = make_uint2(0u, 0u);  // (dist 0: never kept)
   const uint32_t lane = lane_id();
   for (uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_id()); t < n_todo; t += (uint32_t)kVW) {
     const uint32_t i = (uint32_t)__builtin_amdgcn_readfirstlane((int)R.todo[t]);
-    const float2 me = point(scan[i]);
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-      const uint32_t q = side ? i + 1u + lane : i - 1u - lane;  // (wraps below 0: fails q < n)
-      bool hit = false;
-      if (q < n) {
-        const float2 pc = point(scan[q]);
-        const float dx = me.x - pc.x, dy = me.y - pc.y;
-        const float d2 = dx * dx + dy * dy;
-        hit = d2 <= r2;
-      }
-      cnt += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(hit));
-    }
+    // (the three node loads, then the three gathers: two round trips per listed sample)
+    const uint32_t qb = i - 1u - lane, qa = i + 1u + lane;  // (qb wraps below 0: fails q < n)
+    const uint2 nm = scan[i], nb = qb < n ? scan[qb] : none, na = qa < n ? scan[qa] : none;
+    const float2 cm = cs[nd_q14(nm)], cb = cs[nd_q14(nb)], ca = cs[nd_q14(na)];
+    const float2 me = ror_point<FAST_DIV>(nm, cm, p, q_min16), pb = ror_point<FAST_DIV>(nb, cb, p, q_min16),
+                 pa = ror_point<FAST_DIV>(na, ca, p, q_min16);
+    const float dxb = me.x - pb.x, dyb = me.y - pb.y, dxa = me.x - pa.x, dya = me.y - pa.y;
+    const float d2b = dxb * dxb + dyb * dyb, d2a = dxa * dxa + dya * dya;
+    const uint32_t cnt = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(d2b <= r2)) +
+                         (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(d2a <= r2));
     if (lane == 0u) {
       if (cnt >= need) {
-        ror_append<FAST_DIV, SAFE, XF>(S, scan, i, cs, p, q_min16, ibfe_off, ibfe_w, xf, flags);
+        ror_append<FAST_DIV, SAFE, XF>(S, nm, cm, i, p, q_min16, ibfe_off, ibfe_w, xf, flags);
       } else {
         const uint32_t sl = atomicAdd(&R.n_todo2, 1u);
         if (sl < kRorFewCap) R.todo2[sl] = (uint16_t)i;
@@ -1038,36 +1114,7 @@ __device__ __forceinline__ bool ror_resolve(QueueSink &S, RorSide &R, const KPar
   const uint32_t n2 = R.n_todo2;
   if (n2 == 0u) return false;
   if (n2 > kRorFewCap) return true;
-  if (threadIdx.x < n2) {
-    R.few_pt[threadIdx.x] = point(scan[R.todo2[threadIdx.x]]);
-    R.few_cnt[threadIdx.x] = 0u;
-  }
-  __syncthreads();
-  uint32_t hits[kRorFewCap];
-#pragma unroll
-  for (uint32_t u = 0; u < kRorFewCap; ++u) hits[u] = 0u;
-  for (uint32_t q = threadIdx.x; q < n; q += (uint32_t)kVB) {
-    const float2 pc = point(scan[q]);
-#pragma unroll
-    for (uint32_t u = 0; u < kRorFewCap; ++u) {
-      if (u < n2) {  // (block-uniform)
-        const float2 me = R.few_pt[u];
-        const float dx = me.x - pc.x, dy = me.y - pc.y;
-        const float d2 = dx * dx + dy * dy;
-        hits[u] += (q != (uint32_t)R.todo2[u] && d2 <= r2) ? 1u : 0u;
-      }
-    }
-  }
-#pragma unroll
-  for (uint32_t u = 0; u < kRorFewCap; ++u) {
-    if (u < n2) {
-      const uint32_t tot = wave_incl_scan_fast(hits[u]);  // (the wave's sum in lane 63)
-      if (lane == 63u && tot) atomicAdd(&R.few_cnt[u], tot);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < n2 && R.few_cnt[threadIdx.x] >= need)
-    ror_append<FAST_DIV, SAFE, XF>(S, scan, R.todo2[threadIdx.x], cs, p, q_min16, ibfe_off, ibfe_w, xf, flags);
+  ror_exhaustive<FAST_DIV, SAFE, XF>(S, R, p, cs, scan, n, xf, q_min16, ibfe_off, ibfe_w, n2, flags);
   return false;
 }
 
@@ -1104,12 +1151,15 @@ __device__ __forceinline__ void voxel_stream_dispatch(QueueSink &sink, const KPa
                                                       uint32_t ibfe_w, uint32_t &flags,
                                                       unsigned long long *dbg_slot,
                                                       RorSide *rs = nullptr, uint32_t oob_off = 0u) {
-  if constexpr (RORM == 1) {  // E5 inside the pass: two loop instances (with / without the transform)
+  if constexpr (RORM == 1) {  // E5 inside the pass: transform (quality test always on) / quality filter / neither
     if (use_xf)
       voxel_stream<FAST_DIV, SAFE, SPLIT, false, true, false, true, AHEAD, true>(
           sink, p, cs, rsrc, blk0, blk_end, nullptr, 0u, sd.xf, q_min16, ibfe_off, ibfe_w, flags, nullptr, rs, oob_off);
-    else
+    else if (q_min16)
       voxel_stream<FAST_DIV, SAFE, SPLIT, false, true, false, false, AHEAD, true>(
+          sink, p, cs, rsrc, blk0, blk_end, nullptr, 0u, sd.xf, q_min16, ibfe_off, ibfe_w, flags, nullptr, rs, oob_off);
+    else
+      voxel_stream<FAST_DIV, SAFE, SPLIT, false, false, false, false, AHEAD, true>(
           sink, p, cs, rsrc, blk0, blk_end, nullptr, 0u, sd.xf, q_min16, ibfe_off, ibfe_w, flags, nullptr, rs, oob_off);
     return;
   }

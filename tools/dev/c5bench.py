@@ -15,7 +15,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 n = 32000
 dev = torch.device("cuda:0")
-batch = synth.make_batch(2026 + 5, B, n, noise_m=0.01)
+batch = synth.make_batch(2026 + 5, B, n, noise_m=0.01, invalid_p=float(os.environ.get("C5_INVALID", "0.10")))
 d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
 d_len = torch.full((B,), n, dtype=torch.int32, device=dev)
 cap = B * n
@@ -68,7 +68,14 @@ def timed(fn):
     return best
 
 
-for rnd in range(2):
+p_ror = p
+p = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1, voxel_leaf=0.05)
+print(f"lib={Path(os.environ.get('RPLGPU_LIBRARY', 'default')).name} without E5: arena {timed(arena):.4f} ms, "
+      f"fused grid {timed(fused):.4f} ms", flush=True)
+p = Params.defaults(clip_enable=1, q_min=1, range_min=0.15, range_max=40.0, voxel_enable=1, voxel_leaf=0.05)
+print(f"  without E5, q_min 1 (quality test + FILL pass): arena {timed(arena):.4f} ms", flush=True)
+p = p_ror
+for rnd in range(int(os.environ.get("C5_ROUNDS", "2"))):
     for name, fn in (("c5 arena", arena), ("fused grid x8", fused)):
         row = []
         for mode in (0, 1):
