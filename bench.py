@@ -480,8 +480,8 @@ def decode_stage(gpu, dev, stream, cpu_seconds):
 
 
 def regime(gpu, dev, stream, name, batch_np, params, arena, cursor, start, npts, stat, reps):
-    """One data regime at the full batch shape: k_cloud_voxel (+ k_ror_mask when E5 is on) into the
-    arena; ms per launch, Gpts/s, roofline fractions.  Returns (dict, cells)."""
+    """One data regime at the full batch shape: k_cloud_voxel (E5, when on, inside it or as k_ror_mask in
+    front of it: rplgpu_set_ror_mode) into the arena; ms per launch, Gpts/s, roofline fractions.  Returns (dict, cells)."""
     import torch
 
     B, n = batch_np.shape
@@ -957,6 +957,17 @@ def main():
                              voxel_leaf=0.05, ror_enable=1, ror_radius=0.10, ror_min_neighbors=2)
         c5 = regime(gpu, dev, stream, "c5", c5b, p5, big_arena, d_cursor, d_start, d_np, d_st, vreps)
         c5["workload"] = f"8 sensors x {B // 8} frames x {n} samples, 1 cm range noise, ROR(0.10 m, >= 2) + voxel 5 cm"
+        # (round 6) E5 runs inside the voxel kernel's streaming pass (include/rplgpu.h RPLGPU_ROR_INSIDE: one pass
+        # over the scans); work items it cannot settle go to the two kernels of rounds 1-5, timed here as well
+        c5["e5"] = "inside the voxel kernel (RPLGPU_ROR_INSIDE)"
+        c5["items_left_to_two_kernels"] = gpu.debug_ror_listed()
+        gpu.set_ror_mode(1)
+        try:
+            two = regime(gpu, dev, stream, "c5", c5b, p5, big_arena, d_cursor, d_start, d_np, d_st, vreps)
+        finally:
+            gpu.set_ror_mode(0)
+        c5["two_kernels"] = {"ms": two["ms"], "frac": two["frac"], "cells": two["cells"],
+                             "note": "k_ror_mask + k_cloud_voxel with the mask (RPLGPU_ROR_TWO_KERNELS)"}
         # ... and as ONE grid per time step (E8): per-sensor motion de-skew + planar pose, the 8
         # sensors of a frame voxelised together (rplgpu_cloud_fused_voxel_dev, group = 8)
         rng = np.random.default_rng(args.seed)
@@ -974,9 +985,15 @@ def main():
                                       d_po.data_ptr(), big_arena.data_ptr(), cap5, d_cursor.data_ptr(),
                                       d_start.data_ptr(), d_np.data_ptr(), d_st.data_ptr())
 
+        gpu.set_ror_mode(1)
+        try:
+            ms_two = timed(fused, stream, vreps, sync)
+        finally:
+            gpu.set_ror_mode(0)
         ms = timed(fused, stream, vreps, sync)
         cells = int(d_cursor.item())
-        c5["fused_grid"] = {"ms": round(ms, 4), "gpts_s": round(B * n / ms / 1e6, 1),
+        c5["fused_grid"] = {"ms": round(ms, 4), "ms_two_kernels": round(ms_two, 4),
+                            "gpts_s": round(B * n / ms / 1e6, 1),
                             "frac": round((8 * B * n + 16 * cells) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "cells": cells, "status_bits": int(d_st[: B // 8].max().item()),
                             "workload": "the same scans, de-skewed + posed, one voxel grid per time step "
