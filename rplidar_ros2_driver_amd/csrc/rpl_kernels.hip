@@ -606,11 +606,24 @@ __global__ __launch_bounds__(kAscT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         const bool sc = i + 1u < nm && (W || nc.x != c.x || nc.y != c.y);
         // (a run of invalid nodes changes both nodes of most of its pairs: one 16-byte store then — the
         // pair is 16-byte aligned when W is even)
-        if (sa && sc && !(W & 1u)) {
-          *reinterpret_cast<uint4 *>(&scan[i + W]) = make_uint4(na.x, na.y, nc.x, nc.y);
-        } else {
-          if (sa) scan[i + W] = na;
-          if (sc) scan[i + 1u + W] = nc;
+        // Whole 128-byte lines (eight lanes' pairs) wherever one of their nodes changed (round 6: partial-line
+        // writes of scattered 8- and 16-byte pieces cost +-3 words of jitter 9 %); a wave with nothing to
+        // store skips all of it.
+        const uint64_t chg = __builtin_amdgcn_ballot_w64(sa || sc);
+        if (chg != 0ull) {  // wave-uniform
+          uint64_t g = W ? 0ull : chg;
+          g |= g >> 4;
+          g |= g >> 2;
+          g |= g >> 1;
+          g = (g & 0x0101010101010101ull) * 0xFFull;
+          if (__builtin_amdgcn_inverse_ballot_w64(g) && i + 1u < nm) {
+            *reinterpret_cast<uint4 *>(&scan[i]) = make_uint4(na.x, na.y, nc.x, nc.y);
+          } else if (sa && sc && !(W & 1u)) {
+            *reinterpret_cast<uint4 *>(&scan[i + W]) = make_uint4(na.x, na.y, nc.x, nc.y);
+          } else {
+            if (sa) scan[i + W] = na;
+            if (sc) scan[i + 1u + W] = nc;
+          }
         }
       }
       // what is left out of order inside the chunk after the repair (nothing, normally)
