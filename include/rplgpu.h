@@ -351,8 +351,9 @@ int32_t rplgpu_set_voxel_aggregation(rplgpu_handle_t h, int32_t mode);
  * work item with more open samples than that (clutter: > 256 after the index test or > 8 after the
  * window) is redone by the two kernels of TWO_KERNELS behind the launch.  TWO_KERNELS: k_ror_mask
  * writes one keep bit per sample, the voxel kernel reads the scan again with the mask (rounds 1-5;
- * also what rplgpu_cloud_batch_dev and the single-scan calls use, and any launch whose divides were
- * not validated on this device). */
+ * also what any launch uses whose divides were not validated on this device, and the single-scan call
+ * rplgpu_scan_to_cloud below 8192 samples, where index neighbours are mostly farther apart than the
+ * radius).  rplgpu_cloud_batch_dev (per-scan regions) follows the mode as well. */
 #define RPLGPU_ROR_INSIDE 0
 #define RPLGPU_ROR_TWO_KERNELS 1
 int32_t rplgpu_set_ror_mode(rplgpu_handle_t h, int32_t mode);

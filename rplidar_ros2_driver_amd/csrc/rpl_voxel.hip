@@ -121,6 +121,7 @@ static_assert(kVWG != 2 || sizeof(VoxelLds) <= 80u * 1024u, "two workgroups per 
 
 // E5 inside the voxel kernel (the ROR instance, round 6): what the streaming pass leaves for the
 // exact steps behind it — the samples whose index neighbours did not settle them.
+constexpr uint32_t kRorListedBit = 0x80000000u;  // status of a work item left to the two kernels (internal; == rplgpu_api.hip)
 constexpr uint32_t kRorTodoCap = 256;  // unsettled samples of a scan the kernel resolves itself
 constexpr uint32_t kRorFewCap = 8;     // ... of which may still be unsettled after the +-64 window
 struct RorSide {
@@ -1256,7 +1257,14 @@ __device__ __forceinline__ void voxel_work_loop(VoxelLds &L, const KParams &p, c
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();  // (workgroup-scope release / acquire: covers the record store too)
       if (RORM == 1 && abandoned) {  // block-uniform: left to the two-kernel path
-        if (threadIdx.x == 0) T.redo[4u + atomicAdd(&T.redo[0], 1u)] = b;
+        if (threadIdx.x == 0) {
+          T.redo[4u + atomicAdd(&T.redo[0], 1u)] = b;
+          // (what a caller sees who looks before the listed launches ran — the single-scan entry points
+          // do, instead of launching them blind: no points and the internal "listed" bit)
+          n_points[b] = 0u;
+          if (status) status[b] = kRorListedBit;
+          if (arena.base) arena.scan_start[b] = 0ull;
+        }
         break;
       }
       pc.lap(0);
@@ -1710,7 +1718,7 @@ hipError_t launch_cloud_voxel(hipStream_t s, const void *nodes, uint32_t n_strid
                               uint32_t group, const float *motion, const float *pose2d,
                               bool arena_xyi, int ror_mode) {
   if (B == 0) return hipSuccess;
-  if (ror_mode && (!p.fast_div || !T.redo || !arena || p.dbg)) return hipErrorInvalidValue;
+  if (ror_mode && (!p.fast_div || !T.redo || p.dbg)) return hipErrorInvalidValue;
   if (ror_mode == 2 && !keepmask) return hipErrorInvalidValue;
   if (group == 0) group = 1;
   group = std::min(group, B);  // (a group larger than the batch is the whole batch)

@@ -837,22 +837,28 @@ static int32_t prepare_cloud(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, ui
 // samples than that (clutter: hundreds of isolated returns) is put on a list instead, and the two
 // kernels of rounds 1-5 — k_ror_mask, then the voxel kernel with the mask — run over the LISTED
 // items behind it: two launches that find an empty list on ring-like data and end at once.
+// (d_arena null: per-scan regions d_xyzi + b * out_stride, rplgpu_cloud_batch_dev.  `defer_listed`: the two
+// launches over the list are left to the caller, who looks at the status word first — the single-scan
+// entry points wait for their one scan anyway and redo it only if it carries kRorListed.)
+constexpr uint32_t kRorListed = 0x80000000u;  // internal status bit (== rpl_voxel.hip kRorListedBit)
 static int32_t voxel_with_ror(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
                               const uint32_t *d_n_per_scan, uint32_t B, const rpl::KParams &kp,
                               const rpl::Tables &T, uint32_t *d_n_points, uint32_t *d_status,
                               float *d_arena, uint64_t arena_capacity, uint64_t *d_cursor,
                               uint64_t *d_start, uint32_t group, const float *d_motion,
-                              const float *d_pose2d, bool xyi) {
+                              const float *d_pose2d, bool xyi, float *d_xyzi = nullptr,
+                              uint32_t out_stride = 0, bool defer_listed = false) {
   RPL_HIP(h, hipMemsetAsync(h->d_redo, 0, 4, h->stream));
   RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, T, nullptr,
-                                     kMaskStride, nullptr, 0, d_n_points, d_status, d_arena,
+                                     kMaskStride, d_xyzi, out_stride, d_n_points, d_status, d_arena,
                                      arena_capacity, reinterpret_cast<unsigned long long *>(d_cursor),
                                      reinterpret_cast<unsigned long long *>(d_start), group, d_motion,
                                      d_pose2d, xyi, 1));
+  if (defer_listed) return RPLGPU_OK;
   RPL_HIP(h, rpl::launch_ror_mask(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, T, h->d_rormask,
                                   kMaskStride, true, std::max(1u, std::min(group, B))));
   RPL_HIP(h, rpl::launch_cloud_voxel(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, T, h->d_rormask,
-                                     kMaskStride, nullptr, 0, d_n_points, d_status, d_arena,
+                                     kMaskStride, d_xyzi, out_stride, d_n_points, d_status, d_arena,
                                      arena_capacity, reinterpret_cast<unsigned long long *>(d_cursor),
                                      reinterpret_cast<unsigned long long *>(d_start), group, d_motion,
                                      d_pose2d, xyi, 2));
@@ -970,22 +976,38 @@ int32_t rplgpu_cloud_fused_voxel_dev(rplgpu_handle_t h, const rplgpu_node_t *d_n
   return RPLGPU_OK;
 }
 
-int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
-                               const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
-                               float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,
-                               uint32_t *d_status) {
+// `defer_listed`: see voxel_with_ror (single-scan callers; d_status must be given then)
+static int32_t cloud_batch_impl(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
+                                const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
+                                float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,
+                                uint32_t *d_status, bool defer_listed) {
   int32_t rc = check_batch(h, d_nodes, n_stride, d_n_per_scan, B);
   if (rc) return rc;
   if (!p || !d_xyzi || !d_n_points || out_stride == 0) return RPLGPU_ERR_INVALID_ARG;
   rpl::KParams kp;
   const uint32_t *mask = nullptr;
-  if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask))) return rc;
+  bool ror_inside = false;
+  if ((rc = prepare_cloud(h, d_nodes, n_stride, d_n_per_scan, B, p, &kp, &mask,
+                          p->voxel_enable ? &ror_inside : nullptr)))
+    return rc;
   rpl::Tables T_batch = tables_of(h);
   if (p->voxel_enable) T_batch.voxel_split = voxel_split_for(h, d_nodes, n_stride, B, 1u) ? 1 : 0;
+  if (ror_inside)
+    return voxel_with_ror(h, d_nodes, n_stride, d_n_per_scan, B, kp, T_batch, d_n_points, d_status, nullptr, 0,
+                          nullptr, nullptr, 1u, nullptr, nullptr, false, d_xyzi, out_stride,
+                          defer_listed && d_status);
   RPL_HIP(h, rpl::launch_cloud(h->stream, d_nodes, n_stride, d_n_per_scan, B, kp, T_batch,
                                p->voxel_enable != 0, mask, kMaskStride, d_xyzi, out_stride,
                                d_n_points, d_status));
   return RPLGPU_OK;
+}
+
+int32_t rplgpu_cloud_batch_dev(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
+                               const uint32_t *d_n_per_scan, uint32_t B, const rplgpu_params_t *p,
+                               float *d_xyzi, uint32_t out_stride, uint32_t *d_n_points,
+                               uint32_t *d_status) {
+  return cloud_batch_impl(h, d_nodes, n_stride, d_n_per_scan, B, p, d_xyzi, out_stride, d_n_points, d_status,
+                          false);
 }
 
 int32_t rplgpu_pack_clouds_dev(rplgpu_handle_t h, const float *d_xyzi, uint32_t out_stride,
@@ -1114,14 +1136,33 @@ int32_t rplgpu_scan_to_cloud(rplgpu_handle_t h, const rplgpu_node_t *nodes, size
     // the handle's own staging)
     const bool chk = h->check_ptrs;
     h->check_ptrs = false;
-    const int32_t rc = rplgpu_cloud_batch_dev(h, d_in, (uint32_t)n, d_in_n, 1, p,
-                                              reinterpret_cast<float *>(st.d_out), (uint32_t)n,
-                                              d_words, d_words + 1);
+    // (E5 + E4: the voxel kernel applies E5 itself, round 6; a scan it cannot settle comes back with the
+    // internal "listed" status and is redone by the two kernels — this call waits for its scan anyway)
+    // (Only for dense scans: below ~8 k samples per revolution the index neighbours of a sample are mostly
+    // farther away than r — 360 samples at 10 m are 17 cm apart — the kernel gives the scan up at once and
+    // the call would pay for both paths: 87 against 59 us at 360 samples, 61 against 73 us at 32 000.)
+    const int32_t fused_keep = h->ror_fused;
+    if (n < 8192u) h->ror_fused = 0;
+    int32_t rc = cloud_batch_impl(h, d_in, (uint32_t)n, d_in_n, 1, p, reinterpret_cast<float *>(st.d_out),
+                                  (uint32_t)n, d_words, d_words + 1, true);
+    h->ror_fused = fused_keep;
     h->check_ptrs = chk;
     if (rc) return rc;
     if (int32_t wrc = wait_scan(h)) return wrc;
     uint32_t w[2];
     std::memcpy(w, st.h_out + n * 16, 8);
+    if (w[1] & kRorListed) {
+      const int32_t keep = h->ror_fused;
+      h->ror_fused = 0;
+      h->check_ptrs = false;
+      rc = cloud_batch_impl(h, d_in, (uint32_t)n, d_in_n, 1, p, reinterpret_cast<float *>(st.d_out), (uint32_t)n,
+                            d_words, d_words + 1, false);
+      h->check_ptrs = chk;
+      h->ror_fused = keep;
+      if (rc) return rc;
+      if (int32_t wrc = wait_scan(h)) return wrc;
+      std::memcpy(w, st.h_out + n * 16, 8);
+    }
     *n_points = w[0];
     if (status) *status = w[1];
     std::memcpy(xyzi, st.h_out, (size_t)w[0] * 16);

@@ -181,3 +181,59 @@ def test_groups_sharing_one_grid(gpu, group):
     assert listed >= 1
     _, listed = _both(gpu, batch, [n] * B, p, group=group)  # no transform: identity
     assert listed >= 1
+
+
+def test_per_scan_regions_and_single_scan_calls(gpu, oracle):
+    """rplgpu_cloud_batch_dev (per-scan regions) and the single-scan entry point rplgpu_scan_to_cloud with
+    E5 + E4: both modes give the same cloud — on a ring (settled inside the kernel), on a ring with more
+    isolated returns than the kernel counts itself and on random ranges (both handed to the two kernels: the
+    single-scan call sees the internal "listed" status and redoes the scan, the batch call launches them
+    behind the kernel) — and the short ones equal the oracle's."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 9000  # (the single-scan call runs E5 inside the kernel from 8192 samples on)
+    scans = [synth.make_scan(41, 0, n, noise_m=0.01), _ring_with_outliers(42, n, 12),
+             synth.make_scan(43, 0, n, kind="uniform"), synth.make_scan(44, 0, 360, noise_m=0.005, r0_range=(1, 3)),
+             synth.make_scan(45, 0, 1, noise_m=0.0)]
+    p = Params.defaults(**P_C5)
+    for s in scans:
+        res = []
+        for mode in (0, 1):
+            gpu.set_ror_mode(mode)
+            try:
+                cloud, st = gpu.scan_to_cloud(s, p)
+            finally:
+                gpu.set_ror_mode(0)
+            assert st == 0, hex(st)
+            res.append(cloud.tobytes())
+        assert res[0] == res[1]
+        if len(s) <= 9000:
+            ref, _, _ = oracle.cloud_pipeline(s, oracle_lib.copy_params(p))
+            got = np.frombuffer(res[0], np.float32).reshape(-1, 4)
+            assert len(ref) == len(got)
+            assert np.abs(ref[:, :2] - got[:, :2]).max(initial=0.0) <= 1e-6
+            assert np.array_equal(ref[:, 3], got[:, 3])
+    # the batch call over per-scan regions
+    B = 4
+    batch = np.stack([np.resize(s, n) if len(s) >= n else np.concatenate([s, np.zeros(n - len(s), s.dtype)])
+                      for s in scans[:B]])
+    lens = np.array([min(len(s), n) for s in scans[:B]], np.int32)
+    out = []
+    for mode in (0, 1):
+        gpu.set_ror_mode(mode)
+        try:
+            d_nodes = torch.from_numpy(batch.view(np.uint8).reshape(B, n * 8)).to(dev)
+            d_len = torch.from_numpy(lens).to(dev)
+            d_xyzi = torch.zeros(B, n, 4, dtype=torch.float32, device=dev)
+            d_np = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            d_st = torch.full((B,), -1, dtype=torch.int32, device=dev)
+            gpu.cloud_batch_dev(d_nodes.data_ptr(), n, d_len.data_ptr(), B, p, d_xyzi.data_ptr(), n,
+                                d_np.data_ptr(), d_st.data_ptr())
+            gpu.synchronize()
+            npts = d_np.cpu().numpy()
+            assert int(d_st.cpu().numpy().max()) == 0 and npts.min() >= 0
+            x = d_xyzi.cpu().numpy()
+            out.append([x[b, :npts[b]].tobytes() for b in range(B)])
+        finally:
+            gpu.set_ror_mode(0)
+    assert out[0] == out[1]
