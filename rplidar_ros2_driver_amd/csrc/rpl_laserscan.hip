@@ -43,6 +43,20 @@ __device__ __forceinline__ float ls_div(float a, float d, float rd) {
   return fmaf(e, rd, q);
 }
 
+// angle_rad of a sample COMPUTED instead of gathered (round 6).  The reference's expressions
+// (src/rplidar_node.cpp:588-589): angle_deg = q14 * 90.0f / 16384.0f is exact in fp32 (q14 * 45 has 22 bits,
+// the rest is a power of two), angle_rad = (float)((double)angle_deg * (M_PI / 180.0f)) is one fp64 multiply
+// by the same constant and one rounding to fp32 — IEEE operations the device has.  The wraps of :594-599
+// never fire for a u16 input.  Like the cheap divides this is not taken on faith: k_validate_idx compares it
+// with the host-built table for every angle word on this device, and only then (FAST) is it used.  It takes
+// the 32 table gathers per lane out of the conversion step, which was bound by their issue rate (512 wave
+// gathers per scan at ~30 cycles each: 15.4 k of the 65 k cycles a scan takes).  The inverted table
+// (:646-651: one more fp64 subtraction, a compare and a second one near angle 0) stays a gather.
+__device__ __forceinline__ float ls_angle(uint32_t q14) {
+  const float deg = (float)q14 * 0.0054931640625f;  // q14 * 90.0f / 16384.0f, exact
+  return (float)((double)deg * (M_PI / 180.0f));
+}
+
 // PAIRS: the sample pairs a lane works on.  Pair j of a lane holds samples 2 * (1024 j + lane)
 // and the next one, so a scan of n samples only reaches the first ceil(n / 2048) pairs; the batch
 // entry points use all 16, a single-scan call (its length is a launch argument) the instance that
@@ -50,7 +64,8 @@ __device__ __forceinline__ float ls_div(float a, float d, float rd) {
 // 16 waves converting 32 mostly all-zero samples per lane were most of the kernel: 21 -> 16 us per
 // call at 360 samples, 24 -> 20 at 3200.
 // MSG: the (single) scan goes straight into its serialised message (LsMsgOut, rpl_launch.hpp).
-template <bool FAST, int PAIRS, bool MSG>
+// ANG: angles computed (ls_angle) instead of gathered: FAST launches with the non-inverted table.
+template <bool FAST, int PAIRS, bool MSG, bool ANG = false>
 __global__ __launch_bounds__(kBlock) void k_laserscan_a(
     const uint2 *__restrict__ nodes, uint32_t n_stride, const uint32_t *__restrict__ n_per_scan,
     KParams p, Tables T, const float *__restrict__ inc_table, const float *__restrict__ rinc_table,
@@ -152,7 +167,8 @@ __global__ __launch_bounds__(kBlock) void k_laserscan_a(
 #pragma unroll
   for (int j = 0; j < PAIRS; ++j) {
     const uint4 ww = w[j];
-    const float aA = lut[ww.x & 0xFFFFu], aB = lut[ww.z & 0xFFFFu];
+    const float aA = ANG ? ls_angle(ww.x & 0xFFFFu) : lut[ww.x & 0xFFFFu];
+    const float aB = ANG ? ls_angle(ww.z & 0xFFFFu) : lut[ww.z & 0xFFFFu];
     const float tA = FAST ? ls_div(aA, inc, rinc) : aA / inc;  // :653-654 (angle - 0.0f == angle)
     const float tB = FAST ? ls_div(aB, inc, rinc) : aB / inc;
     uint32_t iA = (uint32_t)(int)tA, iB = (uint32_t)(int)tB;
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(256) void k_validate_idx(const float *__restrict__ 
   uint32_t bad = 0;
   for (uint32_t q = threadIdx.x; q < 65536u; q += 256u) {
     const float a0 = angle[q], a1 = angle_inv[q];
+    if (c == 1u) bad += (__float_as_uint(ls_angle(q)) != __float_as_uint(a0));  // (once: block 0 checks ls_angle)
     bad += ((int)ls_div(a0, inc, rinc) != (int)(a0 / inc));
     bad += ((int)ls_div(a1, inc, rinc) != (int)(a1 / inc));
   }
@@ -252,16 +269,18 @@ hipError_t launch_laserscan_a(hipStream_t s, const void *nodes, uint32_t n_strid
   const bool to_msg = msg_out != nullptr;
   if (to_msg && !(B == 1u && fast)) return hipErrorInvalidValue;
   const LsMsgOut mo = to_msg ? *msg_out : LsMsgOut{};
+  const bool ang = fast && !p.inverted;  // (see ls_angle)
+#define RPL_LAUNCH_LS_A(F, P, M, A)                                                                 \
+  hipLaunchKernelGGL((k_laserscan_a<F, P, M, A>), dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, \
+                     n_stride, n_per_scan, p, T, inc_table, rinc_table, ranges, intens, beam_count,  \
+                     n_given, mo)
 #define RPL_LAUNCH_LS(F, P)                                                                         \
   do {                                                                                              \
-    if (F && to_msg)                                                                                \
-      hipLaunchKernelGGL((k_laserscan_a<F, P, F>), dim3(B), dim3(kBlock), 0, s, (const uint2 *)nodes, \
-                         n_stride, n_per_scan, p, T, inc_table, rinc_table, ranges, intens,        \
-                         beam_count, n_given, mo);                                                  \
-    else                                                                                            \
-      hipLaunchKernelGGL((k_laserscan_a<F, P, false>), dim3(B), dim3(kBlock), 0, s,                \
-                         (const uint2 *)nodes, n_stride, n_per_scan, p, T, inc_table, rinc_table,   \
-                         ranges, intens, beam_count, n_given, mo);                                  \
+    if (F && to_msg) {                                                                              \
+      if (ang) RPL_LAUNCH_LS_A(F, P, F, F); else RPL_LAUNCH_LS_A(F, P, F, false);                   \
+    } else {                                                                                        \
+      if (F && ang) RPL_LAUNCH_LS_A(F, P, false, F); else RPL_LAUNCH_LS_A(F, P, false, false);      \
+    }                                                                                               \
   } while (0)
 #define RPL_LAUNCH_LS_P(F)                      \
   do {                                          \
@@ -274,6 +293,7 @@ hipError_t launch_laserscan_a(hipStream_t s, const void *nodes, uint32_t n_strid
   if (fast) RPL_LAUNCH_LS_P(true); else RPL_LAUNCH_LS_P(false);
 #undef RPL_LAUNCH_LS_P
 #undef RPL_LAUNCH_LS
+#undef RPL_LAUNCH_LS_A
   return hipGetLastError();
 }
 

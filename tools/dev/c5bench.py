@@ -70,13 +70,16 @@ def timed(fn):
 
 p_ror = p
 p = Params.defaults(clip_enable=1, q_min=0, range_min=0.15, range_max=40.0, voxel_enable=1, voxel_leaf=0.05)
-print(f"lib={Path(os.environ.get('RPLGPU_LIBRARY', 'default')).name} without E5: arena {timed(arena):.4f} ms, "
-      f"fused grid {timed(fused):.4f} ms", flush=True)
-p = Params.defaults(clip_enable=1, q_min=1, range_min=0.15, range_max=40.0, voxel_enable=1, voxel_leaf=0.05)
-print(f"  without E5, q_min 1 (quality test + FILL pass): arena {timed(arena):.4f} ms", flush=True)
+if not os.environ.get("C5_ONLY"):
+    print(f"lib={Path(os.environ.get('RPLGPU_LIBRARY', 'default')).name} without E5: arena {timed(arena):.4f} ms, "
+          f"fused grid {timed(fused):.4f} ms", flush=True)
+    p = Params.defaults(clip_enable=1, q_min=1, range_min=0.15, range_max=40.0, voxel_enable=1, voxel_leaf=0.05)
+    print(f"  without E5, q_min 1 (quality test + FILL pass): arena {timed(arena):.4f} ms", flush=True)
 p = p_ror
 for rnd in range(int(os.environ.get("C5_ROUNDS", "2"))):
     for name, fn in (("c5 arena", arena), ("fused grid x8", fused)):
+        if os.environ.get("C5_ONLY") and os.environ["C5_ONLY"] not in name:
+            continue
         row = []
         for mode in (0, 1):
             gpu.set_ror_mode(mode)
