@@ -134,6 +134,10 @@ def test_mixed_batch_ragged_lengths_and_k(gpu):
         for radius in (0.03, 0.25):
             p = Params.defaults(**{**P_C5, "ror_min_neighbors": k, "ror_radius": radius})
             _both(gpu, batch, lens, p)
+    # the corners: no neighbour asked for, a radius nobody reaches, a radius everybody reaches
+    for k, radius in ((0, 0.10), (2, 1e-4), (3, 50.0), (64, 50.0)):
+        p = Params.defaults(**{**P_C5, "ror_min_neighbors": k, "ror_radius": radius})
+        _both(gpu, batch, lens, p)
     # the quality filter in front of E5
     p = Params.defaults(**{**P_C5, "q_min": 100})
     _both(gpu, batch, lens, p)
