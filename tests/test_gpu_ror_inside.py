@@ -241,3 +241,39 @@ def test_per_scan_regions_and_single_scan_calls(gpu, oracle):
         finally:
             gpu.set_ror_mode(0)
     assert out[0] == out[1]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RPL_FUZZ_SEEDS", "12"))))
+def test_fuzz_inside_against_two_kernels_and_oracle(gpu, oracle, seed):
+    """Random batches — the scans of tests/test_gpu_fuzz.py (any order of angle words, any u32 as a distance,
+    points on cell faces, clip bounds, heavy drop-outs, lengths 1 .. 4000) plus dense noisy rings — with random
+    E1 / E5 / E4 parameters through the arena entry point: E5 inside the kernel equals the two kernels byte for
+    byte, and every scan equals the oracle's pipeline."""
+    from tests.test_gpu_fuzz import LEAVES, _random_scan
+    rng = np.random.default_rng(424200 + seed)
+    scans = [_random_scan(rng) for _ in range(10)]
+    scans += [synth.make_scan(int(rng.integers(1 << 30)), 0, int(rng.integers(500, 4000)),
+                              noise_m=float(rng.choice([0.0, 0.005, 0.03])), r0_range=(0.3, 12.0)) for _ in range(4)]
+    n = max(len(s) for s in scans)
+    B = len(scans)
+    batch = np.zeros((B, n), scans[0].dtype)
+    for b, s_ in enumerate(scans):
+        batch[b, :len(s_)] = s_
+    lens = [len(s_) for s_ in scans]
+    for it in range(3):
+        p = Params.defaults(is_new_protocol=int(rng.integers(0, 2)), inverted=int(rng.integers(0, 2)), clip_enable=1,
+                            q_min=int(rng.choice([0, 1, 40, 255])), range_min=float(rng.choice([0.15, 0.0, 0.5])),
+                            range_max=float(rng.choice([12.0, 40.0, 8.0])), voxel_enable=1,
+                            voxel_leaf=float(LEAVES[int(rng.integers(0, len(LEAVES)))]), ror_enable=1,
+                            ror_radius=float(rng.choice([0.1, 0.05, 0.5, 2.0])),
+                            ror_min_neighbors=int(rng.integers(0, 5)))
+        (clouds, npts, st, arena, start), _ = _both(gpu, batch, lens, p)
+        assert int(st.max()) == 0, f"seed {seed} it {it}"
+        for b, s_ in enumerate(scans):
+            want, _, _ = oracle.cloud_pipeline(s_, oracle_lib.copy_params(p))
+            got = np.frombuffer(clouds[b], np.float32).reshape(-1, 4)
+            ctx = f"seed {seed} it {it} scan {b} n {len(s_)}"
+            assert len(got) == len(want), ctx
+            if len(want):
+                assert np.max(np.abs(got[:, :2].astype(np.float64) - want[:, :2])) <= 1e-6, ctx
+                assert got[:, 3].tobytes() == want[:, 3].tobytes(), ctx
