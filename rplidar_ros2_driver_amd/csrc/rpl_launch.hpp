@@ -51,6 +51,9 @@ hipError_t launch_validate_idx(hipStream_t s, const Tables &T, const float *inc_
 hipError_t launch_laserscan_raw(hipStream_t s, const void *nodes, uint32_t n_stride,
                                 const uint32_t *n_per_scan, uint32_t B, const KParams &p,
                                 float *ranges, float *intens, uint32_t *beam_count);
+// status of a work item the voxel kernel's ROR instance left to the two kernels (internal: the listed launches
+// overwrite it; the single-scan entry points look for it instead of launching them blind)
+constexpr uint32_t kRorListedBit = 0x80000000u;
 // `keepmask` (optional): one bit per sample from launch_ror_mask, `mask_stride` words per scan.
 hipError_t launch_cloud(hipStream_t s, const void *nodes, uint32_t n_stride,
                         const uint32_t *n_per_scan, uint32_t B, const KParams &p, const Tables &T,

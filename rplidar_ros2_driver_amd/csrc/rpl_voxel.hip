@@ -121,7 +121,6 @@ static_assert(kVWG != 2 || sizeof(VoxelLds) <= 80u * 1024u, "two workgroups per 
 
 // E5 inside the voxel kernel (the ROR instance, round 6): what the streaming pass leaves for the
 // exact steps behind it — the samples whose index neighbours did not settle them.
-constexpr uint32_t kRorListedBit = 0x80000000u;  // status of a work item left to the two kernels (internal; == rplgpu_api.hip)
 constexpr uint32_t kRorTodoCap = 256;  // unsettled samples of a scan the kernel resolves itself
 constexpr uint32_t kRorFewCap = 8;     // ... of which may still be unsettled after the +-64 window
 struct RorSide {

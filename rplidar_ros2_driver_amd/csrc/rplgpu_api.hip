@@ -840,7 +840,7 @@ static int32_t prepare_cloud(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, ui
 // (d_arena null: per-scan regions d_xyzi + b * out_stride, rplgpu_cloud_batch_dev.  `defer_listed`: the two
 // launches over the list are left to the caller, who looks at the status word first — the single-scan
 // entry points wait for their one scan anyway and redo it only if it carries kRorListed.)
-constexpr uint32_t kRorListed = 0x80000000u;  // internal status bit (== rpl_voxel.hip kRorListedBit)
+constexpr uint32_t kRorListed = rpl::kRorListedBit;
 static int32_t voxel_with_ror(rplgpu_handle_t h, const rplgpu_node_t *d_nodes, uint32_t n_stride,
                               const uint32_t *d_n_per_scan, uint32_t B, const rpl::KParams &kp,
                               const rpl::Tables &T, uint32_t *d_n_points, uint32_t *d_status,
