@@ -35,6 +35,14 @@
 // Otherwise the LDS part joins the rest in the store and the key range is bisected until a band
 // fits; every band re-reads the RECORDS (16 B per run, from L2), not the scan.
 //
+// E5 (radius outlier removal) INSIDE the pass — the ROR instance of the kernel (round 6; config 5 reads a scan
+// once): a block owns 124 of the 128 samples it reads, a kept sample with `ror_k` of its four nearest indices
+// within r survives at once (four distance tests per lane, the lane-behind operands by DPP, the counts from
+// the scalar compare masks), one without is run past the wave's 128 samples, then listed for ror_resolve
+// (64 indices either side, then the whole scan); a sample settled late joins the queue as a record of its
+// own.  A scan with more open samples than that is handed to k_ror_mask + this kernel's masked instance
+// through a list of work items (RORM 1 / 2 below; rplgpu_api.hip voxel_with_ror).
+//
 // Fixed point: offset = (x - ix*leaf) * 2^K with 2^-K = ulp(leaf) (K = 28 for 5 cm), summed as
 // wrapping 32-bit integers (a block prefix stays below 2^32; the tiny negative offsets of a
 // quotient that rounded up to the next integer are recognised by their top bits when a run sum
